@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the MI355X-native Clair3 inference path (BASELINE.json metric:
+candidate-windows/sec, pileup + full-alignment).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (c3_predict_device: every kernel of the forward pass) over one batch of
+synthetic candidate windows already resident in HBM, plus -- for N > 1 -- the RCCL gather of the (B, 24|90)
+probability rows to rank 0.  One process per GPU, windows sharded with no data-path collective
+(weak scaling: every GPU gets the configured batch).  Rank 0 prints ONE JSON line:
+
+  value        whole-job candidate-windows/s of the headline workload = BASELINE.json configs[2]
+               "ONT r10.4.1 full-alignment model, synthetic (B=256, 89, 33, 8)" (the path the north-star target
+               is quoted on); the same measurement for configs[1] (pileup, B=1024) is in "pileup";
+  roofline     dominant kernel family (implicit-GEMM 3x3 convolutions on v_mfma_f32_32x32x2_f32), HIP-event
+               timed per launch on the launch stream in a second, profiled pass over the same steps;
+               achieved = algorithmic FLOP (2*MACs of the reference layer shapes) / kernel time;
+  cpu_baseline the reference CPU path's arithmetic (oracle/torch_port.py: the same ATen operators the
+               reference modules call) timed on this node's host cores, rank 0, N=1 only, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (kind, batch, channels, add_indel_length, FLOP/window, algorithmic bytes/window, BASELINE.json config)
+    "full_alignment": ("full_alignment", 256, 8, True, 451538432, 23856,
+                       "configs[2]: ONT r10.4.1 full-alignment model, synthetic (B=256, 89, 33, 8) int8, 1xMI355X"),
+    "pileup": ("pileup", 1024, 18, False, 47785984, 690,
+               "configs[1]: ONT r10.4.1 pileup model, synthetic (B=1024, 33, 18) [= (1024, 33, 594/33)] int8, 1xMI355X"),
+    "full_alignment_dwell": ("full_alignment", 256, 9, True, 452419712, 26793,
+                             "configs[4]: ONT --enable_dwell_time full-alignment, synthetic (B=256, 89, 33, 9) int8"),
+}
+
+
+def build_model(kind, channels, indel, device):
+    from clair3_amd import synthetic as syn
+    from clair3_amd.model import Clair3_F, Clair3_P
+    cls = Clair3_P if kind == syn.PILEUP else Clair3_F
+    m = cls(add_indel_length=indel, predict=True, input_channels=channels).to(device)
+    m.eval()
+    sd = syn.make_state_dict(kind, channels, indel, seed=0)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def run_workload(name, args, rank, world, local):
+    import torch
+    import torch.distributed as dist
+    from clair3_amd import dist as c3dist, synthetic as syn
+    kind, batch, channels, indel, flop_w, bytes_w, cfg = WORKLOADS[name]
+    if args.batch:
+        batch = args.batch
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    model, sd = build_model(kind, channels, indel, local)
+    x_host = syn.make_windows(kind, batch, seed=1000 + rank, channels=channels)
+    x = torch.from_numpy(x_host).to(dev)  # inputs resident in HBM before the timed region
+    n_total = batch * world
+
+    def step():
+        y = model(x)  # c3_predict_device on torch's current stream
+        if world > 1:
+            return c3dist.gather_rows(y, n_total, dst=0)
+        return y
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        assert out is not None and out.shape == (n_total, 90 if indel else 24)
+        assert bool(torch.isfinite(out).all())
+    res = {
+        "workload": cfg, "batch_per_gpu": batch, "windows_per_step": n_total,
+        "value": n_total * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+        "flop_per_window": flop_w, "bytes_per_window": bytes_w,
+    }
+
+    # ---- second, profiled pass: HIP events around every kernel launch on the launch stream ----
+    model.profile(True)
+    model.profile_reset()
+    for _ in range(args.steps):
+        model(x)
+    torch.cuda.synchronize()
+    stats = model.profile_read()
+    model.profile(False)
+    res["kernels"] = {r["name"]: {"launches": r["launches"], "avg_us": 1e3 * r["total_ms"] / r["launches"],
+                                  "tflops": r["flops"] / r["total_ms"] / 1e9 if r["total_ms"] > 0 else None}
+                      for r in stats}
+    if kind == syn.FULL_ALIGNMENT:
+        dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res"))]
+        dom_name = "gemm_mfma_kernel<ConvLoader/Conv1Loader> (9 implicit-GEMM 3x3 conv launches per step)"
+    else:
+        dom = [r for r in stats if r["name"].startswith("p.lstm")]
+        dom_name = "lstm_recurrent_kernel<128|160> (2 launches per step)"
+    ms = sum(r["total_ms"] for r in dom)
+    fl = sum(r["flops"] for r in dom)
+    launches = sum(r["launches"] for r in dom)
+    achieved = fl / ms / 1e9 if ms > 0 else 0.0
+    res["roofline"] = {
+        "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom_name,
+        "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
+        "share_of_step_time": ms / max(sum(r["total_ms"] for r in stats), 1e-9),
+        "whole_forward_frac": res["value"] / world * flop_w / (FP32_MFMA_PEAK_TFLOPS * 1e12),
+        "hbm_algorithmic_gbs": res["value"] / world * bytes_w / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
+    }
+    res["_sd"], res["_x"], res["_kind"], res["_indel"] = sd, x_host, kind, indel
+    return res
+
+
+def cpu_baseline(res, budget_s):
+    """Reference CPU arithmetic on this node's host cores (rank 0, N=1): bounded sample of the same workload."""
+    import torch
+    from oracle import torch_port
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    kind, indel = res["_kind"], res["_indel"]
+    sd = torch_port.to_torch(res["_sd"])
+    x = torch.from_numpy(res["_x"])
+    kw = {"lstms": torch_port.make_lstms(sd)} if kind == "pileup" else {}
+    torch_port.forward(kind, sd, x[: max(1, len(x) // 4)], indel, **kw)  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start < budget_s or not times):
+        t0 = time.perf_counter()
+        torch_port.forward(kind, sd, x, indel, **kw)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": len(x) / med, "unit": "candidate-windows/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} x one batch of {len(x)} windows, median; oracle/torch_port.py = the ATen/oneDNN "
+                      f"operators the reference modules call, torch.set_num_threads({cores}), torch {torch.__version__}",
+            "ms_per_batch": 1e3 * med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="all", choices=["all"] + list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/experiments only)")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from clair3_amd import dist as c3dist
+    rank, world, local = c3dist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+
+    names = ["full_alignment", "pileup"] if args.workload == "all" else [args.workload]
+    results = {n: run_workload(n, args, rank, world, local) for n in names}
+    head = results[names[0]]
+
+    if rank == 0:
+        line = {
+            "metric": "candidate-windows/sec", "value": head["value"], "unit": "candidate-windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": head["workload"], "batch_per_gpu": head["batch_per_gpu"],
+                       "windows_per_step": head["windows_per_step"], "weights": "seeded random (no checkpoints offline)",
+                       "sharding": f"windows x{world}, gather of probability rows to rank 0" if world > 1 else "single GPU",
+                       "inputs": "resident in HBM before the timed region"},
+            "roofline": head["roofline"], "kernels": head["kernels"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(head, args.cpu_budget)
+            line["speedup_vs_cpu_baseline"] = head["value"] / line["cpu_baseline"]["value"]
+        for n in names[1:]:
+            r = results[n]
+            sub = {"value": r["value"], "unit": "candidate-windows/s", "ms_per_step": r["ms_per_step"],
+                   "config": {"workload": r["workload"], "batch_per_gpu": r["batch_per_gpu"]},
+                   "roofline": r["roofline"], "kernels": r["kernels"]}
+            if world == 1 and not args.no_cpu_baseline:
+                sub["cpu_baseline"] = cpu_baseline(r, args.cpu_budget / 2)
+            line[n] = sub
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

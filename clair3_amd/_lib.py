@@ -1,0 +1,102 @@
+"""ctypes binding of libc3hip.so (C ABI: include/c3hip.h).
+
+The reference binds its native code with cffi in API mode (build.py:38-85 -> ``libclair3.lib.<fn>``); cffi is
+not installed in this image, so the binding below uses ctypes against the same C ABI -- INTEGRATION.md
+shows the equivalent cffi ``cdef``.  There is NO fallback: if the HIP library is missing or cannot be
+loaded, importing a model fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("C3HIP_LIB", os.path.join(_HERE, "lib", "libc3hip.so"))
+
+KIND_PILEUP = 0
+KIND_FULL_ALIGNMENT = 1
+DTYPE_I8, DTYPE_I32, DTYPE_F32, DTYPE_I64 = 0, 1, 2, 3
+
+# every symbol include/c3hip.h declares (tests/test_abi.py checks the header against this list)
+EXPORTS = (
+    "c3_version", "c3_last_error", "c3_device_count", "c3_mem_info", "c3_model_create", "c3_model_set_geometry",
+    "c3_model_load", "c3_model_output_size", "c3_model_window_bytes", "c3_predict", "c3_predict_submit",
+    "c3_predict_wait", "c3_predict_device", "c3_model_synchronize", "c3_model_destroy", "c3_debug_fetch",
+    "c3_debug_keep_activations", "c3_profile_enable", "c3_profile_reset", "c3_profile_read",
+)
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("data", C.c_void_p)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+class C3Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libc3hip.so once; raise if it is not there (no CPU fallback by design)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise C3Error(f"{LIB_PATH} not found: build it with `python -m clair3_amd.build` "
+                      "(hipcc --offload-arch=gfx950); clair3_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.c3_version.restype = C.c_char_p
+    L.c3_last_error.restype = C.c_char_p
+    L.c3_device_count.restype = C.c_int
+    L.c3_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.c3_model_create.restype = C.c_void_p
+    L.c3_model_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.c3_model_set_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.c3_model_load.argtypes = [C.c_void_p, C.POINTER(TensorDesc), C.c_int]
+    L.c3_model_output_size.argtypes = [C.c_void_p]
+    L.c3_model_window_bytes.restype = C.c_int64
+    L.c3_model_window_bytes.argtypes = [C.c_void_p, C.c_int]
+    L.c3_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+    L.c3_predict_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int]
+    L.c3_predict_wait.argtypes = [C.c_void_p, C.c_int]
+    L.c3_predict_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    L.c3_model_synchronize.argtypes = [C.c_void_p]
+    L.c3_model_destroy.argtypes = [C.c_void_p]
+    L.c3_debug_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    L.c3_debug_keep_activations.argtypes = [C.c_void_p, C.c_int]
+    L.c3_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.c3_profile_reset.argtypes = [C.c_void_p]
+    L.c3_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError here = the .so is older than the header
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().c3_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise C3Error(f"{what}: {last_error()}")
+
+
+def device_count():
+    n = lib().c3_device_count()
+    if n < 0:
+        raise C3Error(f"c3_device_count: {last_error()}")
+    return n
+
+
+def mem_info(device=0):
+    """(free_bytes, total_bytes) of a device -- the ROCm replacement for the reference's nvidia-smi probe
+    (clair3/CallVariantsFromCffiGPU.py:13-19)."""
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    check(lib().c3_mem_info(device, C.byref(f), C.byref(t)), "c3_mem_info")
+    return f.value, t.value

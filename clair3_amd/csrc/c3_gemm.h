@@ -1,0 +1,357 @@
+// c3_gemm.h -- the one tiled fp32 MFMA contraction every dense layer of both networks runs on.
+//
+//   C[m][n] = epilogue( sum_k A[m][k] * Bt[n][k] )
+//
+// * A rows come from a pluggable loader: im2col gather of a 3x3 convolution over NHWC fp32 activations
+//   (clair3/model.py:195,228-231), the int8 full-alignment window itself for conv1 (model.py:378-382,
+//   x.float()/100 folded into the packed weights), the int8/int32 pileup window (model.py:131-132), or a
+//   plain row-major fp32 matrix (nn.Linear L4, LSTM input projections).
+// * Bt is always "[N][K], K contiguous" -- PyTorch's native nn.Linear layout; conv weights are packed once
+//   on the host as [Cout][kh][kw][Cin] with the BatchNorm scale folded in.
+// * Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  One wave owns a (BM/2)x(BN/2)
+//   sub-tile = RBxCB accumulators of 32x32.  A and B fragments are read from LDS with ds_read_b128: lane l
+//   takes 4 consecutive k of row (l&31) starting at k = 8g + 4*(l>>5); MFMA j of group g then contracts
+//   k = 8g+j (lanes 0-31) and k = 8g+4+j (lanes 32-63) -- the same k permutation on both operands.
+// * LDS tile rows are 128 B (BK = 32 floats); the 16-B chunk c of row r is stored at chunk c ^ ((r>>1)&7),
+//   which makes both the staging ds_write_b128 (8 consecutive lanes = one row) and the fragment
+//   ds_read_b128 (16 rows x one chunk column per lane group) bank-conflict free.
+// * Global -> register -> LDS staging, double buffered: chunk k+1 is fetched into registers before the
+//   MFMAs of chunk k are issued and written to the other LDS buffer after them; one barrier per chunk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 32;        // floats per K chunk
+constexpr int kThreads = 256;  // 4 waves, 2 (M) x 2 (N)
+
+__device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// XCD-aware, bijective block -> tile map: block b runs on XCD b%8 (observed; speed only), so give every
+// XCD a contiguous range of tiles (n fastest): the N-tiles of one M-tile and neighbouring M-tiles, which
+// share A rows / convolution halos, then hit the same 4 MiB L2.
+__device__ __forceinline__ int xcd_tile_index(int block, int n_tiles) {
+    const int xcd = block & 7, slot = block >> 3;
+    const int q = n_tiles >> 3, r = n_tiles & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + slot;
+}
+
+// ------------------------------------------------------------------------------------------ A loaders
+// Every loader serves R = BM/32 rows per thread: rows lr + 32*i of the tile, 16-B chunk lc of the K chunk.
+
+// 3x3 / pad 1 convolution over NHWC fp32, Cin % 32 == 0.  K order = (kh, kw, cin).
+struct ConvLoaderParams {
+    const float *x;
+    int Hin, Win, Cin, Ho, Wo, stride;
+    int chunks_per_tap;  // Cin / 32
+};
+template <int R>
+struct ConvLoader {
+    typedef ConvLoaderParams Params;
+    const float *x;
+    int64_t off[R];
+    uint32_t mask[R];
+    int Win, Cin, cpt, tap, cc;
+    __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
+        x = p.x, Win = p.Win, Cin = p.Cin, cpt = p.chunks_per_tap, tap = 0, cc = 0;
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + lr + 32 * i;
+            uint32_t mk = 0;
+            int64_t o = 0;
+            if (m < M) {
+                const int b = m / hw, rem = m - b * hw;
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
+                o = (((int64_t)b * p.Hin + ih0) * p.Win + iw0) * p.Cin + lc * 4;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ih = ih0 + t / 3, iw = iw0 + t % 3;
+                    if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) mk |= 1u << t;
+                }
+            }
+            off[i] = o, mask[i] = mk;
+        }
+    }
+    // fetch the next chunk in K order (called once per chunk, in order)
+    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int64_t koff = (int64_t)(kh * Win + kw) * Cin + cc * kBK;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            // always issue the load (from a safe address when the tap is padding) and select afterwards: a
+            // branch around each load would make the compiler drain vmcnt per row
+            const bool ok = (mask[i] >> tap) & 1u;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(ok ? x + off[i] + koff : x);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            out[i] = ok ? v : z;
+        }
+        if (++cc == cpt) cc = 0, ++tap;
+    }
+};
+
+// conv1 of Clair3_F straight from the int8 window (B, H, W, C), stride 2, pad 1, 3*C <= 32.
+// K is padded to 3 chunks (one per kh) of 32 slots: slot j = kw*C + c for j < 3C, zero beyond; the three
+// input pixels (kw = 0..2) of one kh are 3C consecutive bytes.
+struct Conv1LoaderParams {
+    const int8_t *x;
+    int Hin, Win, C, Ho, Wo;
+};
+template <int R>
+struct Conv1Loader {
+    typedef Conv1LoaderParams Params;
+    const int8_t *x;
+    int64_t off[R];  // byte offset of (b, ih0, iw0, 0) + 4*lc
+    int ih0[R], iw0[R];
+    int Hin, Win, C, lc4, kh;
+    __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
+        x = p.x, Hin = p.Hin, Win = p.Win, C = p.C, lc4 = lc * 4, kh = 0;
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + lr + 32 * i;
+            if (m < M) {
+                const int b = m / hw, rem = m - b * hw;
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                ih0[i] = oh * 2 - 1, iw0[i] = ow * 2 - 1;
+                off[i] = (((int64_t)b * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.C + lc4;
+            } else {
+                ih0[i] = -100000, iw0[i] = 0, off[i] = 0;  // every row test fails -> zeros
+            }
+        }
+    }
+    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            f32x4 v;
+            const int ih = ih0[i] + kh;
+            const bool row_ok = ih >= 0 && ih < Hin;
+            const int8_t *p = x + off[i] + (int64_t)kh * Win * C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = lc4 + e;
+                const int iw = iw0[i] + j / C;
+                const bool ok = row_ok && j < 3 * C && iw >= 0 && iw < Win;
+                const int8_t q = *(ok ? p + e : x);
+                v[e] = ok ? (float)q : 0.f;
+            }
+            out[i] = v;
+        }
+        ++kh;
+    }
+};
+
+// Row-major integer matrix (the pileup window rows: M = B*33 rows of C counts), K padded to one 32-chunk.
+template <typename T>
+struct IntRowLoaderParams {
+    const T *x;
+    int C;
+};
+template <int R, typename T>
+struct IntRowLoader {
+    typedef IntRowLoaderParams<T> Params;
+    const T *row[R];
+    bool ok[R];
+    int C, lc4;
+    __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
+        C = p.C, lc4 = lc * 4;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + lr + 32 * i;
+            ok[i] = m < M;
+            row[i] = p.x + (int64_t)(ok[i] ? m : 0) * p.C;
+        }
+    }
+    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = ok[i] && lc4 + e < C;
+                const T q = row[i][in ? lc4 + e : 0];
+                v[e] = in ? (float)q : 0.f;
+            }
+            out[i] = v;
+        }
+    }
+};
+
+// Row-major fp32 matrix A[M][lda]; the K range [k0, k0 + 32*nk) is selected by the kernel (split-K).
+struct DenseLoaderParams {
+    const float *a;
+    int64_t lda;
+};
+template <int R>
+struct DenseLoader {
+    typedef DenseLoaderParams Params;
+    const float *row[R];
+    bool ok[R];
+    int k;
+    __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
+        k = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + lr + 32 * i;
+            ok[i] = m < M;
+            row[i] = p.a + (int64_t)(ok[i] ? m : 0) * p.lda + lc * 4;
+        }
+    }
+    __device__ __forceinline__ void seek(int k0) { k = k0; }
+    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row[i] + k);  // row clamped to 0 when out of range
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            out[i] = ok[i] ? v : z;
+        }
+        k += kBK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ epilogues
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_RES_RELU = 2, EPI_PARTIAL = 3 };
+
+struct EpilogueParams {
+    float *c;            // [M][ldc]   (EPI_PARTIAL: [split][M][ldc])
+    const float *bias;   // [N]
+    const float *res;    // residual, same layout as c (EPI_BIAS_RES_RELU)
+    int64_t ldc;
+    int64_t split_stride;  // M*ldc for EPI_PARTIAL
+};
+
+struct GemmParams {
+    const float *bt;  // [N][ldb]
+    int64_t ldb;
+    int M, N;
+    int nk;          // K chunks per block (per split)
+    int tiles_n;     // N / BN
+    int tiles;       // tiles_m * tiles_n
+};
+
+template <class Loader, int EPI, int BM, int BN>
+__global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Params lp, GemmParams gp,
+                                                              EpilogueParams ep) {
+    constexpr int RA = BM / 32, RBt = BN / 32;  // staged rows per thread
+    constexpr int RB = BM / 64, CB = BN / 64;   // 32x32 accumulators per wave (rows x cols)
+    constexpr int kStage = (BM + BN) * 128;     // bytes per LDS stage
+    __shared__ __attribute__((aligned(16))) char smem[2 * kStage];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lc = tid & 7, lr = tid >> 3;
+
+    const int tile = xcd_tile_index(blockIdx.x, gp.tiles);
+    const int tm = tile / gp.tiles_n, tn = tile - tm * gp.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int k0 = split * gp.nk * kBK;
+
+    Loader loader;
+    loader.init(lp, m0, lr, lc, gp.M);
+    if constexpr (requires { loader.seek(0); }) loader.seek(k0);
+
+    const float *bptr[RBt];
+#pragma unroll
+    for (int i = 0; i < RBt; ++i) bptr[i] = gp.bt + (int64_t)(n0 + lr + 32 * i) * gp.ldb + k0 + lc * 4;
+
+    int st_off_a[RA], st_off_b[RBt];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) st_off_a[i] = lds_chunk_off(lr + 32 * i, lc);
+#pragma unroll
+    for (int i = 0; i < RBt; ++i) st_off_b[i] = BM * 128 + lds_chunk_off(lr + 32 * i, lc);
+
+    // fragment read offsets: row (lane&31) of each 32-row block, chunk 2g + (lane>>5)
+    const int frow = lane & 31, fhi = lane >> 5, fsw = (frow >> 1) & 7;
+    int rd_a[RB], rd_b[CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rd_a[i] = (wm * (BM / 2) + i * 32 + frow) * 128;
+#pragma unroll
+    for (int i = 0; i < CB; ++i) rd_b[i] = BM * 128 + (wn * (BN / 2) + i * 32 + frow) * 128;
+
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    f32x4 ra[RA], rb[RBt];
+    loader.fetch(ra);
+#pragma unroll
+    for (int i = 0; i < RBt; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(bptr[i]);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_a[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_b[i]) = rb[i];
+    __syncthreads();
+
+    for (int kc = 0; kc < gp.nk; ++kc) {
+        const char *cur = smem + (kc & 1) * kStage;
+        char *nxt = smem + ((kc + 1) & 1) * kStage;
+        const bool more = kc + 1 < gp.nk;
+        if (more) {
+            loader.fetch(ra);
+#pragma unroll
+            for (int i = 0; i < RBt; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)(kc + 1) * kBK);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int coff = ((2 * g + fhi) ^ fsw) << 4;
+            f32x4 a[RB], b[CB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) a[i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
+#pragma unroll
+            for (int i = 0; i < CB; ++i) b[i] = *reinterpret_cast<const f32x4 *>(cur + rd_b[i] + coff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int c = 0; c < CB; ++c)
+                        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[c][j], acc[i][c], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_a[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_b[i]) = rb[i];
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of 32x32x2: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+    float *cbase = ep.c + (EPI == EPI_PARTIAL ? (int64_t)split * ep.split_stride : 0);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int n = n0 + wn * (BN / 2) + c * 32 + (lane & 31);
+        float bias = 0.f;
+        if (EPI != EPI_PARTIAL) bias = ep.bias[n];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int mrow0 = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = mrow0 + (v & 3) + 8 * (v >> 2);
+                if (m < gp.M) {
+                    float val = acc[i][c][v] + bias;
+                    const int64_t idx = (int64_t)m * ep.ldc + n;
+                    if (EPI == EPI_BIAS_RES_RELU) val += ep.res[idx];
+                    if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) val = fmaxf(val, 0.f);
+                    cbase[idx] = val;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace c3

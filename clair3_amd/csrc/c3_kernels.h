@@ -1,0 +1,220 @@
+// c3_kernels.h -- the non-GEMM kernels: persistent bidirectional LSTM recurrence, spatial-pyramid
+// max-pool, and the fused FC tail (split-K reduce + SELU + branches + heads + SELU + soft-max).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "c3_gemm.h"
+
+namespace c3 {
+
+// nn.SELU constants (torch/nn/functional.py selu; same values as TF)
+__device__ __forceinline__ float selu_f(float x) {
+    const float kScale = 1.0507009873554804934193349852946f;
+    const float kAlpha = 1.6732632423543772848170429916717f;
+    return x > 0.f ? kScale * x : kScale * kAlpha * expm1f(x);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------- LSTM recurrence
+// One workgroup = 16 windows x one direction, all T steps (clair3/model.py:132-133, torch.nn.LSTM:
+// gates = W_ih x_t + b_ih + W_hh h_{t-1} + b_hh, rows i,f,g,o; c' = s(f)c + s(i)tanh(g); h' = s(o)tanh(c')).
+// The x-projection (+ both biases) of every step was hoisted into one big MFMA GEMM (gx); this kernel adds
+// the recurrent term with v_mfma_f32_16x16x4_f32 and applies the cell.
+//   * wave w owns hidden units [16w, 16w+16) and keeps their 4 gate blocks as 4 accumulators, so the
+//     i/f/g/o values of one (window, unit) sit in the same lane and register index: no cross-lane traffic;
+//   * h_{t-1} (16 x H) is exchanged between the H/16 waves through a double-buffered LDS tile
+//     (row stride H+4 floats -> conflict-free ds_read_b128), one barrier per step;
+//   * W_hh is read as pre-packed MFMA B fragments, 1 KiB per wave-instruction, fully coalesced; it is
+//     L2-resident (<= 400 KiB per direction) and re-streamed every step;
+//   * the cell state c stays in registers for all T steps.
+struct LstmParams {
+    const float *gx;   // [B*T][ld_gx]; column = dir*4H + wave*64 + gate*16 + unit
+    const float *whh;  // [dir][wave][gate][q = H/16][lane][4]
+    float *hout;       // [B][T][2H]; column = dir*H + unit
+    int B, T;
+    int64_t ld_gx;
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_recurrent_kernel(LstmParams p) {
+    constexpr int NW = H / 16;   // waves
+    constexpr int NQ = H / 16;   // k groups of 16
+    constexpr int LDH = H + 4;   // LDS row stride (floats)
+    __shared__ __attribute__((aligned(16))) float hbuf[2][16][LDH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane >> 4, col = lane & 15;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * 16;
+
+    for (int i = tid; i < 16 * LDH; i += NW * 64) (&hbuf[0][0][0])[i] = 0.f;
+
+    const float *wbase = p.whh + ((int64_t)(dir * NW + wave) * 4 * NQ * 64 + lane) * 4;
+    const int gx_col = dir * 4 * H + wave * 64 + col;
+    const int h_col = dir * H + wave * 16 + col;
+
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    bool rowok[4];
+    int64_t rowbase[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int b = b0 + 4 * s + v;
+        rowok[v] = b < p.B;
+        rowbase[v] = (int64_t)(rowok[v] ? b : 0) * p.T;
+    }
+    __syncthreads();
+
+    for (int step = 0; step < p.T; ++step) {
+        const int t = dir ? p.T - 1 - step : step;
+        const int cur = step & 1;
+        f32x4v acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc[g][v] = p.gx[(rowbase[v] + t) * p.ld_gx + gx_col + g * 16];
+        if (step > 0) {  // h_{-1} = 0
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                // A fragment: rows = windows (lane&15), k = 16q + 4s + e
+                const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v w = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)(g * NQ + q) * 256);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w[e], acc[g], 0, 0, 0);
+                }
+            }
+        }
+        // cell update.  C/D map of 16x16x4: col = lane&15 (unit), row = 4*(lane>>4) + v (window)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float ig = sigmoid_f(acc[0][v]);
+            const float fg = sigmoid_f(acc[1][v]);
+            const float gg = tanhf(acc[2][v]);
+            const float og = sigmoid_f(acc[3][v]);
+            c[v] = fg * c[v] + ig * gg;
+            const float h = og * tanhf(c[v]);
+            hbuf[cur ^ 1][4 * s + v][wave * 16 + col] = h;
+            if (rowok[v]) p.hout[(rowbase[v] + t) * (2 * H) + h_col] = h;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- spatial pyramid pooling
+// clair3/model.py:250-279.  in: NHWC fp32 (B, H, W, C) ; out: (B, nbins*C) in (bin, c) order where bins run
+// pool 3 (h, w), pool 2 (h, w), pool 1 -- the reference's permute(0,2,3,1)+flatten+cat order.
+struct SppParams {
+    const float *in;
+    float *out;
+    int B, H, W, C, nbins;
+    // window of every bin clipped to the image; pad != 0 when the un-clipped window reached into the zero
+    // padding added by F.pad (model.py:267-268), in which case 0 takes part in the max.
+    short h0[16], h1[16], w0[16], w1[16], pad[16];
+};
+__global__ __launch_bounds__(256) void spp_kernel(SppParams p) {
+    const int64_t total = (int64_t)p.B * p.nbins * p.C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % p.C);
+        const int bin = (int)((i / p.C) % p.nbins);
+        const int64_t b = i / ((int64_t)p.C * p.nbins);
+        const float *src = p.in + b * p.H * p.W * p.C + c;
+        float m = p.pad[bin] ? 0.f : -INFINITY;
+        for (int h = p.h0[bin]; h < p.h1[bin]; ++h)
+            for (int w = p.w0[bin]; w < p.w1[bin]; ++w) m = fmaxf(m, src[((int64_t)h * p.W + w) * p.C]);
+        p.out[i] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------- FC tail
+// clair3/model.py:136-159 (pileup) / 391-414 (full alignment), dropout = identity in eval():
+//   x  = selu(sum_s part[s] + L4.bias)                  (deterministic split-K reduction of the L4 GEMM)
+//   h_b = selu(L5_b x + b5_b)           b = 0..NB-1
+//   y_b = softmax(selu(head_b h_b + bh_b))              heads 21 / 3 / 33 / 33, written concatenated.
+struct TailParams {
+    const float *part;  // [S][B][FC]
+    const float *b4;    // [FC]
+    const float *w5t;   // [FC][NB*128]
+    const float *b5;    // [NB*128]
+    const float *wh;    // [NB][128][64]  (head columns zero-padded to 64)
+    const float *bh;    // [NB][64]
+    float *y;           // [B][nout]
+    float *l4_dbg;      // optional [B][FC]
+    int B, S, NB, nout;
+};
+constexpr int kTailWindows = 8;
+
+template <int FC>
+__global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
+    constexpr int TB = kTailWindows;
+    __shared__ float xs[TB][FC];
+    __shared__ float h5[TB][4 * 128];
+    __shared__ float lg[TB][96];
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * TB;
+    // label_shape = 21, 3, 33, 33 (shared/param_p.py:37); ternaries instead of arrays keep these in SGPRs
+    auto head_n = [](int br) { return br == 0 ? 21 : br == 1 ? 3 : 33; };
+    auto head_off = [](int br) { return br == 0 ? 0 : br == 1 ? 21 : br == 2 ? 24 : 57; };
+
+    for (int i = tid; i < TB * FC; i += 256) {
+        const int t = i / FC, k = i - t * FC;
+        const int b = b0 + t;
+        float v = 0.f;
+        if (b < p.B) {
+            v = p.b4[k];
+            for (int s = 0; s < p.S; ++s) v += p.part[((int64_t)s * p.B + b) * FC + k];
+            v = selu_f(v);
+            if (p.l4_dbg) p.l4_dbg[(int64_t)b * FC + k] = v;
+        }
+        xs[t][k] = v;
+    }
+    __syncthreads();
+
+    const int n5 = p.NB * 128;
+    for (int j = tid; j < n5; j += 256) {
+        float acc[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) acc[t] = p.b5[j];
+        for (int k = 0; k < FC; ++k) {
+            const float w = p.w5t[(int64_t)k * n5 + j];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) acc[t] = fmaf(xs[t][k], w, acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) h5[t][j] = selu_f(acc[t]);
+    }
+    __syncthreads();
+
+    for (int i = tid; i < TB * p.nout; i += 256) {
+        const int t = i / p.nout, o = i - t * p.nout;
+        const int br = o < 21 ? 0 : o < 24 ? 1 : o < 57 ? 2 : 3;
+        const int idx = o - head_off(br);
+        float acc = p.bh[br * 64 + idx];
+        const float *w = p.wh + (int64_t)br * 128 * 64 + idx;
+        const float *h = &h5[t][br * 128];
+        for (int k = 0; k < 128; ++k) acc = fmaf(h[k], w[k * 64], acc);
+        lg[t][o] = selu_f(acc);
+    }
+    __syncthreads();
+
+    for (int i = tid; i < TB * p.NB; i += 256) {
+        const int t = i / p.NB, br = i - t * p.NB;
+        const int b = b0 + t;
+        if (b >= p.B) continue;
+        const float *l = &lg[t][head_off(br)];
+        const int n = head_n(br);
+        float m = l[0];
+        for (int k = 1; k < n; ++k) m = fmaxf(m, l[k]);
+        float sum = 0.f;
+        for (int k = 0; k < n; ++k) sum += expf(l[k] - m);
+        float *y = p.y + (int64_t)b * p.nout + head_off(br);
+        for (int k = 0; k < n; ++k) y[k] = expf(l[k] - m) / sum;
+    }
+}
+
+}  // namespace c3

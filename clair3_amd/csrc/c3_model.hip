@@ -1,0 +1,857 @@
+// c3_model.hip -- host side of libc3hip.so: the C ABI of include/c3hip.h, weight packing (BatchNorm folding,
+// gate re-ordering, MFMA fragment layouts), workspace management and the launch sequences of the two
+// forward passes (clair3/model.py:130-161 and :377-416).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/c3hip.h"
+#include "c3_gemm.h"
+#include "c3_kernels.h"
+
+using namespace c3;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define TRY(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ model
+static const int kHeadN[4] = {21, 3, 33, 33};
+static const char *kHeadName[4] = {"Y_gt21_logits", "Y_genotype_logits", "Y_indel_length_logits_1",
+                                   "Y_indel_length_logits_2"};
+static const char *kConvName[9] = {"conv1.conv",         "res_block1.0.conv1", "res_block1.0.conv2",
+                                   "conv3.conv",         "res_block2.0.conv1", "res_block2.0.conv2",
+                                   "conv5.conv",         "res_block3.0.conv1", "res_block3.0.conv2"};
+static const char *kBnName[9] = {"conv1.bn",         "res_block1.0.bn1", "res_block1.0.bn2",
+                                 "conv3.bn",         "res_block2.0.bn1", "res_block2.0.bn2",
+                                 "conv5.bn",         "res_block3.0.bn1", "res_block3.0.bn2"};
+static const int kConvCout[9] = {64, 64, 64, 128, 128, 128, 256, 256, 256};
+static const int kConvStride[9] = {2, 1, 1, 2, 1, 1, 2, 1, 1};
+static const char *kFaLayerTag[9] = {"fa.conv1", "fa.res1a", "fa.res1b", "fa.conv3", "fa.res2a",
+                                     "fa.res2b", "fa.conv5", "fa.res3a", "fa.res3b"};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+
+struct HostSlot {
+    void *pin_x = nullptr;
+    float *pin_y = nullptr;
+    void *dev_x = nullptr;
+    float *dev_y = nullptr;
+    size_t cap_x = 0, cap_y = 0;
+    hipEvent_t ev_h2d = nullptr, ev_compute = nullptr, ev_out = nullptr;
+    float *y_host = nullptr;
+    size_t y_bytes = 0;
+    bool busy = false;
+};
+
+struct c3_model {
+    int kind = 0, C = 0, add_indel = 0, device = 0;
+    int depth = 89, positions = 33;
+    int nb = 2, nout = 24;
+    bool loaded = false;
+    hipStream_t stream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;
+
+    // ---- packed weights (device) ----
+    // pileup
+    float *proj_w[2] = {nullptr, nullptr};  // [2*4H][Kp]
+    float *proj_b[2] = {nullptr, nullptr};  // [2*4H]
+    float *whh[2] = {nullptr, nullptr};     // fragment-packed W_hh
+    // full alignment
+    float *conv_w[9] = {};
+    float *conv_b[9] = {};
+    // shared FC tail
+    float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
+    float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
+    int FC = 0, K4 = 0;
+
+    // ---- workspace ----
+    int64_t cap = 0;  // windows per micro-batch the workspace can hold
+    bool keep = false;  // debug: one buffer per layer instead of the 3-buffer rotation
+    std::vector<DevBuf> bufs;
+    float *act[9] = {};
+    float *spp = nullptr, *part = nullptr, *l4dbg = nullptr;
+    float *gx1 = nullptr, *h1 = nullptr, *gx2 = nullptr, *h2 = nullptr;
+    int splits = 1;
+    int64_t last_n = 0;  // windows of the last micro-batch (for debug fetch)
+
+    HostSlot slot[2];
+
+    bool prof = false;
+    std::vector<ProfRec> recs;
+};
+
+static int conv_out(int n, int s) { return (n - 1) / s + 1; }
+
+static void fa_geometry(const c3_model *m, int hh[10], int ww[10]) {
+    hh[0] = m->depth, ww[0] = m->positions;
+    for (int l = 0; l < 9; ++l) hh[l + 1] = conv_out(hh[l], kConvStride[l]), ww[l + 1] = conv_out(ww[l], kConvStride[l]);
+}
+
+// ------------------------------------------------------------------------------------------ profiling scope
+struct ProfScope {
+    c3_model *m;
+    hipStream_t s;
+    ProfRec r;
+    bool on;
+    ProfScope(c3_model *m_, hipStream_t s_, const char *name, double flops, double bytes) : m(m_), s(s_), on(m_->prof) {
+        if (!on) return;
+        r.name = name, r.flops = flops, r.bytes = bytes;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        m->recs.push_back(r);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ launches
+template <class Loader, int EPI, int BM, int BN>
+static int launch_gemm(hipStream_t s, const typename Loader::Params &lp, const float *bt, int64_t ldb, int M, int N,
+                       int nk, int splits, const EpilogueParams &ep) {
+    if (N % BN) return fail("internal: N=%d not a multiple of BN=%d", N, BN);
+    if (M <= 0) return 0;
+    GemmParams gp;
+    gp.bt = bt, gp.ldb = ldb, gp.M = M, gp.N = N, gp.nk = nk;
+    gp.tiles_n = N / BN;
+    gp.tiles = ((M + BM - 1) / BM) * gp.tiles_n;
+    dim3 grid(gp.tiles, splits);
+    hipLaunchKernelGGL((gemm_mfma_kernel<Loader, EPI, BM, BN>), grid, dim3(kThreads), 0, s, lp, gp, ep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Split-K factor of the L4 GEMM (K = 10560 / 3584, N = 128 / 256: far too few output tiles to fill 256 CUs).
+// It is a constant of the model, NOT a function of the batch size: the partial sums are added in a fixed
+// order by the tail kernel, so a window's probabilities are bit-identical whatever batch it travels in.
+static int l4_splits(const c3_model *m) {
+    const int nk = m->K4 / kBK;
+    const int want = m->kind == C3_KIND_PILEUP ? 15 : 28;
+    int best = 1;
+    for (int s = 1; s <= nk && s <= want; ++s)
+        if (nk % s == 0) best = s;
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------ memory
+static int dev_alloc(c3_model *m, void **p, size_t bytes) {
+    DevBuf b;
+    b.bytes = bytes;
+    HIP_TRY(hipMalloc(&b.p, std::max<size_t>(bytes, 256)));
+    m->bufs.push_back(b);
+    *p = b.p;
+    return 0;
+}
+static int upload(c3_model *m, float **dst, const std::vector<float> &src) {
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(src.size() * sizeof(float), 256)));
+    HIP_TRY(hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (*dst) (void)hipFree(*dst);
+    *dst = (float *)p;
+    (void)m;
+    return 0;
+}
+
+static void free_workspace(c3_model *m) {
+    for (auto &b : m->bufs) (void)hipFree(b.p);
+    m->bufs.clear();
+    m->cap = 0;
+}
+
+static int64_t max_microbatch(const c3_model *m) { return m->kind == C3_KIND_PILEUP ? 16384 : 2048; }
+
+static int ensure_workspace(c3_model *m, int64_t n) {
+    n = std::min<int64_t>(n, max_microbatch(m));
+    if (n <= m->cap) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    free_workspace(m);
+    if (m->kind == C3_KIND_FULL_ALIGNMENT) {
+        int hh[10], ww[10];
+        fa_geometry(m, hh, ww);
+        size_t act_elems[9];
+        size_t biggest = 0;
+        for (int l = 0; l < 9; ++l) {
+            act_elems[l] = (size_t)hh[l + 1] * ww[l + 1] * kConvCout[l];
+            biggest = std::max(biggest, act_elems[l]);
+        }
+        if (m->keep) {
+            for (int l = 0; l < 9; ++l) TRY(dev_alloc(m, (void **)&m->act[l], act_elems[l] * n * sizeof(float)));
+        } else {
+            float *rot[3];
+            for (int i = 0; i < 3; ++i) TRY(dev_alloc(m, (void **)&rot[i], biggest * n * sizeof(float)));
+            for (int l = 0; l < 9; ++l) m->act[l] = rot[l % 3];
+        }
+        TRY(dev_alloc(m, (void **)&m->spp, (size_t)n * m->K4 * sizeof(float)));
+    } else {
+        const int T = m->positions;
+        TRY(dev_alloc(m, (void **)&m->gx1, (size_t)n * T * 1024 * sizeof(float)));
+        TRY(dev_alloc(m, (void **)&m->h1, (size_t)n * T * 256 * sizeof(float)));
+        TRY(dev_alloc(m, (void **)&m->gx2, (size_t)n * T * 1280 * sizeof(float)));
+        TRY(dev_alloc(m, (void **)&m->h2, (size_t)n * T * 320 * sizeof(float)));
+    }
+    TRY(dev_alloc(m, (void **)&m->part, (size_t)l4_splits(m) * n * m->FC * sizeof(float)));  // [S][n][FC]
+    TRY(dev_alloc(m, (void **)&m->l4dbg, (size_t)n * m->FC * sizeof(float)));
+    m->cap = n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+struct TensorView {
+    const float *d;
+    std::vector<int64_t> shape;
+};
+typedef std::map<std::string, TensorView> TensorMap;
+
+static int want(const TensorMap &tm, const std::string &name, std::initializer_list<int64_t> shape, const float **out) {
+    auto it = tm.find(name);
+    if (it == tm.end()) return fail("Missing key in state_dict: \"%s\"", name.c_str());
+    std::vector<int64_t> s(shape);
+    if (it->second.shape != s) {
+        std::string got, exp;
+        for (auto v : it->second.shape) got += std::to_string(v) + ",";
+        for (auto v : s) exp += std::to_string(v) + ",";
+        return fail("size mismatch for %s: got (%s) expected (%s)", name.c_str(), got.c_str(), exp.c_str());
+    }
+    *out = it->second.d;
+    return 0;
+}
+
+static int pack_tail(c3_model *m, const TensorMap &tm) {
+    const int FC = m->FC, K4 = m->K4, nb = m->nb;
+    const float *w, *b;
+    TRY(want(tm, "L4.weight", {FC, K4}, &w));
+    TRY(want(tm, "L4.bias", {FC}, &b));
+    TRY(upload(m, &m->l4_w, std::vector<float>(w, w + (size_t)FC * K4)));
+    TRY(upload(m, &m->l4_b, std::vector<float>(b, b + FC)));
+    std::vector<float> w5t((size_t)FC * nb * 128), b5((size_t)nb * 128), wh((size_t)nb * 128 * 64, 0.f), bh((size_t)nb * 64, 0.f);
+    for (int br = 0; br < nb; ++br) {
+        const std::string l5 = "L5_" + std::to_string(br + 1);
+        TRY(want(tm, l5 + ".weight", {128, FC}, &w));
+        TRY(want(tm, l5 + ".bias", {128}, &b));
+        for (int j = 0; j < 128; ++j) {
+            b5[br * 128 + j] = b[j];
+            for (int k = 0; k < FC; ++k) w5t[(size_t)k * nb * 128 + br * 128 + j] = w[(size_t)j * FC + k];
+        }
+        const std::string hd = kHeadName[br];
+        TRY(want(tm, hd + ".weight", {kHeadN[br], 128}, &w));
+        TRY(want(tm, hd + ".bias", {kHeadN[br]}, &b));
+        for (int i = 0; i < kHeadN[br]; ++i) {
+            bh[br * 64 + i] = b[i];
+            for (int k = 0; k < 128; ++k) wh[((size_t)br * 128 + k) * 64 + i] = w[(size_t)i * 128 + k];
+        }
+    }
+    TRY(upload(m, &m->w5t, w5t));
+    TRY(upload(m, &m->b5, b5));
+    TRY(upload(m, &m->wh, wh));
+    TRY(upload(m, &m->bh, bh));
+    return 0;
+}
+
+// LSTM layer `layer` (0/1): hidden H, input size `in`.
+//   proj_w row n = dir*4H + wave*64 + gate*16 + unit  <->  PyTorch gate row gate*H + wave*16 + unit
+//   whh fragments: [dir][wave][gate][q][lane][e] = W_hh[gate*H + wave*16 + (lane&15)][16q + 4*(lane>>4) + e]
+static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in, int Kp) {
+    const std::string base = layer == 0 ? "LSTM1" : "LSTM2";
+    const int NW = H / 16, NQ = H / 16;
+    std::vector<float> pw((size_t)2 * 4 * H * Kp, 0.f), pb((size_t)2 * 4 * H), wf((size_t)2 * 4 * H * H);
+    for (int dir = 0; dir < 2; ++dir) {
+        const std::string sfx = dir ? "_reverse" : "";
+        const float *wih, *whh, *bih, *bhh;
+        TRY(want(tm, base + ".weight_ih_l0" + sfx, {4 * H, in}, &wih));
+        TRY(want(tm, base + ".weight_hh_l0" + sfx, {4 * H, H}, &whh));
+        TRY(want(tm, base + ".bias_ih_l0" + sfx, {4 * H}, &bih));
+        TRY(want(tm, base + ".bias_hh_l0" + sfx, {4 * H}, &bhh));
+        for (int w = 0; w < NW; ++w)
+            for (int g = 0; g < 4; ++g)
+                for (int u = 0; u < 16; ++u) {
+                    const int r = g * H + w * 16 + u;
+                    const size_t n = (size_t)dir * 4 * H + w * 64 + g * 16 + u;
+                    pb[n] = (float)((double)bih[r] + (double)bhh[r]);
+                    for (int k = 0; k < in; ++k) pw[n * Kp + k] = wih[(size_t)r * in + k];
+                }
+        for (int w = 0; w < NW; ++w)
+            for (int g = 0; g < 4; ++g)
+                for (int q = 0; q < NQ; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = g * H + w * 16 + (lane & 15);
+                            const int k = 16 * q + 4 * (lane >> 4) + e;
+                            wf[(((((size_t)dir * NW + w) * 4 + g) * NQ + q) * 64 + lane) * 4 + e] = whh[(size_t)r * H + k];
+                        }
+    }
+    TRY(upload(m, &m->proj_w[layer], pw));
+    TRY(upload(m, &m->proj_b[layer], pb));
+    TRY(upload(m, &m->whh[layer], wf));
+    return 0;
+}
+
+// conv layer l: fold BatchNorm2d(eval, eps=1e-3) into weight and bias (clair3/model.py:191,195-197):
+//   scale = gamma / sqrt(var + eps);  w' = w * scale;  b' = (b - mean) * scale + beta
+// layout [Cout][kh][kw][Cin]; conv1 additionally folds x/100 (model.py:378) and pads each kh to 32 slots.
+static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
+    const int Cout = kConvCout[l];
+    const float *w, *b, *g, *beta, *mean, *var;
+    const std::string cv = kConvName[l], bn = kBnName[l];
+    TRY(want(tm, cv + ".weight", {Cout, Cin, 3, 3}, &w));
+    TRY(want(tm, cv + ".bias", {Cout}, &b));
+    TRY(want(tm, bn + ".weight", {Cout}, &g));
+    TRY(want(tm, bn + ".bias", {Cout}, &beta));
+    TRY(want(tm, bn + ".running_mean", {Cout}, &mean));
+    TRY(want(tm, bn + ".running_var", {Cout}, &var));
+    const int ldb = l == 0 ? 96 : 9 * Cin;
+    std::vector<float> pw((size_t)Cout * ldb, 0.f), pb(Cout);
+    for (int co = 0; co < Cout; ++co) {
+        const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+        pb[co] = (float)(((double)b[co] - (double)mean[co]) * scale + (double)beta[co]);
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const double v = (double)w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] * scale;
+                    if (l == 0)
+                        pw[(size_t)co * ldb + kh * 32 + kw * Cin + ci] = (float)(v / 100.0);
+                    else
+                        pw[(size_t)co * ldb + (size_t)(kh * 3 + kw) * Cin + ci] = (float)v;
+                }
+    }
+    TRY(upload(m, &m->conv_w[l], pw));
+    TRY(upload(m, &m->conv_b[l], pb));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ forward passes
+static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int64_t n, float *y, const char *tag_l4,
+                    const char *tag_tail) {
+    const int FC = m->FC, K4 = m->K4;
+    const int nk_total = K4 / kBK;
+    const int S = l4_splits(m);
+    {
+        ProfScope ps(m, s, tag_l4, 2.0 * n * FC * K4, 4.0 * (n * K4 + (double)FC * K4 + (double)S * n * FC));
+        DenseLoaderParams lp{a, lda};
+        EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
+        TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
+    }
+    {
+        const double fl = 2.0 * n * (FC * 128.0 * m->nb + 128.0 * m->nout);
+        ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
+        TailParams tp{m->part, m->l4_b, m->w5t, m->b5, m->wh, m->bh, y, m->keep ? m->l4dbg : nullptr,
+                      (int)n, S, m->nb, m->nout};
+        const int grid = (int)((n + kTailWindows - 1) / kTailWindows);
+        if (FC == 256)
+            hipLaunchKernelGGL(fc_tail_kernel<256>, dim3(grid), dim3(256), 0, s, tp);
+        else
+            hipLaunchKernelGGL(fc_tail_kernel<128>, dim3(grid), dim3(256), 0, s, tp);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float *y) {
+    int hh[10], ww[10];
+    fa_geometry(m, hh, ww);
+    int cin = m->C;
+    for (int l = 0; l < 9; ++l) {
+        const int Cout = kConvCout[l];
+        const int M = (int)(n * hh[l + 1] * ww[l + 1]);
+        const double flops = 2.0 * M * Cout * 9.0 * cin;
+        const double bytes = (l == 0 ? 1.0 : 4.0) * n * hh[l] * ww[l] * cin + 4.0 * M * Cout * (l % 3 == 2 ? 2 : 1) +
+                             4.0 * Cout * 9.0 * cin;
+        ProfScope ps(m, s, kFaLayerTag[l], flops, bytes);
+        EpilogueParams ep{m->act[l], m->conv_b[l], l % 3 == 2 ? m->act[l - 2] : nullptr, Cout, 0};
+        if (l == 0) {
+            Conv1LoaderParams lp{x, hh[0], ww[0], cin, hh[1], ww[1]};
+            TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU, 128, 64>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep)));
+        } else {
+            ConvLoaderParams lp{m->act[l - 1], hh[l], ww[l], cin, hh[l + 1], ww[l + 1], kConvStride[l], cin / kBK};
+            const int nk = 9 * cin / kBK;
+            const int64_t ldb = 9 * cin;
+            const bool res = l % 3 == 2;
+            if (Cout == 64) {
+                if (res)
+                    TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RES_RELU, 128, 64>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep)));
+                else
+                    TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RELU, 128, 64>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep)));
+            } else {
+                if (res)
+                    TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RES_RELU, 128, 128>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep)));
+                else
+                    TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RELU, 128, 128>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep)));
+            }
+        }
+        cin = Cout;
+    }
+    {
+        // PyramidPolling geometry, clair3/model.py:250-279
+        SppParams sp;
+        sp.in = m->act[8], sp.out = m->spp, sp.B = (int)n, sp.H = hh[9], sp.W = ww[9], sp.C = 256;
+        int nbins = 0;
+        const int pools[3] = {3, 2, 1};
+        for (int pi = 0; pi < 3; ++pi) {
+            const int p = pools[pi], H = hh[9], W = ww[9];
+            const int wh_ = (H + p - 1) / p, ww_ = (W + p - 1) / p;
+            const int oh_n = (H + wh_ - 1) / wh_, ow_n = (W + ww_ - 1) / ww_;
+            const int pad_h = std::max((oh_n - 1) * wh_ + wh_ - H, 0), pad_w = std::max((ow_n - 1) * ww_ + ww_ - W, 0);
+            const int pt = pad_h / 2, pl = pad_w / 2;
+            for (int oh = 0; oh < oh_n; ++oh)
+                for (int ow = 0; ow < ow_n; ++ow) {
+                    if (nbins >= 16) return fail("unsupported geometry: more than 16 pyramid bins");
+                    const int a0 = oh * wh_ - pt, a1 = a0 + wh_, c0 = ow * ww_ - pl, c1 = c0 + ww_;
+                    sp.h0[nbins] = (short)std::max(a0, 0), sp.h1[nbins] = (short)std::min(a1, H);
+                    sp.w0[nbins] = (short)std::max(c0, 0), sp.w1[nbins] = (short)std::min(c1, W);
+                    sp.pad[nbins] = (a0 < 0 || a1 > H || c0 < 0 || c1 > W) ? 1 : 0;
+                    ++nbins;
+                }
+        }
+        if (nbins * 256 != m->K4) return fail("unsupported geometry: %d pyramid bins (L4 expects %d inputs)", nbins, m->K4);
+        sp.nbins = nbins;
+        ProfScope ps(m, s, "fa.spp", 0.0, 4.0 * n * (hh[9] * ww[9] * 256.0 + m->K4));
+        const int64_t total = n * m->K4;
+        const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(spp_kernel, dim3(grid), dim3(256), 0, s, sp);
+        HIP_TRY(hipGetLastError());
+    }
+    return run_tail(m, s, m->spp, m->K4, n, y, "fa.l4", "fa.tail");
+}
+
+template <typename T>
+static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float *y) {
+    const int Tn = m->positions;
+    const int M = (int)(n * Tn);
+    {
+        ProfScope ps(m, s, "p.proj1", 2.0 * M * 1024.0 * m->C, sizeof(T) * (double)M * m->C + 4.0 * M * 1024);
+        IntRowLoaderParams<T> lp{x, m->C};
+        EpilogueParams ep{m->gx1, m->proj_b[0], nullptr, 1024, 0};
+        TRY((launch_gemm<IntRowLoader<4, T>, EPI_BIAS, 128, 128>(s, lp, m->proj_w[0], 32, M, 1024, 1, 1, ep)));
+    }
+    {
+        ProfScope ps(m, s, "p.lstm1", 2.0 * M * 2.0 * 512.0 * 128.0, 4.0 * M * (1024.0 + 256.0));
+        LstmParams lp{m->gx1, m->whh[0], m->h1, (int)n, Tn, 1024};
+        hipLaunchKernelGGL(lstm_recurrent_kernel<128>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(m, s, "p.proj2", 2.0 * M * 1280.0 * 256.0, 4.0 * M * (256.0 + 1280.0));
+        DenseLoaderParams lp{m->h1, 256};
+        EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
+        TRY((launch_gemm<DenseLoader<4>, EPI_BIAS, 128, 128>(s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep)));
+    }
+    {
+        ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
+        LstmParams lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
+        hipLaunchKernelGGL(lstm_recurrent_kernel<160>, dim3((unsigned)((n + 15) / 16), 2), dim3(640), 0, s, lp);
+        HIP_TRY(hipGetLastError());
+    }
+    return run_tail(m, s, m->h2, m->K4, n, y, "p.l4", "p.tail");
+}
+
+static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype, int64_t batch, float *y) {
+    if (!m->loaded) return fail("model has no weights: call c3_model_load first");
+    if (batch < 0) return fail("negative batch");
+    if (batch == 0) return 0;
+    if (m->kind == C3_KIND_FULL_ALIGNMENT && x_dtype != C3_DTYPE_I8)
+        return fail("full-alignment windows must be int8 (got dtype %d)", x_dtype);
+    if (m->kind == C3_KIND_PILEUP && x_dtype != C3_DTYPE_I8 && x_dtype != C3_DTYPE_I32)
+        return fail("pileup windows must be int8 or int32 (got dtype %d)", x_dtype);
+    TRY(ensure_workspace(m, batch));
+    const int64_t wbytes = c3_model_window_bytes(m, x_dtype);
+    for (int64_t off = 0; off < batch; off += m->cap) {
+        const int64_t n = std::min<int64_t>(m->cap, batch - off);
+        const char *xp = (const char *)x + off * wbytes;
+        float *yp = y + off * m->nout;
+        if (m->kind == C3_KIND_FULL_ALIGNMENT)
+            TRY(run_fa(m, s, (const int8_t *)xp, n, yp));
+        else if (x_dtype == C3_DTYPE_I8)
+            TRY(run_pileup_t<int8_t>(m, s, (const int8_t *)xp, n, yp));
+        else
+            TRY(run_pileup_t<int32_t>(m, s, (const int32_t *)xp, n, yp));
+        m->last_n = n;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char *c3_version(void) { return "c3hip 0.1.0 (gfx950, fp32 MFMA)"; }
+const char *c3_last_error(void) { return g_err.c_str(); }
+
+int c3_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) {
+        fail("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return n;
+}
+
+int c3_mem_info(int device, size_t *free_bytes, size_t *total_bytes) {
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    hipError_t e = hipMemGetInfo(&f, &t);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return fail("hipMemGetInfo failed: %s", hipGetErrorString(e));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
+c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int device) {
+    if (kind != C3_KIND_PILEUP && kind != C3_KIND_FULL_ALIGNMENT) {
+        fail("unknown model kind %d", kind);
+        return nullptr;
+    }
+    if (kind == C3_KIND_PILEUP && (in_channels < 1 || in_channels > 32)) {
+        fail("pileup input_channels must be in [1,32], got %d", in_channels);
+        return nullptr;
+    }
+    if (kind == C3_KIND_FULL_ALIGNMENT && (in_channels < 1 || in_channels > 10)) {
+        fail("full-alignment input_channels must be in [1,10], got %d", in_channels);
+        return nullptr;
+    }
+    int ndev = c3_device_count();
+    if (ndev <= 0) {
+        fail("no HIP device visible (libc3hip has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail("device %d out of range (%d visible)", device, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail("hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    c3_model *m = new c3_model();
+    m->kind = kind, m->C = in_channels, m->add_indel = add_indel_length ? 1 : 0, m->device = device;
+    m->nb = m->add_indel ? 4 : 2, m->nout = m->add_indel ? 90 : 24;
+    m->FC = kind == C3_KIND_PILEUP ? 128 : 256;
+    m->K4 = kind == C3_KIND_PILEUP ? m->positions * 320 : 14 * 256;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->h2d_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->d2h_stream, hipStreamNonBlocking) != hipSuccess) {
+        fail("hipStreamCreate failed");
+        delete m;
+        return nullptr;
+    }
+    if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
+    return m;
+}
+
+int c3_model_set_geometry(c3_model *m, int depth, int positions) {
+    if (!m) return fail("null model");
+    if (positions < 1 || depth < 1) return fail("bad geometry %dx%d", depth, positions);
+    HIP_TRY(hipSetDevice(m->device));
+    m->depth = depth, m->positions = positions;
+    if (m->kind == C3_KIND_PILEUP) m->K4 = positions * 320;
+    if (m->K4 % kBK) return fail("unsupported geometry: L4 fan-in %d is not a multiple of %d", m->K4, kBK);
+    free_workspace(m);
+    m->loaded = false;
+    return 0;
+}
+
+int c3_model_output_size(const c3_model *m) { return m ? m->nout : -1; }
+
+int64_t c3_model_window_bytes(const c3_model *m, int x_dtype) {
+    if (!m) return -1;
+    const int64_t item = x_dtype == C3_DTYPE_I32 ? 4 : 1;
+    if (m->kind == C3_KIND_PILEUP) return item * m->positions * m->C;
+    return item * m->depth * m->positions * m->C;
+}
+
+int c3_model_load(c3_model *m, const c3_tensor_desc *tensors, int n_tensors) {
+    if (!m || (!tensors && n_tensors)) return fail("null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i) {
+        const c3_tensor_desc &t = tensors[i];
+        if (!t.name) return fail("tensor %d has no name", i);
+        const std::string name = t.name;
+        const bool nbt = name.size() > 19 && name.compare(name.size() - 19, 19, "num_batches_tracked") == 0;
+        if (nbt) continue;  // BatchNorm bookkeeping, unused in eval()
+        if (t.dtype != C3_DTYPE_F32) return fail("tensor %s: only float32 parameters are supported", t.name);
+        if (t.ndim < 1 || t.ndim > 4 || !t.data) return fail("tensor %s: bad descriptor", t.name);
+        TensorView v;
+        v.d = (const float *)t.data;
+        v.shape.assign(t.shape, t.shape + t.ndim);
+        tm[name] = v;
+    }
+    size_t expected = 0;
+    if (m->kind == C3_KIND_PILEUP) {
+        TRY(pack_lstm(m, tm, 0, 128, m->C, 32));
+        TRY(pack_lstm(m, tm, 1, 160, 256, 256));
+        expected = 16;
+    } else {
+        int cin = m->C;
+        if (3 * cin > 32) return fail("full-alignment input_channels %d not supported (3*C must be <= 32)", cin);
+        for (int l = 0; l < 9; ++l) {
+            TRY(pack_conv(m, tm, l, cin));
+            cin = kConvCout[l];
+        }
+        expected = 54;
+    }
+    TRY(pack_tail(m, tm));
+    expected += 2 + 4 * (size_t)m->nb;
+    if (tm.size() != expected) {
+        // strict like load_state_dict: report the first unexpected key
+        return fail("Unexpected key(s) in state_dict: %zu tensors given, %zu expected", tm.size(), expected);
+    }
+    m->loaded = true;
+    return 0;
+}
+
+int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, void *stream) {
+    if (!m) return fail("null model");
+    if (batch > 0 && (!x_dev || !y_dev)) return fail("null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    return forward_device(m, stream ? (hipStream_t)stream : m->stream, x_dev, x_dtype, batch, y_dev);
+}
+
+static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
+    if (!sl.ev_h2d) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_compute, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+    if (xb > sl.cap_x) {
+        if (sl.pin_x) (void)hipHostFree(sl.pin_x);
+        if (sl.dev_x) (void)hipFree(sl.dev_x);
+        sl.pin_x = sl.dev_x = nullptr, sl.cap_x = 0;
+        HIP_TRY(hipHostMalloc(&sl.pin_x, xb, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&sl.dev_x, xb));
+        sl.cap_x = xb;
+    }
+    if (yb > sl.cap_y) {
+        if (sl.pin_y) (void)hipHostFree(sl.pin_y);
+        if (sl.dev_y) (void)hipFree(sl.dev_y);
+        sl.pin_y = nullptr, sl.dev_y = nullptr, sl.cap_y = 0;
+        HIP_TRY(hipHostMalloc((void **)&sl.pin_y, yb, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&sl.dev_y, yb));
+        sl.cap_y = yb;
+    }
+    (void)m;
+    return 0;
+}
+
+int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
+    if (!m) return fail("null model");
+    if (slot < 0 || slot > 1) return fail("slot must be 0 or 1");
+    if (batch < 0) return fail("negative batch");
+    if (batch > 0 && (!x_host || !y_host)) return fail("null buffer");
+    HostSlot &sl = m->slot[slot];
+    if (sl.busy) return fail("slot %d still in flight: call c3_predict_wait first", slot);
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->loaded) return fail("model has no weights: call c3_model_load first");
+    const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
+    const size_t yb = (size_t)batch * m->nout * sizeof(float);
+    sl.y_host = y_host, sl.y_bytes = yb, sl.busy = true;
+    if (batch == 0) return 0;
+    TRY(ensure_slot(m, sl, xb, yb));
+    memcpy(sl.pin_x, x_host, xb);
+    HIP_TRY(hipMemcpyAsync(sl.dev_x, sl.pin_x, xb, hipMemcpyHostToDevice, m->h2d_stream));
+    HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
+    HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
+    int rc = forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y);
+    if (rc) {
+        sl.busy = false;
+        return rc;
+    }
+    HIP_TRY(hipEventRecord(sl.ev_compute, m->stream));
+    HIP_TRY(hipStreamWaitEvent(m->d2h_stream, sl.ev_compute, 0));
+    HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->d2h_stream));
+    HIP_TRY(hipEventRecord(sl.ev_out, m->d2h_stream));
+    return 0;
+}
+
+int c3_predict_wait(c3_model *m, int slot) {
+    if (!m) return fail("null model");
+    if (slot < 0 || slot > 1) return fail("slot must be 0 or 1");
+    HostSlot &sl = m->slot[slot];
+    if (!sl.busy) return fail("slot %d has nothing in flight", slot);
+    sl.busy = false;
+    if (sl.y_bytes == 0) return 0;
+    HIP_TRY(hipEventSynchronize(sl.ev_out));
+    memcpy(sl.y_host, sl.pin_y, sl.y_bytes);
+    return 0;
+}
+
+int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host) {
+    TRY(c3_predict_submit(m, x_host, x_dtype, batch, y_host, 0));
+    return c3_predict_wait(m, 0);
+}
+
+int c3_model_synchronize(c3_model *m) {
+    if (!m) return fail("null model");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int c3_model_destroy(c3_model *m) {
+    if (!m) return 0;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    free_workspace(m);
+    float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
+                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh};
+    for (float *p : ws)
+        if (p) (void)hipFree(p);
+    for (int l = 0; l < 9; ++l) {
+        if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
+        if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);
+    }
+    for (auto &sl : m->slot) {
+        if (sl.pin_x) (void)hipHostFree(sl.pin_x);
+        if (sl.pin_y) (void)hipHostFree(sl.pin_y);
+        if (sl.dev_x) (void)hipFree(sl.dev_x);
+        if (sl.dev_y) (void)hipFree(sl.dev_y);
+        if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
+        if (sl.ev_compute) (void)hipEventDestroy(sl.ev_compute);
+        if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
+    }
+    for (auto &r : m->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->h2d_stream) (void)hipStreamDestroy(m->h2d_stream);
+    if (m->d2h_stream) (void)hipStreamDestroy(m->d2h_stream);
+    delete m;
+    return 0;
+}
+
+int c3_debug_keep_activations(c3_model *m, int enable) {
+    if (!m) return fail("null model");
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->keep != (enable != 0)) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        free_workspace(m);
+        m->keep = enable != 0;
+    }
+    return 0;
+}
+
+int c3_debug_fetch(c3_model *m, const char *name, float *host_out, int64_t n_floats) {
+    if (!m || !name || !host_out) return fail("null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->last_n <= 0) return fail("nothing has been predicted yet");
+    const std::string s = name;
+    const float *src = nullptr;
+    int64_t n = 0;
+    if (m->kind == C3_KIND_PILEUP) {
+        if (s == "lstm1_out") src = m->h1, n = m->last_n * m->positions * 256;
+        else if (s == "lstm2_out") src = m->h2, n = m->last_n * m->positions * 320;
+        else if (s == "gx1") src = m->gx1, n = m->last_n * m->positions * 1024;
+        else if (s == "gx2") src = m->gx2, n = m->last_n * m->positions * 1280;
+    } else {
+        int hh[10], ww[10];
+        fa_geometry(m, hh, ww);
+        if (s.size() == 4 && s.compare(0, 3, "act") == 0 && s[3] >= '0' && s[3] <= '8') {
+            if (!m->keep) return fail("activations are recycled: enable c3_debug_keep_activations first");
+            const int l = s[3] - '0';
+            src = m->act[l], n = m->last_n * hh[l + 1] * ww[l + 1] * kConvCout[l];
+        } else if (s == "spp") src = m->spp, n = m->last_n * m->K4;
+    }
+    if (s == "l4_out") {
+        if (!m->keep) return fail("l4_out is only written with c3_debug_keep_activations enabled");
+        src = m->l4dbg, n = m->last_n * m->FC;
+    }
+    if (!src) return fail("unknown debug tensor \"%s\"", name);
+    if (n != n_floats) return fail("debug tensor %s has %lld floats, caller expects %lld", name, (long long)n, (long long)n_floats);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(host_out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int c3_profile_enable(c3_model *m, int enable) {
+    if (!m) return fail("null model");
+    m->prof = enable != 0;
+    return 0;
+}
+
+int c3_profile_reset(c3_model *m) {
+    if (!m) return fail("null model");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto &r : m->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    m->recs.clear();
+    return 0;
+}
+
+int c3_profile_read(c3_model *m, c3_kernel_stat *out, int max_entries) {
+    if (!m || (!out && max_entries > 0)) {
+        fail("null argument");
+        return -1;
+    }
+    if (hipSetDevice(m->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        fail("device synchronize failed");
+        return -1;
+    }
+    std::vector<std::string> order;
+    std::map<std::string, c3_kernel_stat> agg;
+    for (auto &r : m->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        auto it = agg.find(r.name);
+        if (it == agg.end()) {
+            c3_kernel_stat st;
+            memset(&st, 0, sizeof(st));
+            snprintf(st.name, sizeof(st.name), "%s", r.name.c_str());
+            it = agg.insert({r.name, st}).first;
+            order.push_back(r.name);
+        }
+        it->second.launches += 1;
+        it->second.total_ms += ms;
+        it->second.flops += r.flops;
+        it->second.bytes += r.bytes;
+    }
+    int n = 0;
+    for (auto &k : order) {
+        if (n >= max_entries) break;
+        out[n++] = agg[k];
+    }
+    return (int)order.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+"""Multi-GPU sharding of candidate windows: one process per GPU, no data-path collective, one gather of the
+per-window probability rows to rank 0.
+
+The reference shards by *files* across GPU slots with GNU parallel and meets on disk in SortVcf
+(clair3/CallVariantsFromCffiGPU.py:138-156,163-199; preprocess/SortVcf.py:290-362).  Windows are independent
+samples (BatchNorm in eval mode, LSTM state per window), so here every rank takes a contiguous, near-equal
+range of the window list -- which keeps VCF order trivially -- runs the HIP forward on its own GPU and the
+(n_r, 24|90) float32 rows are gathered to rank 0 (RCCL over xGMI: backend "nccl" on ROCm; "gloo" on CPU for
+the tests) for the unchanged reference decoder / MergeVcf.  Payload is 96 B (pileup) / 360 B (full alignment)
+per window: even at 8 x 200 k windows/s that is < 0.6 GB/s into rank 0, three orders of magnitude below one
+xGMI link, so one padded gather per super-batch is all the communication there is.
+"""
+import os
+
+
+def shard_range(n_windows, rank, world_size):
+    """[start, stop) of rank's contiguous share; the first n % world ranks get one extra window."""
+    base, extra = divmod(int(n_windows), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank); a no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def gather_rows(y_local, n_total, dst=0):
+    """Gather the per-rank probability rows (torch tensor (n_r, W) float32, on the GPU for nccl / host for
+    gloo) to rank ``dst`` in rank order.  Every rank's n_r must equal shard_range(n_total, r, world).
+    Returns the (n_total, W) tensor on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return y_local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    if y_local.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {y_local.shape[0]} rows, its shard has {counts[rank]}")
+    width = y_local.shape[1]
+    pad = max(counts)
+    send = y_local
+    if y_local.shape[0] != pad:  # pad to a common size: gather needs equal shapes
+        send = torch.zeros((pad, width), dtype=y_local.dtype, device=y_local.device)
+        send[: y_local.shape[0]] = y_local
+    send = send.contiguous()
+    if rank == dst:
+        parts = [torch.empty((pad, width), dtype=y_local.dtype, device=y_local.device) for _ in range(world)]
+        dist.gather(send, parts, dst=dst)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    dist.gather(send, None, dst=dst)
+    return None
+
+
+def predict_sharded(model, x_all, dst=0):
+    """Whole-job helper: every rank passes the same host window array (or its own memmap of it), computes its
+    contiguous shard on its GPU and rank ``dst`` receives all rows in window order (numpy), others None."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    n = len(x_all)
+    lo, hi = shard_range(n, rank, world)
+    x = np.ascontiguousarray(x_all[lo:hi])
+    if world == 1:
+        return model.predict_numpy(x)
+    xd = torch.from_numpy(x).cuda()
+    yd = model(xd)
+    out = gather_rows(yd, n, dst)
+    return out.cpu().numpy() if out is not None else None

@@ -1,0 +1,130 @@
+/*
+ * c3hip.h -- C ABI of libc3hip.so, the MI355X (gfx950) native inference path for the two Clair3
+ * networks.  This is the drop-in boundary for the *model call* of the reference's
+ * CallVariantsFromCffi / CallVariantsFromCffiGPU step; everything else of the reference pipeline
+ * (tensor extraction, VCF emitters, run_clair3.py) stays untouched.
+ *
+ * What each entry point replaces in the reference (paths relative to the Clair3 repo):
+ *
+ *   c3_device_count / c3_mem_info   nvidia-smi parsing in clair3/CallVariantsFromCffiGPU.py:13-43
+ *                                   (get_gpu_memory / check_gpu_memory) -- not available on ROCm.
+ *   c3_model_create                 model factory  clair3/CallVariantsFromCffi.py:223-243
+ *                                   (Clair3_P / Clair3_F(add_indel_length, predict=True, input_channels)),
+ *                                   clair3/model.py:58-128 and :282-368; device selection :215-221.
+ *   c3_model_load                   _load_torch_checkpoint + strict load_state_dict,
+ *                                   clair3/CallVariantsFromCffi.py:19-28 (the Python wrapper does the
+ *                                   torch.load and hands the named float32 tensors over).
+ *   c3_predict                      _torch_predict(model, device, X) -> numpy (B, 24|90) float32,
+ *                                   clair3/CallVariantsFromCffi.py:48-52 (twin: clair3/CallVariants.py:83-87):
+ *                                   H2D copy + Clair3_P.forward (model.py:130-161) or Clair3_F.forward
+ *                                   (model.py:377-416) + D2H copy.
+ *   c3_predict_submit / _wait       same, split so the caller's loop (CallVariantsFromCffi.py:302-353)
+ *                                   can overlap batch i+1's transfer with batch i's kernels/decoding.
+ *   c3_predict_device               the forward pass alone on tensors already resident in HBM
+ *                                   (what bench.py times; also the hook for the RCCL gather of SURVEY 8e).
+ *   c3_model_destroy                model going out of scope at process exit.
+ *
+ * Conventions (mirroring libclair3's cffi surface, build.py:38-85, src/clair3_pileup.h:90-113):
+ *   - plain C types only; the library owns all device memory; the caller owns host x / y buffers
+ *     (C-contiguous; pageable is fine -- the library stages through its own pinned buffers);
+ *   - every int-returning function returns 0 on success, non-zero on failure, and c3_last_error()
+ *     then describes the failure (thread-local).  Nothing aborts the process;
+ *   - one model per handle, one handle per OS process per GPU slot is the intended use
+ *     (clair3/CallVariantsFromCffiGPU.py:163-199 launches one worker per slot); a handle is not
+ *     thread-safe, different handles are independent.
+ *   - the output row layout is exactly the reference's: [gt21 (21) | genotype (3) | indel_1 (33) |
+ *     indel_2 (33)], columns label_shape_cum = 21,24,57,90 (shared/param_p.py:37-39), float32
+ *     probabilities, consumed unchanged by batch_output (clair3/CallVariants.py:1069-1116).
+ */
+#ifndef C3HIP_H
+#define C3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C3_KIND_PILEUP 0         /* Clair3_P, windows (B, 33, C)    int8 | int32 */
+#define C3_KIND_FULL_ALIGNMENT 1 /* Clair3_F, windows (B, D, 33, C) int8, channels-last */
+
+#define C3_DTYPE_I8 0
+#define C3_DTYPE_I32 1
+#define C3_DTYPE_F32 2
+#define C3_DTYPE_I64 3
+
+typedef struct c3_model c3_model;
+
+/* one entry of a PyTorch state_dict */
+typedef struct {
+    const char *name;  /* e.g. "LSTM1.weight_ih_l0", "conv1.bn.running_var" */
+    int32_t dtype;     /* C3_DTYPE_F32 for every parameter/buffer; *.num_batches_tracked (I64) is accepted and ignored */
+    int32_t ndim;
+    int64_t shape[4];
+    const void *data;  /* host pointer, C-contiguous */
+} c3_tensor_desc;
+
+const char *c3_version(void);
+/* thread-local description of the last failure in this thread ("" if none) */
+const char *c3_last_error(void);
+
+/* number of visible HIP devices (honours HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES); <0 on error */
+int c3_device_count(void);
+int c3_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
+
+/* kind: C3_KIND_*; in_channels: 18 (pileup) / 8 or 9 (full alignment, 9 = dwell time);
+ * add_indel_length: 0 -> (B,24) output, 1 -> (B,90).  Returns NULL on failure. */
+c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int device);
+/* window geometry; defaults are the ONT shapes: depth 89 (ignored for pileup), 33 positions */
+int c3_model_set_geometry(c3_model *m, int depth, int positions);
+/* strict: every expected key must be present with the expected shape, unknown keys are an error */
+int c3_model_load(c3_model *m, const c3_tensor_desc *tensors, int n_tensors);
+/* 24 or 90 */
+int c3_model_output_size(const c3_model *m);
+/* bytes of one input window for dtype x_dtype (594 / 2376 / 23496 / 26433 for the ONT shapes) */
+int64_t c3_model_window_bytes(const c3_model *m, int x_dtype);
+
+/* y_host[batch][24|90] = forward(x_host[batch][...]); synchronous */
+int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host);
+/* asynchronous pair, slot in {0,1}: submit copies x into pinned staging and enqueues H2D + kernels + D2H;
+ * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
+int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);
+int c3_predict_wait(c3_model *m, int slot);
+/* device-resident forward: x_dev / y_dev are device pointers on the model's device, stream is a
+ * hipStream_t (NULL = the model's own stream).  Asynchronous with respect to the host. */
+int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, void *stream);
+/* blocks until everything enqueued on the model's own stream has finished */
+int c3_model_synchronize(c3_model *m);
+int c3_model_destroy(c3_model *m);
+
+/* ---- introspection used by the parity tests and bench.py (not needed by a pipeline) ---- */
+
+/* Copy an intermediate activation of the most recent predict call (its last micro-batch) to the host.
+ * names: pileup  "lstm1_out" (B,33,256) "lstm2_out" (B,33,320) "l4_out" (B,128)
+ *        full-aln "act0".."act8" NHWC conv outputs, "spp" (B,3584), "l4_out" (B,256).
+ * n_floats must equal the tensor's element count for the last batch. */
+int c3_debug_fetch(c3_model *m, const char *name, float *host_out, int64_t n_floats);
+/* enable=1: every layer writes to its own buffer (otherwise three buffers are recycled and only the
+ * non-recycled tensors can be fetched).  Also enabled by the environment variable C3HIP_KEEP_ACTIVATIONS. */
+int c3_debug_keep_activations(c3_model *m, int enable);
+
+/* Per-kernel-family HIP-event timing on the launch stream.  enable=1 brackets every kernel launch with
+ * hipEvents (small overhead -- keep it off when measuring whole-job throughput). */
+int c3_profile_enable(c3_model *m, int enable);
+int c3_profile_reset(c3_model *m);
+/* Fills up to max_entries records; returns the number of families, <0 on error.
+ * flops are ALGORITHMIC (2*MACs of the reference layer shapes, no padding). */
+typedef struct {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+    double flops; /* summed over the recorded launches */
+    double bytes; /* algorithmic bytes moved (inputs+outputs+weights once per launch) */
+} c3_kernel_stat;
+int c3_profile_read(c3_model *m, c3_kernel_stat *out, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C3HIP_H */

@@ -1,0 +1,40 @@
+"""Host-side logic that needs no GPU: state_dict specs, synthetic recipes, sharding arithmetic."""
+import numpy as np
+import pytest
+
+from clair3_amd import synthetic as syn
+from clair3_amd.dist import shard_range
+
+
+def test_parameter_counts_match_the_reference():
+    # Clair3_P 2,074,520 parameters; Clair3_F 2,986,522 (C=8) / 2,987,098 (C=9) + 2,688 BN buffers
+    n = sum(int(np.prod(s)) for _, s in syn.state_dict_spec(syn.PILEUP))
+    assert n == 2074520
+    for c, want in ((8, 2986522), (9, 2987098)):
+        spec = syn.state_dict_spec(syn.FULL_ALIGNMENT, c, True)
+        params = sum(int(np.prod(s)) for k, s in spec if "running" not in k)
+        bufs = sum(int(np.prod(s)) for k, s in spec if "running" in k)
+        assert params == want and bufs == 2688
+
+
+def test_window_recipes():
+    x = syn.make_pileup_windows(64, seed=3)
+    assert x.shape == (64, 33, 18) and x.dtype == np.int8
+    # no all-zero column (preprocess/CreateTensorPileupFromCffi.py:365 drops them)
+    assert (np.abs(x.astype(np.int32)).sum(axis=2) > 0).all()
+    f = syn.make_fa_windows(4, seed=1, channels=9)
+    assert f.shape == (4, 89, 33, 9) and f.dtype == np.int8
+    assert set(np.unique(f[..., 0])) <= {0, 25, 50, 75, 100}
+    assert ((f[..., 8] != 0) <= (f[..., 0] != 0)).all()  # dwell only where there is a base
+    u = syn.make_fa_windows(2, seed=1, recipe="uniform")
+    assert u.min() >= -100 and u.max() <= 100
+
+
+@pytest.mark.parametrize("n,world", [(0, 1), (1, 8), (7, 8), (8, 8), (1000, 3), (1024, 8), (10007, 8)])
+def test_shard_ranges_partition_the_windows(n, world):
+    spans = [shard_range(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0 and a0 <= a1
+    sizes = [b - a for a, b in spans]
+    assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,223 @@
+"""Parity tests proper (need an MI355X): the HIP path called through the C ABI against
+  * the golden rows produced by the real reference modules (tests/golden/*.npz),
+  * the CPU oracle on the same seeded inputs, layer by layer,
+  * size-independent properties at the full BASELINE.json sizes.
+Gate (BASELINE.json north_star): probabilities within 1e-4 (fp32), genotype/zygosity labels identical.
+"""
+import numpy as np
+import pytest
+
+from clair3_amd import _lib, synthetic as syn
+from clair3_amd.model import Clair3_F, Clair3_P
+from clair3_amd.predict import _hip_predict
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(util.manifest().keys())
+
+
+def make_model(kind, channels, add_indel, sd, keep=False):
+    cls = Clair3_P if kind == syn.PILEUP else Clair3_F
+    m = cls(add_indel_length=add_indel, predict=True, input_channels=channels)
+    if keep:
+        m.keep_activations(True)
+    m.to("cuda:0")
+    m.eval()
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.fixture(scope="module")
+def oracle_mod():
+    from oracle import oracle
+    return oracle
+
+
+def test_extension_is_loaded_and_sees_the_gpu():
+    assert _lib.device_count() >= 1
+    free_b, total_b = _lib.mem_info(0)
+    assert total_b > 100 * 2 ** 30 and 0 < free_b <= total_b  # 288 GB HBM3E part
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_rows(name):
+    """HIP rows vs rows of the reference PyTorch modules on identical tensors."""
+    meta = util.manifest()[name]
+    sd, x = util.case_inputs(meta)
+    m = make_model(meta["kind"], meta["channels"], meta["add_indel_length"], sd)
+    y = _hip_predict(m, "cuda:0", x)
+    err = util.assert_rows_match(y, util.golden_y(name), what=name)
+    print(f"{name}: max|dY| vs reference = {err:.2e}")
+    assert err < 2e-5  # fp32 MFMA path: expected ~1e-6
+
+
+@pytest.mark.parametrize("name", ["fa_realistic", "fa_dwell", "fa_uniform"])
+def test_full_alignment_layers_vs_oracle(name, oracle_mod):
+    meta = util.manifest()[name]
+    sd, x = util.case_inputs(meta)
+    x = x[:6]
+    m = make_model(meta["kind"], meta["channels"], True, sd, keep=True)
+    y = m.predict_numpy(x)
+    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+    for l in range(9):
+        a = m.debug_fetch(f"act{l}", d[f"act{l}"].shape)
+        scale = max(1.0, float(np.abs(d[f"act{l}"]).max()))
+        err = float(np.abs(a - d[f"act{l}"]).max()) / scale
+        assert err < 2e-5, f"{name}: conv layer {l} rel err {err:.3e}"
+    for key in ("spp", "l4_out"):
+        a = m.debug_fetch(key, d[key].shape)
+        scale = max(1.0, float(np.abs(d[key]).max()))
+        assert float(np.abs(a - d[key]).max()) / scale < 2e-5, key
+    util.assert_rows_match(y, y_o, what=name + " vs oracle")
+
+
+@pytest.mark.parametrize("name", ["pileup_realistic", "pileup_uniform_i32", "pileup_indel_heads"])
+def test_pileup_layers_vs_oracle(name, oracle_mod):
+    meta = util.manifest()[name]
+    sd, x = util.case_inputs(meta)
+    m = make_model(meta["kind"], meta["channels"], meta["add_indel_length"], sd, keep=True)
+    y = m.predict_numpy(x)
+    y_o, d = oracle_mod.pileup_forward(sd, x, meta["add_indel_length"], debug=True)
+    for key in ("lstm1_out", "lstm2_out", "l4_out"):
+        a = m.debug_fetch(key, d[key].shape)
+        scale = max(1.0, float(np.abs(d[key]).max()))
+        err = float(np.abs(a - d[key]).max()) / scale
+        assert err < 2e-5, f"{name}: {key} err {err:.3e}"
+    util.assert_rows_match(y, y_o, what=name + " vs oracle")
+
+
+@pytest.mark.parametrize("kind", [syn.PILEUP, syn.FULL_ALIGNMENT])
+def test_ragged_and_empty_batches(kind, oracle_mod):
+    """batch sizes that are not multiples of any tile (1, 17, 129, 200 = the reference's predictBatchSize), and 0."""
+    indel = kind == syn.FULL_ALIGNMENT
+    ch = 18 if kind == syn.PILEUP else 8
+    sd = syn.make_state_dict(kind, ch, indel, seed=21)
+    m = make_model(kind, ch, indel, sd)
+    x = syn.make_windows(kind, 200, seed=22)
+    y_o = oracle_mod.forward(kind, sd, x, indel)
+    y_all = m.predict_numpy(x)
+    util.assert_rows_match(y_all, y_o, what="batch 200")
+    for n in (1, 17, 129):
+        y = m.predict_numpy(x[:n])
+        # per-window independence: the first n rows must not depend on the batch they were computed in
+        assert np.array_equal(y, y_all[:n]), f"rows change with batch size {n}"
+    y0 = m.predict_numpy(x[:0])
+    assert y0.shape == (0, 90 if indel else 24)
+
+
+def test_extreme_and_degenerate_windows(oracle_mod):
+    """int8 extremes (-128 / 127: the wrap-around quirk of the GPU .npy path, CreateTensorPileupFromCffi.py:447),
+    all-zero windows, single-read full-alignment windows."""
+    sd = syn.make_state_dict(syn.PILEUP, seed=31)
+    m = make_model(syn.PILEUP, 18, False, sd)
+    x = np.zeros((8, 33, 18), np.int8)
+    x[1] = 127
+    x[2] = -128
+    x[3, ::2] = 127
+    x[3, 1::2] = -128
+    x[4:] = syn.make_pileup_windows(4, seed=32, recipe="uniform")
+    util.assert_rows_match(m.predict_numpy(x), oracle_mod.pileup_forward(sd, x), what="pileup extremes")
+    sdf = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=33)
+    mf = make_model(syn.FULL_ALIGNMENT, 8, True, sdf)
+    xf = np.zeros((6, 89, 33, 8), np.int8)
+    xf[1] = 127
+    xf[2] = -128
+    xf[3, 44] = syn.make_fa_windows(1, seed=34, recipe="uniform")[0, 0]  # one read in the middle row
+    xf[4:] = syn.make_fa_windows(2, seed=35, recipe="uniform")
+    util.assert_rows_match(mf.predict_numpy(xf), oracle_mod.fa_forward(sdf, xf, True), what="fa extremes")
+
+
+def test_int32_and_int8_pileup_inputs_agree():
+    sd = syn.make_state_dict(syn.PILEUP, seed=41)
+    m = make_model(syn.PILEUP, 18, False, sd)
+    x8 = syn.make_pileup_windows(64, seed=42)
+    assert np.array_equal(m.predict_numpy(x8), m.predict_numpy(x8.astype(np.int32)))
+
+
+def test_async_submit_wait_and_device_paths_agree():
+    import torch
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=51)
+    m = make_model(syn.FULL_ALIGNMENT, 8, True, sd)
+    xa = syn.make_fa_windows(40, seed=52)
+    xb = syn.make_fa_windows(24, seed=53)
+    ya, yb = m.predict_numpy(xa), m.predict_numpy(xb)
+    ta = m.submit(xa, slot=0)
+    tb = m.submit(xb, slot=1)
+    assert np.array_equal(m.wait(ta), ya) and np.array_equal(m.wait(tb), yb)
+    yd = m(torch.from_numpy(xa).cuda())
+    torch.cuda.synchronize()
+    assert yd.is_cuda and np.array_equal(yd.cpu().numpy(), ya)
+
+
+def test_strict_state_dict_loading():
+    sd = syn.make_state_dict(syn.PILEUP, seed=61)
+    m = Clair3_P(predict=True).to("cuda:0")
+    missing = dict(sd)
+    missing.pop("L4.bias")
+    with pytest.raises(_lib.C3Error, match="Missing key.*L4.bias"):
+        m.load_state_dict(missing)
+    extra = dict(sd)
+    extra["bogus.weight"] = np.zeros(3, np.float32)
+    with pytest.raises(_lib.C3Error, match="Unexpected key"):
+        m.load_state_dict(extra)
+    bad = dict(sd)
+    bad["L5_1.weight"] = np.zeros((128, 64), np.float32)
+    with pytest.raises(_lib.C3Error, match="size mismatch.*L5_1.weight"):
+        m.load_state_dict(bad)
+    with pytest.raises(_lib.C3Error, match="shape"):
+        m.load_state_dict(sd)
+        m.predict_numpy(np.zeros((2, 33, 17), np.int8))
+
+
+def test_checkpoint_file_roundtrip(tmp_path):
+    """the .pt path of _load_torch_checkpoint: bare state_dict and {"state_dict": ...}, with and without '.pt'."""
+    import torch
+    from clair3_amd.predict import build_model
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 9, True, seed=71)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    torch.save(tsd, str(tmp_path / "full_alignment.pt"))
+    torch.save({"state_dict": tsd}, str(tmp_path / "wrapped.pt"))
+    x = syn.make_fa_windows(5, seed=72, channels=9)
+    m0 = make_model(syn.FULL_ALIGNMENT, 9, True, sd)
+    y0 = m0.predict_numpy(x)
+    for path in (str(tmp_path / "full_alignment"), str(tmp_path / "wrapped.pt")):
+        m = build_model(pileup=False, add_indel_length=True, enable_dwell_time=True, device="cuda:0", chkpnt_fn=path)
+        assert np.array_equal(m.predict_numpy(x), y0)
+
+
+# ---------------------------------------------------------------- full BASELINE.json sizes, property based
+@pytest.mark.parametrize("kind,batch", [(syn.PILEUP, 1024), (syn.FULL_ALIGNMENT, 256)])
+def test_full_size_properties(kind, batch, oracle_mod):
+    """configs[1] (B=1024 pileup) and configs[2] (B=256 full alignment): rows are probability vectors, the
+    result is deterministic, invariant under a permutation of the windows (per-window independence, so
+    sharding across GPUs cannot change a call), and a random sample of rows matches the oracle."""
+    indel = kind == syn.FULL_ALIGNMENT
+    ch = 18 if kind == syn.PILEUP else 8
+    sd = syn.make_state_dict(kind, ch, indel, seed=81)
+    m = make_model(kind, ch, indel, sd)
+    x = syn.make_windows(kind, batch, seed=82)
+    y = m.predict_numpy(x)
+    assert y.shape == (batch, 90 if indel else 24) and np.isfinite(y).all()
+    for lo, hi in util.HEAD_SLICES[: 4 if indel else 2]:
+        np.testing.assert_allclose(y[:, lo:hi].sum(1), 1.0, atol=2e-6)
+        assert (y[:, lo:hi] > 0).all()  # SELU before soft-max floors every logit (model.py:142)
+    assert np.array_equal(y, m.predict_numpy(x)), "not deterministic"
+    perm = np.random.default_rng(0).permutation(batch)
+    assert np.array_equal(m.predict_numpy(x[perm]), y[perm]), "rows depend on their batch position"
+    pick = np.sort(np.random.default_rng(1).choice(batch, size=24, replace=False))
+    util.assert_rows_match(y[pick], oracle_mod.forward(kind, sd, x[pick], indel), what="sampled rows vs oracle")
+
+
+def test_multiple_micro_batches(oracle_mod):
+    """more windows than one workspace micro-batch (2048 full-alignment windows): chunking must be seamless."""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, False, seed=91)
+    m = make_model(syn.FULL_ALIGNMENT, 8, False, sd)
+    base = syn.make_fa_windows(64, seed=92)
+    x = np.concatenate([base] * 33)[: 2048 + 37]
+    y = m.predict_numpy(x)
+    y64 = m.predict_numpy(base)
+    for i in range(0, len(x), 64):
+        n = min(64, len(x) - i)
+        assert np.array_equal(y[i:i + n], y64[:n])
+    util.assert_rows_match(y64[:8], oracle_mod.fa_forward(sd, base[:8], False), what="fa 24-col")

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Layer-by-layer diagnostic of the HIP path against the CPU oracle (run on the GPU box).
+Never asserts: prints one line per tensor so a single gpurun call localises a bug."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from clair3_amd import synthetic as syn  # noqa: E402
+from clair3_amd.model import Clair3_F, Clair3_P  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def report(tag, a, ref):
+    d = np.abs(a.astype(np.float64) - ref.astype(np.float64))
+    scale = max(1.0, float(np.abs(ref).max()))
+    bad = d > 1e-4 * scale
+    msg = f"  {tag:12s} shape={str(a.shape):22s} max_abs_err={d.max():.3e} ref_max={np.abs(ref).max():.3e} bad={bad.mean():.4f}"
+    if bad.any():
+        idx = np.argwhere(bad)
+        msg += f" first_bad={idx[0].tolist()} got={a[tuple(idx[0])]:.5f} want={ref[tuple(idx[0])]:.5f}"
+        # which trailing-dim / row positions are wrong (helps to spot tile/lane mapping bugs)
+        flat = bad.reshape(-1, bad.shape[-1])
+        msg += f" bad_cols={np.nonzero(flat.any(0))[0][:12].tolist()} bad_rows={np.nonzero(flat.any(1))[0][:12].tolist()}"
+    print(msg, flush=True)
+
+
+def fa(channels=8, n=6, seed=0):
+    print(f"== full alignment C={channels} n={n}")
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, channels, True, seed=seed)
+    x = syn.make_fa_windows(n, seed=seed, channels=channels)
+    m = Clair3_F(add_indel_length=True, predict=True, input_channels=channels).keep_activations(True).to("cuda:0")
+    m.load_state_dict(sd)
+    y = m.predict_numpy(x)
+    y_o, d = oracle.fa_forward(sd, x, True, debug=True)
+    for l in range(9):
+        report(f"act{l}", m.debug_fetch(f"act{l}", d[f"act{l}"].shape), d[f"act{l}"])
+    report("spp", m.debug_fetch("spp", d["spp"].shape), d["spp"])
+    report("l4_out", m.debug_fetch("l4_out", d["l4_out"].shape), d["l4_out"])
+    report("y", y, y_o)
+
+
+def pileup(n=48, seed=0, dtype=np.int8):
+    print(f"== pileup n={n} {np.dtype(dtype).name}")
+    sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=seed)
+    x = syn.make_pileup_windows(n, seed=seed, dtype=dtype)
+    m = Clair3_P(add_indel_length=False, predict=True).keep_activations(True).to("cuda:0")
+    m.load_state_dict(sd)
+    y = m.predict_numpy(x)
+    y_o, d = oracle.pileup_forward(sd, x, False, debug=True)
+    # gx1 = x W_ih^T + b in the kernel's permuted column order: check through lstm1_out instead
+    for key in ("lstm1_out", "lstm2_out", "l4_out"):
+        report(key, m.debug_fetch(key, d[key].shape), d[key])
+    report("y", y, y_o)
+
+
+def quick_timing():
+    import torch
+    print("== quick timing (device-resident, includes all kernels)")
+    for kind, B, ch, indel in ((syn.FULL_ALIGNMENT, 256, 8, True), (syn.PILEUP, 1024, 18, False)):
+        sd = syn.make_state_dict(kind, ch, indel, seed=0)
+        cls = Clair3_P if kind == syn.PILEUP else Clair3_F
+        m = cls(add_indel_length=indel, predict=True, input_channels=ch).to("cuda:0")
+        m.load_state_dict(sd)
+        x = torch.from_numpy(syn.make_windows(kind, B, seed=1)).cuda()
+        for _ in range(3):
+            m(x)
+        torch.cuda.synchronize()
+        t = time.time()
+        it = 20
+        for _ in range(it):
+            m(x)
+        torch.cuda.synchronize()
+        dt = (time.time() - t) / it
+        print(f"  {kind:15s} B={B}: {dt * 1e3:.3f} ms/batch -> {B / dt:,.0f} windows/s", flush=True)
+        m.profile(True)
+        m.profile_reset()
+        for _ in range(5):
+            m(x)
+        torch.cuda.synchronize()
+        for r in m.profile_read():
+            ms = r["total_ms"] / r["launches"]
+            print(f"    {r['name']:10s} {ms * 1e3:9.1f} us/launch  {r['flops'] / r['launches'] / ms / 1e9:8.1f} TFLOP/s"
+                  f"  {r['bytes'] / r['launches'] / ms / 1e6:8.1f} GB/s", flush=True)
+        m.profile(False)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["fa", "fa9", "pileup", "pileup32", "time"]
+    for w in what:
+        try:
+            if w == "fa":
+                fa(8)
+            elif w == "fa9":
+                fa(9, n=3, seed=3)
+            elif w == "pileup":
+                pileup()
+            elif w == "pileup32":
+                pileup(n=20, seed=1, dtype=np.int32)
+            elif w == "time":
+                quick_timing()
+        except Exception as e:  # keep going: the point is to collect as much as possible per GPU call
+            print(f"!! {w} failed: {type(e).__name__}: {e}", flush=True)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# One gpurun call: diagnostics -> parity tests -> bench -> rocprof kernel trace.  Everything lands in gpurun_out/.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+STAGES="${1:-diag test bench prof}"
+for s in $STAGES; do
+  case $s in
+    diag)  timeout 600 python tools/gpu_diag.py > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
+    test)  timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu.txt ;;
+    testall) timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.txt ;;
+    smoke) timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.txt 2>&1; echo "smoke rc=$?"; tail -5 gpurun_out/smoke.txt ;;
+    bench) timeout 900 python bench.py --gpus 1 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.json | head -c 3000 ;;
+    prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err"); echo "prof rc=$?"; find gpurun_out/prof -name '*stats*' | head ;;
+    pmc)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_fetch.err"); echo "pmc fetch rc=$?"
+           (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OLDPWD/gpurun_out/pmc_write" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_write.err"); echo "pmc write rc=$?" ;;
+  esac
+done
+cat gpurun_out/diag.txt 2>/dev/null | head -80
