@@ -41,6 +41,31 @@ class C3Error(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, found through $ORIGIN) while libc3hip.so's RUNPATH points at /opt/rocm.  If libc3hip is
+    loaded first, a later ``import torch`` brings a SECOND copy of the runtime whose HSA initialisation fails
+    ("No HIP GPUs are available").  Pre-loading torch's copy (without importing torch) makes libc3hip's
+    NEEDED libamdhip64.so.7 resolve to it, so both share one runtime whatever the import order.  Without
+    torch installed nothing happens and /opt/rocm's runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libc3hip.so once; raise if it is not there (no CPU fallback by design)."""
     global _lib
@@ -49,6 +74,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise C3Error(f"{LIB_PATH} not found: build it with `python -m clair3_amd.build` "
                       "(hipcc --offload-arch=gfx950); clair3_amd has no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     L.c3_version.restype = C.c_char_p
     L.c3_last_error.restype = C.c_char_p

@@ -45,111 +45,132 @@ __device__ __forceinline__ int xcd_tile_index(int block, int n_tiles) {
 
 // ------------------------------------------------------------------------------------------ A loaders
 // Every loader serves R = BM/32 rows per thread: rows lr + 32*i of the tile, 16-B chunk lc of the K chunk.
+// A fetch is split in two so that the global-load latency hides behind the MFMAs of the current chunk:
+//   issue(raw)        -- address arithmetic + the global loads, nothing that consumes the loaded values;
+//   finish(raw, out)  -- whatever turns the raw registers into the fp32 chunk (int -> float conversion),
+//                        called after the MFMA block, right before the LDS write.
+// Padding taps / out-of-range elements are not branched around and not masked afterwards: their ADDRESS is
+// redirected to a 256-byte zero page, so the loaded value already is the padding value.  Rows beyond M are
+// clamped to a valid row -- their accumulators are never stored.
 
 // 3x3 / pad 1 convolution over NHWC fp32, Cin % 32 == 0.  K order = (kh, kw, cin).
 struct ConvLoaderParams {
     const float *x;
+    const float *zeros;  // >= 16 readable zero bytes
     int Hin, Win, Cin, Ho, Wo, stride;
     int chunks_per_tap;  // Cin / 32
 };
 template <int R>
 struct ConvLoader {
     typedef ConvLoaderParams Params;
-    const float *x;
+    typedef f32x4 Raw;
+    const float *x, *zeros;
     int64_t off[R];
     uint32_t mask[R];
     int Win, Cin, cpt, tap, cc;
     __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
-        x = p.x, Win = p.Win, Cin = p.Cin, cpt = p.chunks_per_tap, tap = 0, cc = 0;
+        x = p.x, zeros = p.zeros, Win = p.Win, Cin = p.Cin, cpt = p.chunks_per_tap, tap = 0, cc = 0;
         const int hw = p.Ho * p.Wo;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int m = m0 + lr + 32 * i;
+            int m = m0 + lr + 32 * i;
+            if (m >= M) m = M - 1;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
+            off[i] = (((int64_t)b * p.Hin + ih0) * p.Win + iw0) * p.Cin + lc * 4;
             uint32_t mk = 0;
-            int64_t o = 0;
-            if (m < M) {
-                const int b = m / hw, rem = m - b * hw;
-                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
-                o = (((int64_t)b * p.Hin + ih0) * p.Win + iw0) * p.Cin + lc * 4;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ih = ih0 + t / 3, iw = iw0 + t % 3;
-                    if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) mk |= 1u << t;
-                }
+            for (int t = 0; t < 9; ++t) {
+                const int ih = ih0 + t / 3, iw = iw0 + t % 3;
+                if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) mk |= 1u << t;
             }
-            off[i] = o, mask[i] = mk;
+            mask[i] = mk;
         }
     }
-    // fetch the next chunk in K order (called once per chunk, in order)
-    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
+    // loads of the next chunk in K order (called once per chunk, in order)
+    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
         const int kh = tap / 3, kw = tap - kh * 3;
         const int64_t koff = (int64_t)(kh * Win + kw) * Cin + cc * kBK;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            // always issue the load (from a safe address when the tap is padding) and select afterwards: a
-            // branch around each load would make the compiler drain vmcnt per row
             const bool ok = (mask[i] >> tap) & 1u;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(ok ? x + off[i] + koff : x);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            out[i] = ok ? v : z;
+            raw[i] = *reinterpret_cast<const f32x4 *>(ok ? x + off[i] + koff : zeros);
         }
         if (++cc == cpt) cc = 0, ++tap;
+    }
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) out[i] = raw[i];
     }
 };
 
 // conv1 of Clair3_F straight from the int8 window (B, H, W, C), stride 2, pad 1, 3*C <= 32.
-// K is padded to 3 chunks (one per kh) of 32 slots: slot j = kw*C + c for j < 3C, zero beyond; the three
-// input pixels (kw = 0..2) of one kh are 3C consecutive bytes.
+// K is padded to 3 chunks (one per kh) of 32 slots: slot j = kw*C + c for j < 3C (weights are zero beyond);
+// the three input pixels (kw = 0..2) of one kh are 3C consecutive bytes starting at pixel (ih, iw0).
 struct Conv1LoaderParams {
     const int8_t *x;
+    const int8_t *zeros;
     int Hin, Win, C, Ho, Wo;
 };
 template <int R>
 struct Conv1Loader {
     typedef Conv1LoaderParams Params;
-    const int8_t *x;
-    int64_t off[R];  // byte offset of (b, ih0, iw0, 0) + 4*lc
-    int ih0[R], iw0[R];
-    int Hin, Win, C, lc4, kh;
+    struct Raw {
+        int v[4];
+    };
+    const int8_t *x, *zeros;
+    int64_t off[R];     // byte offset of (b, ih0, iw0, 0) + 4*lc
+    int ih0[R];
+    uint32_t colok[R];  // bit e: slot 4*lc+e is a real (kw, c) whose column iw0+kw is inside the image
+    int Hin, rowbytes, kh;
     __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
-        x = p.x, Hin = p.Hin, Win = p.Win, C = p.C, lc4 = lc * 4, kh = 0;
+        x = p.x, zeros = p.zeros, Hin = p.Hin, rowbytes = p.Win * p.C, kh = 0;
         const int hw = p.Ho * p.Wo;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int m = m0 + lr + 32 * i;
-            if (m < M) {
-                const int b = m / hw, rem = m - b * hw;
-                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                ih0[i] = oh * 2 - 1, iw0[i] = ow * 2 - 1;
-                off[i] = (((int64_t)b * p.Hin + ih0[i]) * p.Win + iw0[i]) * p.C + lc4;
-            } else {
-                ih0[i] = -100000, iw0[i] = 0, off[i] = 0;  // every row test fails -> zeros
-            }
-        }
-    }
-    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            f32x4 v;
-            const int ih = ih0[i] + kh;
-            const bool row_ok = ih >= 0 && ih < Hin;
-            const int8_t *p = x + off[i] + (int64_t)kh * Win * C;
+            int m = m0 + lr + 32 * i;
+            if (m >= M) m = M - 1;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int iw0 = ow * 2 - 1;
+            ih0[i] = oh * 2 - 1;
+            off[i] = (((int64_t)b * p.Hin + ih0[i]) * p.Win + iw0) * p.C + lc * 4;
+            uint32_t ck = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int j = lc4 + e;
-                const int iw = iw0[i] + j / C;
-                const bool ok = row_ok && j < 3 * C && iw >= 0 && iw < Win;
-                const int8_t q = *(ok ? p + e : x);
-                v[e] = ok ? (float)q : 0.f;
+                const int j = lc * 4 + e;
+                const int kw = (j >= p.C) + (j >= 2 * p.C);
+                const int iw = iw0 + kw;
+                if (j < 3 * p.C && iw >= 0 && iw < p.Win) ck |= 1u << e;
             }
-            out[i] = v;
+            colok[i] = ck;
+        }
+    }
+    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ih = ih0[i] + kh;
+            const bool row_ok = ih >= 0 && ih < Hin;
+            const int8_t *p = x + off[i] + (int64_t)kh * rowbytes;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = row_ok && ((colok[i] >> e) & 1u);
+                raw[i].v[e] = *(ok ? p + e : zeros);
+            }
         }
         ++kh;
     }
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[i][e] = (float)raw[i].v[e];
+    }
 };
 
-// Row-major integer matrix (the pileup window rows: M = B*33 rows of C counts), K padded to one 32-chunk.
+// Row-major integer matrix (the pileup window rows: M = B*33 rows of C counts), K padded to one 32-chunk
+// (the packed weights are zero for k >= C, so the clamped duplicates loaded there contribute nothing).
 template <typename T>
 struct IntRowLoaderParams {
     const T *x;
@@ -158,30 +179,31 @@ struct IntRowLoaderParams {
 template <int R, typename T>
 struct IntRowLoader {
     typedef IntRowLoaderParams<T> Params;
+    struct Raw {
+        int v[4];
+    };
     const T *row[R];
-    bool ok[R];
     int C, lc4;
     __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
         C = p.C, lc4 = lc * 4;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int m = m0 + lr + 32 * i;
-            ok[i] = m < M;
-            row[i] = p.x + (int64_t)(ok[i] ? m : 0) * p.C;
+            int m = m0 + lr + 32 * i;
+            if (m >= M) m = M - 1;
+            row[i] = p.x + (int64_t)m * p.C;
         }
     }
-    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
+    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            f32x4 v;
+        for (int i = 0; i < R; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool in = ok[i] && lc4 + e < C;
-                const T q = row[i][in ? lc4 + e : 0];
-                v[e] = in ? (float)q : 0.f;
-            }
-            out[i] = v;
-        }
+            for (int e = 0; e < 4; ++e) raw[i].v[e] = (int)row[i][lc4 + e < C ? lc4 + e : C - 1];
+    }
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[i][e] = (float)raw[i].v[e];
     }
 };
 
@@ -193,27 +215,27 @@ struct DenseLoaderParams {
 template <int R>
 struct DenseLoader {
     typedef DenseLoaderParams Params;
+    typedef f32x4 Raw;
     const float *row[R];
-    bool ok[R];
     int k;
     __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
         k = 0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int m = m0 + lr + 32 * i;
-            ok[i] = m < M;
-            row[i] = p.a + (int64_t)(ok[i] ? m : 0) * p.lda + lc * 4;
+            int m = m0 + lr + 32 * i;
+            if (m >= M) m = M - 1;
+            row[i] = p.a + (int64_t)m * p.lda + lc * 4;
         }
     }
     __device__ __forceinline__ void seek(int k0) { k = k0; }
-    __device__ __forceinline__ void fetch(f32x4 (&out)[R]) {
+    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(row[i] + k);  // row clamped to 0 when out of range
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            out[i] = ok[i] ? v : z;
-        }
+        for (int i = 0; i < R; ++i) raw[i] = *reinterpret_cast<const f32x4 *>(row[i] + k);
         k += kBK;
+    }
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) out[i] = raw[i];
     }
 };
 
@@ -285,10 +307,12 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
+    typename Loader::Raw raw[RA];
     f32x4 ra[RA], rb[RBt];
-    loader.fetch(ra);
+    loader.issue(raw);
 #pragma unroll
     for (int i = 0; i < RBt; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(bptr[i]);
+    loader.finish(raw, ra);
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_a[i]) = ra[i];
 #pragma unroll
@@ -299,28 +323,39 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         const char *cur = smem + (kc & 1) * kStage;
         char *nxt = smem + ((kc + 1) & 1) * kStage;
         const bool more = kc + 1 < gp.nk;
-        if (more) {
-            loader.fetch(ra);
+        if (more) {  // global loads of chunk kc+1: in flight during the MFMAs below
+            loader.issue(raw);
 #pragma unroll
             for (int i = 0; i < RBt; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)(kc + 1) * kBK);
         }
+        // fragments of k-group g+1 are read from LDS while the MFMAs of group g run
+        f32x4 a[2][RB], b[2][CB];
+        {
+            const int coff = (fhi ^ fsw) << 4;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) a[0][i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
+#pragma unroll
+            for (int i = 0; i < CB; ++i) b[0][i] = *reinterpret_cast<const f32x4 *>(cur + rd_b[i] + coff);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int coff = ((2 * g + fhi) ^ fsw) << 4;
-            f32x4 a[RB], b[CB];
+            if (g < 3) {
+                const int coff = ((2 * (g + 1) + fhi) ^ fsw) << 4;
 #pragma unroll
-            for (int i = 0; i < RB; ++i) a[i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
+                for (int i = 0; i < RB; ++i) a[(g + 1) & 1][i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
 #pragma unroll
-            for (int i = 0; i < CB; ++i) b[i] = *reinterpret_cast<const f32x4 *>(cur + rd_b[i] + coff);
+                for (int i = 0; i < CB; ++i) b[(g + 1) & 1][i] = *reinterpret_cast<const f32x4 *>(cur + rd_b[i] + coff);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int c = 0; c < CB; ++c)
-                        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[c][j], acc[i][c], 0, 0, 0);
+                        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][j], b[g & 1][c][j], acc[i][c], 0, 0, 0);
         }
         if (more) {
+            loader.finish(raw, ra);
 #pragma unroll
             for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_a[i]) = ra[i];
 #pragma unroll

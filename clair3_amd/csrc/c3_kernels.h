@@ -38,7 +38,16 @@ struct LstmParams {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int H>
+// Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Absolute error
+// of a gate value <= ~2e-7, two orders of magnitude inside the 1e-4 parity budget even after 66 steps; the
+// libm forms (expf / tanhf) cost ~10x the instructions and sit on the per-step critical path.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
+// RESIDENT: keep this wave's W_hh fragments (4 gates x H/16 k-groups = H registers) in VGPRs for all T steps
+// (H = 128: 8 waves x 2 per SIMD fit the 512-entry file).  Otherwise stream them from L2 every step through
+// a 2-deep register ring so the loads of k-group q+1 fly while the MFMAs of group q issue.
+template <int H, bool RESIDENT>
 __global__ __launch_bounds__(H * 4) void lstm_recurrent_kernel(LstmParams p) {
     constexpr int NW = H / 16;   // waves
     constexpr int NQ = H / 16;   // k groups of 16
@@ -56,14 +65,30 @@ __global__ __launch_bounds__(H * 4) void lstm_recurrent_kernel(LstmParams p) {
     const int gx_col = dir * 4 * H + wave * 64 + col;
     const int h_col = dir * H + wave * 16 + col;
 
+    f32x4v wres[RESIDENT ? 4 * NQ : 1];
+    if constexpr (RESIDENT) {
+#pragma unroll
+        for (int i = 0; i < 4 * NQ; ++i) wres[i] = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)i * 256);
+    }
+
     float c[4] = {0.f, 0.f, 0.f, 0.f};
     bool rowok[4];
     int64_t rowbase[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const int b = b0 + 4 * s + v;
+        int b = b0 + 4 * s + v;
         rowok[v] = b < p.B;
-        rowbase[v] = (int64_t)(rowok[v] ? b : 0) * p.T;
+        if (!rowok[v]) b = p.B - 1;
+        rowbase[v] = (int64_t)b * p.T;
+    }
+    // x-projection (+ both biases) of the first step
+    f32x4v gxn[4];
+    {
+        const int t0 = dir ? p.T - 1 : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) gxn[g][v] = p.gx[(rowbase[v] + t0) * p.ld_gx + gx_col + g * 16];
     }
     __syncthreads();
 
@@ -72,33 +97,55 @@ __global__ __launch_bounds__(H * 4) void lstm_recurrent_kernel(LstmParams p) {
         const int cur = step & 1;
         f32x4v acc[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) acc[g] = gxn[g];
+        if (step + 1 < p.T) {  // next step's projection: in flight during this step's MFMAs
+            const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                acc[g][v] = p.gx[(rowbase[v] + t) * p.ld_gx + gx_col + g * 16];
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) gxn[g][v] = p.gx[(rowbase[v] + tn) * p.ld_gx + gx_col + g * 16];
+        }
         if (step > 0) {  // h_{-1} = 0
+            if constexpr (RESIDENT) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                // A fragment: rows = windows (lane&15), k = 16q + 4s + e
-                const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4v w = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)(g * NQ + q) * 256);
+                for (int q = 0; q < NQ; ++q) {
+                    // A fragment: rows = windows (lane&15), k = 16q + 4s + e
+                    const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w[e], acc[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wres[g * NQ + q][e], acc[g], 0, 0, 0);
+                }
+            } else {
+                f32x4v wb[2][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) wb[0][g] = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)(g * NQ) * 256);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + 1 < NQ) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            wb[(q + 1) & 1][g] = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)(g * NQ + q + 1) * 256);
+                    }
+                    const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wb[q & 1][g][e], acc[g], 0, 0, 0);
                 }
             }
         }
         // cell update.  C/D map of 16x16x4: col = lane&15 (unit), row = 4*(lane>>4) + v (window)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const float ig = sigmoid_f(acc[0][v]);
-            const float fg = sigmoid_f(acc[1][v]);
-            const float gg = tanhf(acc[2][v]);
-            const float og = sigmoid_f(acc[3][v]);
+            const float ig = fast_sigmoid(acc[0][v]);
+            const float fg = fast_sigmoid(acc[1][v]);
+            const float gg = fast_tanh(acc[2][v]);
+            const float og = fast_sigmoid(acc[3][v]);
             c[v] = fg * c[v] + ig * gg;
-            const float h = og * tanhf(c[v]);
+            const float h = og * fast_tanh(c[v]);
             hbuf[cur ^ 1][4 * s + v][wave * 16 + col] = h;
             if (rowok[v]) p.hout[(rowbase[v] + t) * (2 * H) + h_col] = h;
         }
@@ -118,16 +165,27 @@ struct SppParams {
     short h0[16], h1[16], w0[16], w1[16], pad[16];
 };
 __global__ __launch_bounds__(256) void spp_kernel(SppParams p) {
-    const int64_t total = (int64_t)p.B * p.nbins * p.C;
+    // one thread per (window, channel): every input value is read exactly once (coalesced over channels) and
+    // folded into the running max of each bin that contains it
+    const int64_t total = (int64_t)p.B * p.C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % p.C);
-        const int bin = (int)((i / p.C) % p.nbins);
-        const int64_t b = i / ((int64_t)p.C * p.nbins);
+        const int64_t b = i / p.C;
         const float *src = p.in + b * p.H * p.W * p.C + c;
-        float m = p.pad[bin] ? 0.f : -INFINITY;
-        for (int h = p.h0[bin]; h < p.h1[bin]; ++h)
-            for (int w = p.w0[bin]; w < p.w1[bin]; ++w) m = fmaxf(m, src[((int64_t)h * p.W + w) * p.C]);
-        p.out[i] = m;
+        float m[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m[k] = (k < p.nbins && p.pad[k]) ? 0.f : -INFINITY;
+        for (int h = 0; h < p.H; ++h)
+            for (int w = 0; w < p.W; ++w) {
+                const float v = src[((int64_t)h * p.W + w) * p.C];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < p.nbins && h >= p.h0[k] && h < p.h1[k] && w >= p.w0[k] && w < p.w1[k]) m[k] = fmaxf(m[k], v);
+            }
+        float *dst = p.out + b * p.nbins * p.C + c;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < p.nbins) dst[(int64_t)k * p.C] = m[k];
     }
 }
 
@@ -147,7 +205,7 @@ struct TailParams {
     float *l4_dbg;      // optional [B][FC]
     int B, S, NB, nout;
 };
-constexpr int kTailWindows = 8;
+constexpr int kTailWindows = 2;  // windows per workgroup: B/2 workgroups keep every CU busy at B >= 512
 
 template <int FC>
 __global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
@@ -161,35 +219,48 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
     auto head_n = [](int br) { return br == 0 ? 21 : br == 1 ? 3 : 33; };
     auto head_off = [](int br) { return br == 0 ? 0 : br == 1 ? 21 : br == 2 ? 24 : 57; };
 
+    // 1. deterministic split-K reduction (fixed order s = 0..S-1) + bias + SELU
     for (int i = tid; i < TB * FC; i += 256) {
         const int t = i / FC, k = i - t * FC;
-        const int b = b0 + t;
-        float v = 0.f;
-        if (b < p.B) {
-            v = p.b4[k];
-            for (int s = 0; s < p.S; ++s) v += p.part[((int64_t)s * p.B + b) * FC + k];
-            v = selu_f(v);
-            if (p.l4_dbg) p.l4_dbg[(int64_t)b * FC + k] = v;
+        const int b = b0 + t < p.B ? b0 + t : p.B - 1;
+        const float *src = p.part + (int64_t)b * FC + k;
+        const int64_t sstride = (int64_t)p.B * FC;
+        float v = p.b4[k];
+        int s = 0;
+        for (; s + 4 <= p.S; s += 4) {  // 4 independent loads in flight, summed in order
+            const float v0 = src[(s + 0) * sstride], v1 = src[(s + 1) * sstride];
+            const float v2 = src[(s + 2) * sstride], v3 = src[(s + 3) * sstride];
+            v = (((v + v0) + v1) + v2) + v3;
         }
+        for (; s < p.S; ++s) v += src[s * sstride];
+        v = selu_f(v);
+        if (p.l4_dbg && b0 + t < p.B) p.l4_dbg[(int64_t)b * FC + k] = v;
         xs[t][k] = v;
     }
     __syncthreads();
 
+    // 2. the NB branch layers as one [FC] x [NB*128] product; weights are read coalesced, 8 k per batch of loads
     const int n5 = p.NB * 128;
     for (int j = tid; j < n5; j += 256) {
         float acc[TB];
 #pragma unroll
         for (int t = 0; t < TB; ++t) acc[t] = p.b5[j];
-        for (int k = 0; k < FC; ++k) {
-            const float w = p.w5t[(int64_t)k * n5 + j];
+        const float *w = p.w5t + j;
+        for (int k = 0; k < FC; k += 8) {
+            float wv[8];
 #pragma unroll
-            for (int t = 0; t < TB; ++t) acc[t] = fmaf(xs[t][k], w, acc[t]);
+            for (int u = 0; u < 8; ++u) wv[u] = w[(int64_t)(k + u) * n5];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < TB; ++t) acc[t] = fmaf(xs[t][k + u], wv[u], acc[t]);
         }
 #pragma unroll
         for (int t = 0; t < TB; ++t) h5[t][j] = selu_f(acc[t]);
     }
     __syncthreads();
 
+    // 3. heads (block diagonal: head b reads branch b) + SELU
     for (int i = tid; i < TB * p.nout; i += 256) {
         const int t = i / p.nout, o = i - t * p.nout;
         const int br = o < 21 ? 0 : o < 24 ? 1 : o < 57 ? 2 : 3;
@@ -197,11 +268,18 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
         float acc = p.bh[br * 64 + idx];
         const float *w = p.wh + (int64_t)br * 128 * 64 + idx;
         const float *h = &h5[t][br * 128];
-        for (int k = 0; k < 128; ++k) acc = fmaf(h[k], w[k * 64], acc);
+        for (int k = 0; k < 128; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w[(k + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(h[k + u], wv[u], acc);
+        }
         lg[t][o] = selu_f(acc);
     }
     __syncthreads();
 
+    // 4. soft-max per (window, head)
     for (int i = tid; i < TB * p.NB; i += 256) {
         const int t = i / p.NB, br = i - t * p.NB;
         const int b = b0 + t;

@@ -97,6 +97,7 @@ struct c3_model {
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
+    float *zeros = nullptr;  // 256-byte zero page: padding taps of the conv loaders read from here
     int FC = 0, K4 = 0;
 
     // ---- workspace ----
@@ -395,10 +396,10 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
         ProfScope ps(m, s, kFaLayerTag[l], flops, bytes);
         EpilogueParams ep{m->act[l], m->conv_b[l], l % 3 == 2 ? m->act[l - 2] : nullptr, Cout, 0};
         if (l == 0) {
-            Conv1LoaderParams lp{x, hh[0], ww[0], cin, hh[1], ww[1]};
+            Conv1LoaderParams lp{x, (const int8_t *)m->zeros, hh[0], ww[0], cin, hh[1], ww[1]};
             TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU, 128, 64>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep)));
         } else {
-            ConvLoaderParams lp{m->act[l - 1], hh[l], ww[l], cin, hh[l + 1], ww[l + 1], kConvStride[l], cin / kBK};
+            ConvLoaderParams lp{m->act[l - 1], m->zeros, hh[l], ww[l], cin, hh[l + 1], ww[l + 1], kConvStride[l], cin / kBK};
             const int nk = 9 * cin / kBK;
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
@@ -441,8 +442,8 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
         if (nbins * 256 != m->K4) return fail("unsupported geometry: %d pyramid bins (L4 expects %d inputs)", nbins, m->K4);
         sp.nbins = nbins;
         ProfScope ps(m, s, "fa.spp", 0.0, 4.0 * n * (hh[9] * ww[9] * 256.0 + m->K4));
-        const int64_t total = n * m->K4;
-        const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+        const int64_t total = n * 256;
+        const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
         hipLaunchKernelGGL(spp_kernel, dim3(grid), dim3(256), 0, s, sp);
         HIP_TRY(hipGetLastError());
     }
@@ -462,7 +463,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 2.0 * 512.0 * 128.0, 4.0 * M * (1024.0 + 256.0));
         LstmParams lp{m->gx1, m->whh[0], m->h1, (int)n, Tn, 1024};
-        hipLaunchKernelGGL(lstm_recurrent_kernel<128>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+        hipLaunchKernelGGL((lstm_recurrent_kernel<128, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
         HIP_TRY(hipGetLastError());
     }
     {
@@ -474,7 +475,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
         LstmParams lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
-        hipLaunchKernelGGL(lstm_recurrent_kernel<160>, dim3((unsigned)((n + 15) / 16), 2), dim3(640), 0, s, lp);
+        hipLaunchKernelGGL((lstm_recurrent_kernel<160, false>), dim3((unsigned)((n + 15) / 16), 2), dim3(640), 0, s, lp);
         HIP_TRY(hipGetLastError());
     }
     return run_tail(m, s, m->h2, m->K4, n, y, "p.l4", "p.tail");
@@ -574,6 +575,11 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
         return nullptr;
     }
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
+    if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
+        fail("hipMalloc(zero page) failed");
+        c3_model_destroy(m);
+        return nullptr;
+    }
     return m;
 }
 
@@ -731,7 +737,7 @@ int c3_model_destroy(c3_model *m) {
     (void)hipDeviceSynchronize();
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
-                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh};
+                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     for (int l = 0; l < 9; ++l) {
