@@ -164,28 +164,65 @@ struct SppParams {
     // padding added by F.pad (model.py:267-268), in which case 0 takes part in the max.
     short h0[16], h1[16], w0[16], w1[16], pad[16];
 };
+// Compile-time geometry (ONT: 12 x 5 after the third stride-2 stage): the H*W loads of one (window, channel)
+// are fully unrolled -- 60 independent, channel-coalesced loads in flight per thread -- and every bin test
+// folds to a constant, leaving three v_max per value (one per pyramid level).
+template <int H, int W>
+__global__ __launch_bounds__(256) void spp_kernel_fixed(const float *__restrict__ in, float *__restrict__ out, int B, int C) {
+    constexpr int P[3] = {3, 2, 1};
+    constexpr int NB0 = ((H + (H + 2) / 3 - 1) / ((H + 2) / 3)) * ((W + (W + 2) / 3 - 1) / ((W + 2) / 3));
+    constexpr int NB1 = ((H + (H + 1) / 2 - 1) / ((H + 1) / 2)) * ((W + (W + 1) / 2 - 1) / ((W + 1) / 2));
+    constexpr int NBINS = NB0 + NB1 + 1;
+    const int64_t total = (int64_t)B * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t b = i / C;
+        const float *src = in + b * H * W * C + c;
+        float v[H * W];
+#pragma unroll
+        for (int k = 0; k < H * W; ++k) v[k] = src[(int64_t)k * C];
+        float m[NBINS];
+        int base = 0;
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) {
+            const int p = P[pi];
+            const int wh = (H + p - 1) / p, ww = (W + p - 1) / p;
+            const int ohn = (H + wh - 1) / wh, own = (W + ww - 1) / ww;
+            const int pad_h = ohn * wh - H > 0 ? ohn * wh - H : 0, pad_w = own * ww - W > 0 ? own * ww - W : 0;
+            const int pt = pad_h / 2, pl = pad_w / 2;
+#pragma unroll
+            for (int oh = 0; oh < ohn; ++oh)
+#pragma unroll
+                for (int ow = 0; ow < own; ++ow) {
+                    const int a0 = oh * wh - pt, a1 = a0 + wh, c0 = ow * ww - pl, c1 = c0 + ww;
+                    const bool padded = a0 < 0 || a1 > H || c0 < 0 || c1 > W;  // F.pad zeros take part in the max
+                    float mm = padded ? 0.f : -INFINITY;
+#pragma unroll
+                    for (int h = (a0 < 0 ? 0 : a0); h < (a1 > H ? H : a1); ++h)
+#pragma unroll
+                        for (int w = (c0 < 0 ? 0 : c0); w < (c1 > W ? W : c1); ++w) mm = fmaxf(mm, v[h * W + w]);
+                    m[base + oh * own + ow] = mm;
+                }
+            base += ohn * own;
+        }
+        float *dst = out + b * NBINS * C + c;
+#pragma unroll
+        for (int k = 0; k < NBINS; ++k) dst[(int64_t)k * C] = m[k];
+    }
+}
+
+// generic geometry fallback (bins described at run time)
 __global__ __launch_bounds__(256) void spp_kernel(SppParams p) {
-    // one thread per (window, channel): every input value is read exactly once (coalesced over channels) and
-    // folded into the running max of each bin that contains it
-    const int64_t total = (int64_t)p.B * p.C;
+    const int64_t total = (int64_t)p.B * p.nbins * p.C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % p.C);
-        const int64_t b = i / p.C;
+        const int bin = (int)((i / p.C) % p.nbins);
+        const int64_t b = i / ((int64_t)p.C * p.nbins);
         const float *src = p.in + b * p.H * p.W * p.C + c;
-        float m[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) m[k] = (k < p.nbins && p.pad[k]) ? 0.f : -INFINITY;
-        for (int h = 0; h < p.H; ++h)
-            for (int w = 0; w < p.W; ++w) {
-                const float v = src[((int64_t)h * p.W + w) * p.C];
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < p.nbins && h >= p.h0[k] && h < p.h1[k] && w >= p.w0[k] && w < p.w1[k]) m[k] = fmaxf(m[k], v);
-            }
-        float *dst = p.out + b * p.nbins * p.C + c;
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k < p.nbins) dst[(int64_t)k * p.C] = m[k];
+        float m = p.pad[bin] ? 0.f : -INFINITY;
+        for (int h = p.h0[bin]; h < p.h1[bin]; ++h)
+            for (int w = p.w0[bin]; w < p.w1[bin]; ++w) m = fmaxf(m, src[((int64_t)h * p.W + w) * p.C]);
+        p.out[i] = m;
     }
 }
 
@@ -246,12 +283,12 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
 #pragma unroll
         for (int t = 0; t < TB; ++t) acc[t] = p.b5[j];
         const float *w = p.w5t + j;
-        for (int k = 0; k < FC; k += 8) {
-            float wv[8];
+        for (int k = 0; k < FC; k += 32) {  // 32 independent coalesced weight loads in flight per thread
+            float wv[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) wv[u] = w[(int64_t)(k + u) * n5];
+            for (int u = 0; u < 32; ++u) wv[u] = w[(int64_t)(k + u) * n5];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 32; ++u)
 #pragma unroll
                 for (int t = 0; t < TB; ++t) acc[t] = fmaf(xs[t][k + u], wv[u], acc[t]);
         }
@@ -268,12 +305,12 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
         float acc = p.bh[br * 64 + idx];
         const float *w = p.wh + (int64_t)br * 128 * 64 + idx;
         const float *h = &h5[t][br * 128];
-        for (int k = 0; k < 128; k += 8) {
-            float wv[8];
+        for (int k = 0; k < 128; k += 32) {
+            float wv[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) wv[u] = w[(k + u) * 64];
+            for (int u = 0; u < 32; ++u) wv[u] = w[(k + u) * 64];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(h[k + u], wv[u], acc);
+            for (int u = 0; u < 32; ++u) acc = fmaf(h[k + u], wv[u], acc);
         }
         lg[t][o] = selu_f(acc);
     }

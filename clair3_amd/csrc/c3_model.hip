@@ -442,9 +442,14 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
         if (nbins * 256 != m->K4) return fail("unsupported geometry: %d pyramid bins (L4 expects %d inputs)", nbins, m->K4);
         sp.nbins = nbins;
         ProfScope ps(m, s, "fa.spp", 0.0, 4.0 * n * (hh[9] * ww[9] * 256.0 + m->K4));
-        const int64_t total = n * 256;
-        const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
-        hipLaunchKernelGGL(spp_kernel, dim3(grid), dim3(256), 0, s, sp);
+        if (hh[9] == 12 && ww[9] == 5) {  // ONT geometry: fully unrolled specialisation
+            const int grid = (int)std::min<int64_t>(n, 8192);  // one block = the 256 channels of one window
+            hipLaunchKernelGGL((spp_kernel_fixed<12, 5>), dim3(grid), dim3(256), 0, s, m->act[8], m->spp, (int)n, 256);
+        } else {
+            const int64_t total = n * m->K4;
+            const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+            hipLaunchKernelGGL(spp_kernel, dim3(grid), dim3(256), 0, s, sp);
+        }
         HIP_TRY(hipGetLastError());
     }
     return run_tail(m, s, m->spp, m->K4, n, y, "fa.l4", "fa.tail");
