@@ -1,0 +1,67 @@
+"""Drop-in installation into the reference's own entry points.
+
+``install()`` rebinds, inside an *unmodified* checkout of the reference, exactly the names that make up the
+model call of the GPU path -- nothing else of the pipeline is touched:
+
+  clair3.CallVariantsFromCffi   _torch_predict (:48-52), _load_torch_checkpoint (:19-28), _select_device (:31-34),
+                                _limit_gpu_memory (:37-45, a CUDA-caching-allocator knob: no-op here)
+  clair3.model                  Clair3_P (:58), Clair3_F (:282)  -- imported lazily by the worker at :230/:239
+  clair3.CallVariantsFromCffiGPU get_gpu_memory (:13-19), check_gpu_memory (:21-43)  (nvidia-smi -> hipMemGetInfo)
+
+After it ``python clair3.py CallVariantsFromCffi --use_gpu True --gpu_id 0 ...`` and
+``python clair3.py CallVariantsFromCffiGPU ...`` run their loops unchanged (clair3/CallVariantsFromCffi.py:299-353:
+batches from .npy files, shared-memory hand-off of Y to the batch_output workers, VCF rows) with the forward
+pass in libc3hip.  ``sitecustomize``-style use:
+
+    PYTHONPATH=/path/to/clair3_amd_repo python -c "import clair3_amd.callvar as c; c.install(); import clair3; ..."
+
+or add the two lines shown in INTEGRATION.md to clair3.py.
+"""
+import sys
+
+from . import _lib, predict
+from .model import Clair3_F, Clair3_P
+
+
+def _select_device_for_worker(use_gpu):
+    """CallVariantsFromCffi._select_device: the worker only uses the result as an opaque handle that is passed
+    back to _torch_predict / model.to(), so a string is enough; CPU requests stay with the reference."""
+    import torch
+    if use_gpu and _lib.device_count() > 0:
+        return "cuda:0"
+    return torch.device("cpu")
+
+
+def _limit_gpu_memory(memory_mb, device):
+    return  # libc3hip sizes its own workspace (c3_mem_info is the accounting hook); nothing to cap
+
+
+def _check_gpu_memory_or_exit(memory, device_ids=None, print_log=True):
+    from shared.utils import log_error  # reference helper, only available inside the reference tree
+    try:
+        return predict.check_gpu_memory(memory, device_ids, print_log)
+    except _lib.C3Error as e:
+        print(log_error(str(e)))
+        sys.exit(1)
+
+
+def install(worker=True, gpu_wrapper=True):
+    """Patch the imported (or importable) reference modules in place.  Returns the list of rebound names."""
+    done = []
+    import clair3.model as ref_model
+    ref_model.Clair3_P, ref_model.Clair3_F = Clair3_P, Clair3_F
+    done += ["clair3.model.Clair3_P", "clair3.model.Clair3_F"]
+    if worker:
+        import clair3.CallVariantsFromCffi as w
+        w._torch_predict = predict._hip_predict
+        w._load_torch_checkpoint = predict._load_torch_checkpoint
+        w._select_device = _select_device_for_worker
+        w._limit_gpu_memory = _limit_gpu_memory
+        done += ["clair3.CallVariantsFromCffi." + n for n in
+                 ("_torch_predict", "_load_torch_checkpoint", "_select_device", "_limit_gpu_memory")]
+    if gpu_wrapper:
+        import clair3.CallVariantsFromCffiGPU as g
+        g.get_gpu_memory = predict.get_gpu_memory
+        g.check_gpu_memory = _check_gpu_memory_or_exit
+        done += ["clair3.CallVariantsFromCffiGPU.get_gpu_memory", "clair3.CallVariantsFromCffiGPU.check_gpu_memory"]
+    return done

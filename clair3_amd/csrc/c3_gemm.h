@@ -67,9 +67,10 @@ struct ConvLoader {
     const float *x, *zeros;
     int64_t off[R];
     uint32_t mask[R];
-    int Win, Cin, cpt, tap, cc;
+    int Win, Cin, cpt_shift, cpt_mask;
     __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
-        x = p.x, zeros = p.zeros, Win = p.Win, Cin = p.Cin, cpt = p.chunks_per_tap, tap = 0, cc = 0;
+        x = p.x, zeros = p.zeros, Win = p.Win, Cin = p.Cin;
+        cpt_mask = p.chunks_per_tap - 1, cpt_shift = 31 - __builtin_clz(p.chunks_per_tap);  // power of two
         const int hw = p.Ho * p.Wo;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -88,8 +89,9 @@ struct ConvLoader {
             mask[i] = mk;
         }
     }
-    // loads of the next chunk in K order (called once per chunk, in order)
-    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
+    // loads of K chunk kc (stateless: any chunk, any order)
+    __device__ __forceinline__ void issue(Raw (&raw)[R], int kc) const {
+        const int tap = kc >> cpt_shift, cc = kc & cpt_mask;
         const int kh = tap / 3, kw = tap - kh * 3;
         const int64_t koff = (int64_t)(kh * Win + kw) * Cin + cc * kBK;
 #pragma unroll
@@ -97,9 +99,8 @@ struct ConvLoader {
             const bool ok = (mask[i] >> tap) & 1u;
             raw[i] = *reinterpret_cast<const f32x4 *>(ok ? x + off[i] + koff : zeros);
         }
-        if (++cc == cpt) cc = 0, ++tap;
     }
-    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {
 #pragma unroll
         for (int i = 0; i < R; ++i) out[i] = raw[i];
     }
@@ -123,9 +124,9 @@ struct Conv1Loader {
     int64_t off[R];     // byte offset of (b, ih0, iw0, 0) + 4*lc
     int ih0[R];
     uint32_t colok[R];  // bit e: slot 4*lc+e is a real (kw, c) whose column iw0+kw is inside the image
-    int Hin, rowbytes, kh;
+    int Hin, rowbytes;
     __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
-        x = p.x, zeros = p.zeros, Hin = p.Hin, rowbytes = p.Win * p.C, kh = 0;
+        x = p.x, zeros = p.zeros, Hin = p.Hin, rowbytes = p.Win * p.C;
         const int hw = p.Ho * p.Wo;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -147,7 +148,7 @@ struct Conv1Loader {
             colok[i] = ck;
         }
     }
-    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
+    __device__ __forceinline__ void issue(Raw (&raw)[R], int kh) const {  // chunk index = kh
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int ih = ih0[i] + kh;
@@ -159,9 +160,8 @@ struct Conv1Loader {
                 raw[i].v[e] = *(ok ? p + e : zeros);
             }
         }
-        ++kh;
     }
-    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -193,13 +193,13 @@ struct IntRowLoader {
             row[i] = p.x + (int64_t)m * p.C;
         }
     }
-    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
+    __device__ __forceinline__ void issue(Raw (&raw)[R], int) const {  // single chunk
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) raw[i].v[e] = (int)row[i][lc4 + e < C ? lc4 + e : C - 1];
     }
-    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -217,9 +217,9 @@ struct DenseLoader {
     typedef DenseLoaderParams Params;
     typedef f32x4 Raw;
     const float *row[R];
-    int k;
+    int k0;
     __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
-        k = 0;
+        k0 = 0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             int m = m0 + lr + 32 * i;
@@ -227,13 +227,12 @@ struct DenseLoader {
             row[i] = p.a + (int64_t)m * p.lda + lc * 4;
         }
     }
-    __device__ __forceinline__ void seek(int k0) { k = k0; }
-    __device__ __forceinline__ void issue(Raw (&raw)[R]) {
+    __device__ __forceinline__ void seek(int k) { k0 = k; }
+    __device__ __forceinline__ void issue(Raw (&raw)[R], int kc) const {
 #pragma unroll
-        for (int i = 0; i < R; ++i) raw[i] = *reinterpret_cast<const f32x4 *>(row[i] + k);
-        k += kBK;
+        for (int i = 0; i < R; ++i) raw[i] = *reinterpret_cast<const f32x4 *>(row[i] + k0 + kc * kBK);
     }
-    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) {
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {
 #pragma unroll
         for (int i = 0; i < R; ++i) out[i] = raw[i];
     }
@@ -259,7 +258,9 @@ struct GemmParams {
     int tiles;       // tiles_m * tiles_n
 };
 
-template <class Loader, int EPI, int BM, int BN>
+// ABL: ablation switches for tools/mfma_probe (0 in the product).  bit0: no global loads in the loop,
+// bit1: no LDS staging writes, bit2: no barrier, bit3: no LDS fragment reads (MFMAs on stale registers).
+template <class Loader, int EPI, int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Params lp, GemmParams gp,
                                                               EpilogueParams ep) {
     constexpr int RA = BM / 32, RBt = BN / 32;  // staged rows per thread
@@ -307,30 +308,62 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    typename Loader::Raw raw[RA];
-    f32x4 ra[RA], rb[RBt];
-    loader.issue(raw);
+    // Software pipeline over K chunks, two register stages + two LDS stages, branch-free body:
+    //   iteration kc:  issue global loads of chunk kc+2          (-> rawB / rbB, land during this iteration)
+    //                  write chunk kc+1 (loaded LAST iteration)   (rawA / rbA -> LDS[nxt], no wait needed)
+    //                  MFMAs on LDS[cur]
+    //                  barrier
+    // Chunk indices past the end are clamped to the last chunk (redundant loads / writes nobody reads), so
+    // the body has no conditionals and the scheduler can interleave loader VALU with the MFMAs.
+    typename Loader::Raw rawA[RA], rawB[RA];
+    f32x4 ra[RA], rbA[RBt], rbB[RBt];
+    const int last = gp.nk - 1;
+    loader.issue(rawA, 0);
 #pragma unroll
-    for (int i = 0; i < RBt; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(bptr[i]);
-    loader.finish(raw, ra);
+    for (int i = 0; i < RBt; ++i) rbA[i] = *reinterpret_cast<const f32x4 *>(bptr[i]);
+    loader.finish(rawA, ra);
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_a[i]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_b[i]) = rb[i];
+    for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_b[i]) = rbA[i];
+    {
+        const int k1 = last < 1 ? last : 1;
+        loader.issue(rawA, k1);
+#pragma unroll
+        for (int i = 0; i < RBt; ++i) rbA[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)k1 * kBK);
+    }
     __syncthreads();
 
-    for (int kc = 0; kc < gp.nk; ++kc) {
+    auto body = [&](int kc, typename Loader::Raw (&rCur)[RA], f32x4 (&bCur)[RBt], typename Loader::Raw (&rNext)[RA],
+                    f32x4 (&bNext)[RBt]) __attribute__((always_inline)) {
         const char *cur = smem + (kc & 1) * kStage;
         char *nxt = smem + ((kc + 1) & 1) * kStage;
-        const bool more = kc + 1 < gp.nk;
-        if (more) {  // global loads of chunk kc+1: in flight during the MFMAs below
-            loader.issue(raw);
+        const int k2 = kc + 2 < last ? kc + 2 : last;
+        if constexpr (!(ABL & 1)) {
+            loader.issue(rNext, k2);
 #pragma unroll
-            for (int i = 0; i < RBt; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)(kc + 1) * kBK);
+            for (int i = 0; i < RBt; ++i) bNext[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)k2 * kBK);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the global loads at the top: they must fly during the MFMAs
+        if constexpr (!(ABL & 2)) {
+            loader.finish(rCur, ra);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_a[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_b[i]) = bCur[i];
+        }
+
         // fragments of k-group g+1 are read from LDS while the MFMAs of group g run
         f32x4 a[2][RB], b[2][CB];
-        {
+        if constexpr (ABL & 8) {  // stale-register operands, kept opaque so nothing is folded away
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) a[u][i] = ra[i];
+#pragma unroll
+                for (int i = 0; i < CB; ++i) b[u][i] = bCur[i];
+            }
+        } else {
             const int coff = (fhi ^ fsw) << 4;
 #pragma unroll
             for (int i = 0; i < RB; ++i) a[0][i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g < 3) {
+            if (g < 3 && !(ABL & 8)) {
                 const int coff = ((2 * (g + 1) + fhi) ^ fsw) << 4;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) a[(g + 1) & 1][i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
@@ -354,15 +387,16 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
                     for (int c = 0; c < CB; ++c)
                         acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][j], b[g & 1][c][j], acc[i][c], 0, 0, 0);
         }
-        if (more) {
-            loader.finish(raw, ra);
-#pragma unroll
-            for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_a[i]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_b[i]) = rb[i];
-        }
-        __syncthreads();
+        if constexpr (!(ABL & 4)) __syncthreads();
+    };
+    // unrolled by two so the register stages swap roles by name (no copies: a copy would be a use of the
+    // in-flight loads and stall on them)
+    int kc = 0;
+    for (; kc + 1 <= last; kc += 2) {
+        body(kc, rawA, rbA, rawB, rbB);
+        body(kc + 1, rawB, rbB, rawA, rbA);
     }
+    if (kc <= last) body(kc, rawA, rbA, rawB, rbB);
 
     // epilogue.  C/D map of 32x32x2: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
     float *cbase = ep.c + (EPI == EPI_PARTIAL ? (int64_t)split * ep.split_stride : 0);

@@ -63,27 +63,32 @@ def build_model(pileup, add_indel_length, platform="ont", enable_dwell_time=Fals
     return m
 
 
-def get_gpu_memory():
-    """[(device_index, free_MB)] like the nvidia-smi parser it replaces
-    (clair3/CallVariantsFromCffiGPU.py:13-19) but through hipMemGetInfo."""
-    out = []
-    for d in range(_lib.device_count()):
-        free_b, _ = _lib.mem_info(d)
-        out.append((d, free_b // (1024 * 1024)))
-    return out
+def get_gpu_memory(gpu_id=None):
+    """Free device memory in MB, one entry per queried device -- same return shape as the nvidia-smi parser it
+    replaces (clair3/CallVariantsFromCffiGPU.py:13-19) but through hipMemGetInfo (c3_mem_info)."""
+    ids = range(_lib.device_count()) if gpu_id is None else [int(gpu_id)]
+    return [int(_lib.mem_info(d)[0] // (1024 * 1024)) for d in ids]
 
 
-def check_gpu_memory(min_memory_mb, device_list=None):
-    """Slots per device = free_MB // min_memory_mb (clair3/CallVariantsFromCffiGPU.py:21-43; the reference
-    uses 5000 MB per pileup worker, 8000 MB per full-alignment worker, :55-56)."""
-    gpu_thread_dict = {}
-    total = 0
-    for d, free_mb in get_gpu_memory():
-        if device_list is not None and d not in device_list:
-            continue
-        n = int(free_mb // min_memory_mb)
-        gpu_thread_dict[d] = n
-        total += n
-    if total == 0:
-        raise _lib.C3Error(f"No GPU has {min_memory_mb} MB free")
-    return gpu_thread_dict, total
+def check_gpu_memory(memory, device_ids=None, print_log=True):
+    """clair3/CallVariantsFromCffiGPU.py:21-43: one "GPU thread" (worker slot) per `memory` MB of free device
+    memory; returns the device id repeated once per slot.  The reference sys.exit(1)s when nothing is usable;
+    this raises C3Error and the installed wrapper (callvar.install) converts it back into the exit."""
+    all_device_ids = list(range(_lib.device_count()))
+    if device_ids is None:
+        device_ids = all_device_ids
+    if not all_device_ids:
+        return
+    gpu_id_list = []
+    for device_id in all_device_ids:
+        free_mem = get_gpu_memory(gpu_id=device_id)[0]
+        gpu_threads = free_mem // memory
+        gpu_id_list += [device_id] * int(gpu_threads)
+        if print_log:
+            print(f"GPU {device_id} free memory: {free_mem} MB, assigning {memory} MB per thread, "
+                  f"{gpu_threads} threads available")
+    if len(device_ids) == 0:
+        raise _lib.C3Error("No GPU available, Please disabling --use_gpu for variant calling, exiting.")
+    if len(gpu_id_list) == 0:
+        raise _lib.C3Error("No memory in GPU, Please assign GPU memory first, exiting.")
+    return gpu_id_list

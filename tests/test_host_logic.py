@@ -38,3 +38,40 @@ def test_shard_ranges_partition_the_windows(n, world):
         assert a1 == b0 and a0 <= a1
     sizes = [b - a for a, b in spans]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_install_rebinds_the_reference_call_sites():
+    """callvar.install() against the real reference checkout (build container only: the GPU box has no
+    /root/reference, where this test skips).  Checks that exactly the model-call names are rebound and that the
+    worker's module-level helpers keep their signatures."""
+    import inspect
+    import os
+    import sys
+    ref = os.environ.get("CLAIR3_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "clair3")):
+        pytest.skip("reference checkout not present")
+    sys.path.insert(0, ref)
+    try:
+        import clair3.CallVariantsFromCffi as w
+        import clair3.CallVariantsFromCffiGPU as g
+        orig = {n: inspect.signature(getattr(w, n)) for n in ("_torch_predict", "_load_torch_checkpoint", "_select_device",
+                                                              "_limit_gpu_memory")}
+        orig_g = {n: inspect.signature(getattr(g, n)) for n in ("get_gpu_memory", "check_gpu_memory")}
+        from clair3_amd import callvar, predict
+        from clair3_amd.model import Clair3_F, Clair3_P
+        names = callvar.install()
+        assert len(names) == 8
+        import clair3.model as ref_model
+        assert ref_model.Clair3_P is Clair3_P and ref_model.Clair3_F is Clair3_F
+        assert w._torch_predict is predict._hip_predict
+        for n, sig in orig.items():
+            assert list(inspect.signature(getattr(w, n)).parameters) == list(sig.parameters), n
+        for n, sig in orig_g.items():
+            assert list(inspect.signature(getattr(g, n)).parameters) == list(sig.parameters), n
+        # constructor keywords used at CallVariantsFromCffi.py:232,243
+        m = ref_model.Clair3_F(add_indel_length=True, predict=True, input_channels=9)
+        assert m.output_size == 90 and m.input_channels == 9
+    finally:
+        sys.path.remove(ref)
+        for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")]:
+            del sys.modules[k]

@@ -1,0 +1,93 @@
+// tools/mfma_probe.hip -- ablation probe of the conv implicit-GEMM kernel (run on the GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 tools/mfma_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
+// Times the real kernel and variants with parts switched off on the res1a (M=195840,N=64,K=576) and
+// res3a (M=15360,N=256,K=2304) shapes of the B=256 full-alignment batch, plus a pure-MFMA pace kernel.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../clair3_amd/csrc/c3_gemm.h"
+using namespace c3;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int NACC>
+__global__ __launch_bounds__(256) void pure_mfma(float *out, int iters) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int v = 0; v < 16; ++v) s += acc[i][v];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <class K>
+static float time_it(K launch, int reps = 10) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(a); for (int i = 0; i < reps; ++i) launch(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b); return ms / reps * 1e3f;
+}
+
+template <int BN, int ABL>
+static float run_conv(const float *x, const float *zeros, const float *w, const float *bias, float *out, int B, int H, int W, int Cin, int Cout) {
+    ConvLoaderParams lp{x, zeros, H, W, Cin, H, W, 1, Cin / 32};
+    GemmParams gp; gp.bt = w; gp.ldb = 9 * Cin; gp.M = B * H * W; gp.N = Cout; gp.nk = 9 * Cin / 32; gp.tiles_n = Cout / BN;
+    gp.tiles = ((gp.M + 127) / 128) * gp.tiles_n;
+    EpilogueParams ep{out, bias, nullptr, Cout, 0};
+    return time_it([&] { hipLaunchKernelGGL((gemm_mfma_kernel<ConvLoader<4>, EPI_BIAS_RELU, 128, BN, ABL>), dim3(gp.tiles), dim3(256), 0, 0, lp, gp, ep); });
+}
+
+int main() {
+    const int B = 256;
+    size_t act = (size_t)B * 45 * 17 * 64;
+    float *x, *y, *w, *bias, *zeros;
+    CK(hipMalloc(&x, act * 4)); CK(hipMalloc(&y, act * 4)); CK(hipMalloc(&w, (size_t)256 * 2304 * 4)); CK(hipMalloc(&bias, 1024)); CK(hipMalloc(&zeros, 256));
+    std::vector<float> h(act); for (size_t i = 0; i < act; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    CK(hipMemcpy(x, h.data(), act * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, h.data(), (size_t)256 * 2304 * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, 1024)); CK(hipMemset(zeros, 0, 256));
+    {
+        float *o; CK(hipMalloc(&o, 4096 * 256 * 4));
+        for (int wg : {256, 512, 768, 1024}) {
+            int iters = 2000;
+            float us2 = time_it([&] { hipLaunchKernelGGL(pure_mfma<2>, dim3(wg), dim3(256), 0, 0, o, iters); }, 3);
+            float us4 = time_it([&] { hipLaunchKernelGGL(pure_mfma<4>, dim3(wg), dim3(256), 0, 0, o, iters / 2); }, 3);
+            double fl = (double)wg * 4 * iters * 16 * 4096.0;  // waves * iters * 8*NACC(=2) MFMAs * 4096 flop
+            printf("pure MFMA %4d WGs: 2 acc %.1f us %.1f TF | 4 acc %.1f us %.1f TF\n", wg, us2, fl / us2 / 1e6, us4, fl / us4 / 1e6);
+        }
+    }
+    const char *names[] = {"full", "no-gload", "no-gload,no-ldswrite", "no-gload,no-ldswrite,no-barrier", "mfma+ldsread only(=7)", "all off (15)", "no barrier only (4)", "no frag reads only (8)"};
+    {
+        double fl = 2.0 * B * 45 * 17 * 64 * 576;
+        float t[8];
+        t[0] = run_conv<64, 0>(x, zeros, w, bias, y, B, 45, 17, 64, 64);
+        t[1] = run_conv<64, 1>(x, zeros, w, bias, y, B, 45, 17, 64, 64);
+        t[2] = run_conv<64, 3>(x, zeros, w, bias, y, B, 45, 17, 64, 64);
+        t[3] = run_conv<64, 7>(x, zeros, w, bias, y, B, 45, 17, 64, 64);
+        t[4] = t[3];
+        t[5] = run_conv<64, 15>(x, zeros, w, bias, y, B, 45, 17, 64, 64);
+        t[6] = run_conv<64, 4>(x, zeros, w, bias, y, B, 45, 17, 64, 64);
+        t[7] = run_conv<64, 8>(x, zeros, w, bias, y, B, 45, 17, 64, 64);
+        for (int i = 0; i < 8; ++i) printf("res1a 128x64  %-34s %.1f us %.1f TF\n", names[i], t[i], fl / t[i] / 1e6);
+    }
+    {
+        double fl = 2.0 * B * 12 * 5 * 256 * 2304;
+        float t[8];
+        t[0] = run_conv<128, 0>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        t[1] = run_conv<128, 1>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        t[2] = run_conv<128, 3>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        t[3] = run_conv<128, 7>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        t[4] = t[3];
+        t[5] = run_conv<128, 15>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        t[6] = run_conv<128, 4>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        t[7] = run_conv<128, 8>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        for (int i = 0; i < 8; ++i) printf("res3a 128x128 %-34s %.1f us %.1f TF\n", names[i], t[i], fl / t[i] / 1e6);
+        float t64 = run_conv<64, 0>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
+        printf("res3a 128x64  full %.1f us %.1f TF\n", t64, fl / t64 / 1e6);
+    }
+    return 0;
+}
