@@ -16,6 +16,7 @@
 #include "../../include/c3hip.h"
 #include "c3_gemm.h"
 #include "c3_kernels.h"
+#include "c3_wino.h"
 
 using namespace c3;
 
@@ -94,6 +95,14 @@ struct c3_model {
     // full alignment
     float *conv_w[9] = {};
     float *conv_b[9] = {};
+    float *wino_v[9] = {};   // Winograd-domain weights of the stride-1 convs (layers 1,2,4,5,7,8)
+    bool use_wino[9] = {};
+    // Measured on MI355X (B=256): Winograd v1 wins on the 64- and 128-channel blocks (res1: 123/141 vs 134/145 us,
+    // res2: 121/132 vs 164/174 us) and loses on the 256-channel block, whose 18 tiles/window quantise badly and whose
+    // input transform is recomputed for 8 N-tiles; v2 (1 workgroup/CU, transform in the MFMA shadows) is bound by the
+    // ~10 B/clk/CU L2->CU path (96 KB of patch + V traffic per 4096 MFMA cycles) and is kept for experiments only.
+    int wino_version = 1;        // env C3HIP_WINOGRAD_VERSION (1 | 2)
+    unsigned wino_mask = 0x36;   // layers run as Winograd (bit l); env C3HIP_WINOGRAD overrides (0x1b6 = all stride-1)
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
@@ -353,6 +362,32 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     }
     TRY(upload(m, &m->conv_w[l], pw));
     TRY(upload(m, &m->conv_b[l], pb));
+    if (kConvStride[l] == 1 && Cin % kWinoBK == 0 && Cout % kWinoNT == 0) {
+        // Winograd F(2x2,3x3) weights V = G g' G^T (g' = BN-folded), in MFMA B-fragment order
+        //   [Cout/32][xi = 4i+j][Cin/16][g][lane][e] = V_xi[n = nt*32 + (lane&31)][k = 16c + 8g + 4(lane>>5) + e]
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        const int nch = Cin / kWinoBK;
+        std::vector<float> pv((size_t)Cout * 16 * Cin);
+        for (int n = 0; n < Cout; ++n) {
+            const double scale = (double)g[n] / std::sqrt((double)var[n] + 1e-3);
+            for (int k = 0; k < Cin; ++k) {
+                double gg[3][3];
+                for (int a = 0; a < 3; ++a)
+                    for (int b2 = 0; b2 < 3; ++b2) gg[a][b2] = (double)w[(((size_t)n * Cin + k) * 3 + a) * 3 + b2] * scale;
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        double v = 0.0;
+                        for (int a = 0; a < 3; ++a)
+                            for (int b2 = 0; b2 < 3; ++b2) v += G[i][a] * gg[a][b2] * G[j][b2];
+                        const int nt = n / 32, ln = n % 32, c = k / 16, kk = k % 16, gq = kk / 8, hi = (kk % 8) / 4, e = kk % 4;
+                        const int lane = hi * 32 + ln;
+                        pv[((((size_t)(nt * 16 + i * 4 + j) * nch + c) * 2 + gq) * 64 + lane) * 4 + e] = (float)v;
+                    }
+            }
+        }
+        TRY(upload(m, &m->wino_v[l], pv));
+        m->use_wino[l] = true;
+    }
     return 0;
 }
 
@@ -395,7 +430,26 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
                              4.0 * Cout * 9.0 * cin;
         ProfScope ps(m, s, kFaLayerTag[l], flops, bytes);
         EpilogueParams ep{m->act[l], m->conv_b[l], l % 3 == 2 ? m->act[l - 2] : nullptr, Cout, 0};
-        if (l == 0) {
+        if (m->use_wino[l] && m->wino_mask & (1u << l)) {
+            WinoParams wp;
+            wp.x = m->act[l - 1], wp.zeros = m->zeros, wp.v = m->wino_v[l], wp.bias = m->conv_b[l];
+            wp.res = l % 3 == 2 ? m->act[l - 2] : nullptr, wp.out = m->act[l];
+            wp.B = (int)n, wp.H = hh[l], wp.W = ww[l], wp.Cin = cin, wp.Cout = Cout;
+            wp.th = (hh[l] + 1) / 2, wp.tw = (ww[l] + 1) / 2, wp.P = (int)n * wp.th * wp.tw;
+            wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
+            if (m->wino_version == 1) {
+                if (wp.res)
+                    hipLaunchKernelGGL(wino_conv_kernel<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
+                else
+                    hipLaunchKernelGGL(wino_conv_kernel<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
+            } else {
+                if (wp.res)
+                    hipLaunchKernelGGL(wino_conv_kernel2<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
+                else
+                    hipLaunchKernelGGL(wino_conv_kernel2<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
+            }
+            HIP_TRY(hipGetLastError());
+        } else if (l == 0) {
             Conv1LoaderParams lp{x, (const int8_t *)m->zeros, hh[0], ww[0], cin, hh[1], ww[1]};
             TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU, 128, 64>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep)));
         } else {
@@ -580,6 +634,8 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
         return nullptr;
     }
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
+    if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_WINOGRAD_VERSION")) m->wino_version = atoi(e);
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
         c3_model_destroy(m);
@@ -748,6 +804,7 @@ int c3_model_destroy(c3_model *m) {
     for (int l = 0; l < 9; ++l) {
         if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);
+        if (m->wino_v[l]) (void)hipFree(m->wino_v[l]);
     }
     for (auto &sl : m->slot) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);

@@ -1,0 +1,463 @@
+// c3_wino.h -- 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3), fully fused, fp32 MFMA.
+//
+// The six stride-1 convolutions of Clair3_F (the two convs of each BasicBlock, clair3/model.py:207-208,228-232)
+// carry 83 % of the network's FLOPs.  F(2x2,3x3) computes every 2x2 output tile from a 4x4 input tile with 16
+// multiplies per (cin, cout) instead of 36:   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A.
+// As GEMMs: for each of the 16 transform components xi:  M_xi[P x Cout] = U_xi[P x Cin] . V_xi[Cin x Cout],
+// P = B * ceil(H/2) * ceil(W/2) tiles (flattened over the batch like the direct kernel's M).
+//
+// One workgroup (4 waves) owns 64 tiles x 32 couts x ALL 16 xi, so both transforms fuse into the GEMM:
+//   * input transform in the A-loader: thread (tile, cin-quad) loads its 4x4 patch as 16 x 16-byte loads
+//     (padding taps read a zero page), applies B^T d B in registers (adds only) and writes the 16 U_xi rows
+//     to LDS ([xi][64 tiles][16 cin], 64-byte rows, chunk c of row r at c ^ ((r>>2)&3): conflict-free);
+//   * wave w contracts xi = 4w..4w+3 with v_mfma_f32_32x32x2_f32: 2 row blocks (64 tiles) x 1 column block
+//     (32 couts) per xi = 8 accumulators; V_xi = G g' G^T (g' = BatchNorm-folded weights, computed in double
+//     on the host) is read straight from L2 in MFMA-fragment order (1 KiB per wave-instruction) and each
+//     fragment feeds both row blocks;
+//   * output transform in the epilogue: the 16 M_xi of a (tile, cout) live in four different waves, so they
+//     are exchanged once through the same LDS buffer (two passes of 16 couts), then each thread applies
+//     A^T M A, bias, optional residual and ReLU and stores the 2x2 pixels (edge tiles are clipped).
+// K chunk = 16 cin; the single 64 KiB U buffer means two workgroups per CU, which run out of phase: one
+// transforms (VALU + memory) while the other issues MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "c3_gemm.h"
+
+namespace c3 {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WinoParams {
+    const float *x;      // [B][H][W][Cin]
+    const float *zeros;  // >= 16 readable zero bytes
+    const float *v;      // packed [Cout/32][16 xi][Cin/16][2][64 lanes][4]
+    const float *bias;   // [Cout] (BatchNorm folded)
+    const float *res;    // residual [B][H][W][Cout] or nullptr
+    float *out;          // [B][H][W][Cout]
+    int B, H, W, Cin, Cout;
+    int th, tw, P;       // tiles per column / row, total tiles
+    int tiles_n, tiles;  // Cout/32, ceil(P/64)*tiles_n
+};
+
+constexpr int kWinoPT = 64;  // tiles per workgroup
+constexpr int kWinoNT = 32;  // couts per workgroup
+constexpr int kWinoBK = 16;  // cin per chunk
+
+// ABL (tools/mfma_probe only; 0 in the product): bit0 no patch loads, bit1 no transform+LDS writes, bit2 no V loads,
+// bit3 no epilogue exchange/stores, bit4 no MFMAs.
+template <bool RES, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
+    __shared__ __attribute__((aligned(16))) char ubuf[16 * kWinoPT * kWinoBK * 4];  // 64 KiB: U_xi / M_xi exchange
+    __shared__ int4 tcoord[kWinoPT];                                                 // (b, 2ty, 2tx, valid)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_tile_index(blockIdx.x, p.tiles);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int p0 = tm * kWinoPT, n0 = tn * kWinoNT;
+
+    // ---- transform role: thread (tl, q) = (tile within block, cin quad within the chunk)
+    const int tl = tid >> 2, q = tid & 3;
+    // The patch is fetched with buffer loads: one 32-bit byte offset per thread + wave-uniform tap offsets, and
+    // the hardware bounds check returns 0 for the padding taps (their offset is forced out of range).
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x), 0, p.B * p.H * p.W * p.Cin * 4, 0x00020000);
+    uint32_t base;        // byte offset of pixel (b, 2ty-1, 2tx-1), channel 4q (wraps for the top/left halo: masked)
+    uint32_t okmask = 0;  // bit dy*4+dx: that pixel of the 4x4 patch is inside the image
+    {
+        int pp = p0 + tl;
+        const bool valid = pp < p.P;
+        if (!valid) pp = p.P - 1;
+        const int tpw = p.th * p.tw;
+        const int b = pp / tpw, r = pp - b * tpw;
+        const int ty = r / p.tw, tx = r - ty * p.tw;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        base = (uint32_t)(((((int64_t)b * p.H + iy0) * p.W + ix0) * p.Cin + q * 4) * 4);
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx)
+                if (iy0 + dy >= 0 && iy0 + dy < p.H && ix0 + dx >= 0 && ix0 + dx < p.W) okmask |= 1u << (dy * 4 + dx);
+        if (q == 0) tcoord[tl] = make_int4(b, 2 * ty, 2 * tx, valid ? 1 : 0);
+    }
+    const int u_wr = tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4);  // byte offset inside one xi plane (4096 B)
+
+    // ---- MFMA role: wave owns xi = 4*wave .. 4*wave+3
+    const int frow = lane & 31, fhi = lane >> 5;
+    int a_rd[2];  // byte offset of this lane's row in row block rb (inside an xi plane), swizzle applied per group
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) a_rd[rb] = (rb * 32 + frow) * 64;
+    const int a_sw = (frow >> 2) & 3;  // (row>>2)&3 is the same for row and row+32
+    const int nchunks = p.Cin / kWinoBK;
+    const float *vbase = p.v + ((int64_t)(tn * 16 + wave * 4) * nchunks * 2 * 64 + lane) * 4;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][rb][v] = 0.f;
+
+    for (int c = 0; c < nchunks; ++c) {
+        // V fragments of this chunk, [xi][g]: the first two xi are fetched now (in flight during the transform),
+        // the other two after the barrier (in flight during the first 32 MFMAs) -- keeps 16 registers free
+        // while the patch is live
+        f32x4 bf[4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if constexpr (ABL & 4) bf[i][g] = f32x4{1.f, 2.f, 3.f, (float)c};
+                else bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
+            }
+
+        // input transform of this thread's (tile, 4 channels): d -> B^T d B, two channels at a time (16 x 8-byte
+        // loads per half keep the live patch at 32 registers next to the 128 accumulators)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x2 d[4][4];
+            const uint32_t choff = base + (uint32_t)(c * kWinoBK + 2 * half) * 4u;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
+                    const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
+                    if constexpr (ABL & 1) d[dy][dx] = f32x2{(float)off, 1.f};
+                    else d[dy][dx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0));
+                }
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {  // t = B^T d (over rows)
+                const f32x2 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
+                d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
+            }
+            if (half == 0 && c > 0) __syncthreads();  // every wave finished reading the previous chunk's U
+            if constexpr (ABL & 2) {
+                asm volatile("" ::"v"(d[0][0]), "v"(d[1][1]), "v"(d[2][2]), "v"(d[3][3]));
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // U = t B (over columns), xi = 4i + j
+                const f32x2 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
+                char *dst = ubuf + u_wr + 8 * half;
+                *reinterpret_cast<f32x2 *>(dst + (4 * i + 0) * 4096) = t0 - t2;
+                *reinterpret_cast<f32x2 *>(dst + (4 * i + 1) * 4096) = t1 + t2;
+                *reinterpret_cast<f32x2 *>(dst + (4 * i + 2) * 4096) = t2 - t1;
+                *reinterpret_cast<f32x2 *>(dst + (4 * i + 3) * 4096) = t1 - t3;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if constexpr (ABL & 4) bf[i][g] = f32x4{1.f, 2.f, 3.f, (float)c};
+                else bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
+            }
+        if constexpr (ABL & 16) {
+            asm volatile("" ::"v"(bf[0][0]), "v"(bf[1][1]), "v"(bf[2][0]), "v"(bf[3][1]));
+            continue;
+        }
+
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char *plane = ubuf + (wave * 4 + i) * 4096;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int coff = ((2 * g + fhi) ^ a_sw) << 4;
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(plane + a_rd[0] + coff);
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(plane + a_rd[1] + coff);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bf[i][g][j], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bf[i][g][j], acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: exchange M_xi through LDS (two passes of 16 couts), A^T M A, bias (+res), ReLU, store
+    float *mbuf = reinterpret_cast<float *>(ubuf);  // [16 xi][64 tiles][16 couts]
+    if constexpr (ABL & 8) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sacc += acc[i][rb][v];
+        if (sacc == 123.456f) p.out[tid] = sacc;
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();  // U (or the previous pass) no longer needed
+        if (((lane & 31) >> 4) == h) {
+            const int c16 = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int t = rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * fhi;
+                        mbuf[((wave * 4 + i) * kWinoPT + t) * 16 + c16] = acc[i][rb][v];
+                    }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {  // not unrolled: the accumulators of pass 1 are still live
+            const int idx = tid + 256 * r;
+            const int c16 = idx & 15, t = idx >> 4;
+            const int4 tc = tcoord[t];
+            float m[4][4];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = mbuf[(xi * kWinoPT + t) * 16 + c16];
+            // Y = A^T M A,  A^T = [[1,1,1,0],[0,1,-1,-1]]
+            float s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[0][j] = m[0][j] + m[1][j] + m[2][j];
+                s[1][j] = m[1][j] - m[2][j] - m[3][j];
+            }
+            const int n = n0 + 16 * h + c16;
+            const float bias = p.bias[n];
+            if (tc.w) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float y0 = s[i][0] + s[i][1] + s[i][2];
+                    const float y1 = s[i][1] - s[i][2] - s[i][3];
+                    const int oy = tc.y + i;
+                    if (oy < p.H) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int ox = tc.z + j;
+                            if (ox < p.W) {
+                                const int64_t o = (((int64_t)tc.x * p.H + oy) * p.W + ox) * p.Cout + n;
+                                float val = (j == 0 ? y0 : y1) + bias;
+                                if (RES) val += p.res[o];
+                                p.out[o] = fmaxf(val, 0.f);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Version 2: one workgroup per CU (4 waves, one per SIMD, the whole 512-entry register file each), the
+// input transform software-pipelined INTO the MFMA stream instead of relying on a second workgroup:
+//   body(c):  issue the 16 patch loads of chunk c+2 and the V fragments of chunk c+1      (2 register stages)
+//             transform the patch of chunk c+1 (loaded one iteration ago) -> U[(c+1)&1]      (2 LDS stages)
+//             64 MFMAs on U[c&1]                                                            (VALU/LDS/VMEM of the
+//             barrier                                                                        lines above fill the gaps)
+// The epilogue exchanges all 32 couts in one pass through the 128 KiB the two U stages occupy.
+template <bool RES>
+__global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
+    // two distinct LDS objects (not one array split in halves) so that alias analysis knows the U stores of
+    // the next chunk cannot touch the fragments being read, and may schedule them among the MFMAs
+    __shared__ __attribute__((aligned(16))) char ubuf0[65536];
+    __shared__ __attribute__((aligned(16))) char ubuf1[65536];
+    __shared__ int4 tcoord[kWinoPT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_tile_index(blockIdx.x, p.tiles);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int p0 = tm * kWinoPT, n0 = tn * kWinoNT;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x), 0, p.B * p.H * p.W * p.Cin * 4, 0x00020000);
+    const int tl = tid >> 2, q = tid & 3;
+    uint32_t base, okmask = 0;
+    {
+        int pp = p0 + tl;
+        const bool valid = pp < p.P;
+        if (!valid) pp = p.P - 1;
+        const int tpw = p.th * p.tw;
+        const int b = pp / tpw, r = pp - b * tpw;
+        const int ty = r / p.tw, tx = r - ty * p.tw;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        base = (uint32_t)(((((int64_t)b * p.H + iy0) * p.W + ix0) * p.Cin + q * 4) * 4);
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx)
+                if (iy0 + dy >= 0 && iy0 + dy < p.H && ix0 + dx >= 0 && ix0 + dx < p.W) okmask |= 1u << (dy * 4 + dx);
+        if (q == 0) tcoord[tl] = make_int4(b, 2 * ty, 2 * tx, valid ? 1 : 0);
+    }
+    const int u_wr = tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4);
+
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int a_rd0 = frow * 64, a_rd1 = (32 + frow) * 64;
+    const int a_sw = (frow >> 2) & 3;
+    const int nchunks = p.Cin / kWinoBK, last = nchunks - 1;
+    const float *vbase = p.v + ((int64_t)(tn * 16 + wave * 4) * nchunks * 2 * 64 + lane) * 4;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][rb][v] = 0.f;
+
+    auto load_patch = [&](f32x4 (&d)[4][4], int c) __attribute__((always_inline)) {
+        const uint32_t choff = base + (uint32_t)(c * kWinoBK) * 4u;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
+                const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
+                d[dy][dx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
+            }
+    };
+    auto load_v = [&](f32x4 (&bf)[4][2], int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
+    };
+    auto transform_store = [&](f32x4 (&d)[4][4], char *__restrict__ u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {  // t = B^T d
+            const f32x4 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
+            d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // U = t B, xi = 4i + j
+            const f32x4 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
+            *reinterpret_cast<f32x4 *>(u + (4 * i + 0) * 4096 + u_wr) = t0 - t2;
+            *reinterpret_cast<f32x4 *>(u + (4 * i + 1) * 4096 + u_wr) = t1 + t2;
+            *reinterpret_cast<f32x4 *>(u + (4 * i + 2) * 4096 + u_wr) = t2 - t1;
+            *reinterpret_cast<f32x4 *>(u + (4 * i + 3) * 4096 + u_wr) = t1 - t3;
+        }
+    };
+
+    f32x4 dA[4][4], dB[4][4], bfA[4][2], bfB[4][2];
+    load_patch(dA, 0);
+    load_v(bfA, 0);
+    load_patch(dB, last < 1 ? last : 1);
+    transform_store(dA, ubuf0);
+    __syncthreads();
+
+    // dCur holds the patch of chunk c+1, bCur the V fragments of chunk c
+    // cur / nxt are the two halves of ubuf; __restrict__ tells the scheduler that the U stores of the next chunk
+    // never alias the fragment reads of the current one, so they may interleave with the MFMAs
+    auto body = [&](int c, const char *__restrict__ cur, char *__restrict__ nxt, f32x4 (&dCur)[4][4], f32x4 (&dNext)[4][4],
+                    f32x4 (&bCur)[4][2], f32x4 (&bNext)[4][2]) __attribute__((always_inline)) {
+        load_patch(dNext, c + 2 < last ? c + 2 : last);
+        load_v(bNext, c + 1 < last ? c + 1 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        // 8 steps (xi i = st>>1, k-group g = st&1) of 8 MFMAs.  Pinned per step (sched_barrier): the A fragments of
+        // step st+1 are read first, then the 8 MFMAs are issued, then one eighth of the NEXT chunk's input
+        // transform (steps 0-3: B^T d for patch column st; steps 4-7: row st-4 of (.)B and its four U stores) --
+        // ~16 VALU ops that execute in the shadow of the step's last MFMAs.
+        f32x4 a[2][2];
+        {
+            const char *plane = cur + (wave * 4) * 4096;
+            const int coff = (fhi ^ a_sw) << 4;
+            a[0][0] = *reinterpret_cast<const f32x4 *>(plane + a_rd0 + coff);
+            a[0][1] = *reinterpret_cast<const f32x4 *>(plane + a_rd1 + coff);
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int i = st >> 1, g = st & 1;
+            if (st < 7) {
+                const int i2 = (st + 1) >> 1, g2 = (st + 1) & 1;
+                const char *plane = cur + (wave * 4 + i2) * 4096;
+                const int coff = ((2 * g2 + fhi) ^ a_sw) << 4;
+                a[(st + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(plane + a_rd0 + coff);
+                a[(st + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(plane + a_rd1 + coff);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][0][j], bCur[i][g][j], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][1][j], bCur[i][g][j], acc[i][1], 0, 0, 0);
+            }
+            if (st < 4) {
+                const int dx = st;  // t = B^T d, column dx
+                const f32x4 d0 = dCur[0][dx], d1 = dCur[1][dx], d2 = dCur[2][dx], d3 = dCur[3][dx];
+                dCur[0][dx] = d0 - d2, dCur[1][dx] = d1 + d2, dCur[2][dx] = d2 - d1, dCur[3][dx] = d1 - d3;
+            } else {
+                const int r = st - 4;  // U = t B, row r: xi = 4r + j
+                const f32x4 t0 = dCur[r][0], t1 = dCur[r][1], t2 = dCur[r][2], t3 = dCur[r][3];
+                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 0) * 4096 + u_wr) = t0 - t2;
+                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 1) * 4096 + u_wr) = t1 + t2;
+                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 2) * 4096 + u_wr) = t2 - t1;
+                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 3) * 4096 + u_wr) = t1 - t3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    int c = 0;
+    for (; c + 1 <= last; c += 2) {
+        body(c, ubuf0, ubuf1, dB, dA, bfA, bfB);
+        body(c + 1, ubuf1, ubuf0, dA, dB, bfB, bfA);
+    }
+    if (c <= last) body(c, ubuf0, ubuf1, dB, dA, bfA, bfB);
+
+    // ---- epilogue: one exchange pass, [16 xi][64 tiles][32 couts] floats = the 128 KiB of both U stages
+    // xi planes 0..7 live in ubuf0, 8..15 in ubuf1 (8 KiB per plane)
+    float *mbuf0 = reinterpret_cast<float *>(ubuf0), *mbuf1 = reinterpret_cast<float *>(ubuf1);
+    {
+        const int c32 = lane & 31;
+        float *mw = wave < 2 ? mbuf0 : mbuf1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int t = rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * fhi;
+                    mw[(((wave & 1) * 4 + i) * kWinoPT + t) * 32 + c32] = acc[i][rb][v];
+                }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int r = 0; r < 8; ++r) {
+        const int idx = tid + 256 * r;
+        const int c32 = idx & 31, t = idx >> 5;
+        const int4 tc = tcoord[t];
+        float m[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+            m[xi >> 2][xi & 3] = (xi < 8 ? mbuf0 : mbuf1)[((xi & 7) * kWinoPT + t) * 32 + c32];
+        float s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = m[0][j] + m[1][j] + m[2][j];
+            s[1][j] = m[1][j] - m[2][j] - m[3][j];
+        }
+        const int n = n0 + c32;
+        const float bias = p.bias[n];
+        if (tc.w) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float y0 = s[i][0] + s[i][1] + s[i][2];
+                const float y1 = s[i][1] - s[i][2] - s[i][3];
+                const int oy = tc.y + i;
+                if (oy < p.H) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ox = tc.z + j;
+                        if (ox < p.W) {
+                            const int64_t o = (((int64_t)tc.x * p.H + oy) * p.W + ox) * p.Cout + n;
+                            float val = (j == 0 ? y0 : y1) + bias;
+                            if (RES) val += p.res[o];
+                            p.out[o] = fmaxf(val, 0.f);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace c3

@@ -15,6 +15,13 @@ for s in $STAGES; do
     prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err"); echo "prof rc=$?"; find gpurun_out/prof -name '*stats*' | head ;;
     pmc)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_fetch.err"); echo "pmc fetch rc=$?"
            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OLDPWD/gpurun_out/pmc_write" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_write.err"); echo "pmc write rc=$?" ;;
+    benchfa) for cfg in "0 1" "0x36 1" "0x36 2" "0x1b6 2"; do set -- $cfg; mask=$1; export C3HIP_WINOGRAD_VERSION=$2; echo "== C3HIP_WINOGRAD=$mask version=$2"; C3HIP_WINOGRAD=$mask timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline 2> gpurun_out/benchfa.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']))
+for k,v in d['kernels'].items(): print('   %-9s %7.1f us %6.1f TF' % (k, v['avg_us'], v['tflops'] or 0))
+"; done; unset C3HIP_WINOGRAD_VERSION ;;
+    diagfa) timeout 600 python tools/gpu_diag.py fa fa9 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
     counters) rocprofv3 -L > gpurun_out/counters.txt 2>&1; echo "counters rc=$?"; wc -l gpurun_out/counters.txt ;;
     pmcsq) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_sq" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq.err"); echo "pmc sq rc=$?" ;;
     info)  (rocminfo | grep -E "Name|Compute Unit|Max Clock|Wavefront" | head -40; lscpu | head -20; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null) > gpurun_out/info.txt 2>&1 ;;

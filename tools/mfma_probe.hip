@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <vector>
 #include "../clair3_amd/csrc/c3_gemm.h"
+#include "../clair3_amd/csrc/c3_wino.h"
 using namespace c3;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -40,6 +41,16 @@ static float run_conv(const float *x, const float *zeros, const float *w, const 
     gp.tiles = ((gp.M + 127) / 128) * gp.tiles_n;
     EpilogueParams ep{out, bias, nullptr, Cout, 0};
     return time_it([&] { hipLaunchKernelGGL((gemm_mfma_kernel<ConvLoader<4>, EPI_BIAS_RELU, 128, BN, ABL>), dim3(gp.tiles), dim3(256), 0, 0, lp, gp, ep); });
+}
+
+template <int ABL>
+static float run_wino(const float *x, const float *zeros, const float *v, const float *bias, float *out, int B, int H, int W, int Cin, int Cout) {
+    WinoParams wp;
+    wp.x = x, wp.zeros = zeros, wp.v = v, wp.bias = bias, wp.res = nullptr, wp.out = out;
+    wp.B = B, wp.H = H, wp.W = W, wp.Cin = Cin, wp.Cout = Cout;
+    wp.th = (H + 1) / 2, wp.tw = (W + 1) / 2, wp.P = B * wp.th * wp.tw;
+    wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
+    return time_it([&] { hipLaunchKernelGGL((wino_conv_kernel<false, ABL>), dim3(wp.tiles), dim3(256), 0, 0, wp); });
 }
 
 int main() {
@@ -88,6 +99,25 @@ int main() {
         for (int i = 0; i < 8; ++i) printf("res3a 128x128 %-34s %.1f us %.1f TF\n", names[i], t[i], fl / t[i] / 1e6);
         float t64 = run_conv<64, 0>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
         printf("res3a 128x64  full %.1f us %.1f TF\n", t64, fl / t64 / 1e6);
+    }
+    {
+        const char *wn[] = {"full", "no patch loads(1)", "no patch loads,no xform/LDS wr(3)", "no V loads(4)", "no epilogue(8)", "no MFMA(16)",
+                            "no loads,xform,V (7)", "only MFMA+frag reads(15)", "only loads+xform (4|8|16)"};
+        struct { int H, W, C; const char *name; } shp[] = {{45, 17, 64, "res1"}, {23, 9, 128, "res2"}, {12, 5, 256, "res3"}};
+        for (auto &sh : shp) {
+            double fl = 2.0 * B * sh.H * sh.W * sh.C * 9.0 * sh.C;
+            float t[9];
+            t[0] = run_wino<0>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[1] = run_wino<1>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[2] = run_wino<3>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[3] = run_wino<4>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[4] = run_wino<8>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[5] = run_wino<16>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[6] = run_wino<7>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[7] = run_wino<15>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            t[8] = run_wino<28>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
+            for (int i = 0; i < 9; ++i) printf("wino %s %-36s %.1f us  (direct-equivalent %.1f TF)\n", sh.name, wn[i], t[i], fl / t[i] / 1e6);
+        }
     }
     return 0;
 }
