@@ -116,7 +116,8 @@ def run_workload(name, args, rank, world, local):
                       for r in stats}
     if kind == syn.FULL_ALIGNMENT:
         dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res"))]
-        dom_name = "gemm_mfma_kernel<ConvLoader/Conv1Loader> (9 implicit-GEMM 3x3 conv launches per step)"
+        dom_name = ("3x3 convolution family: gemm_mfma_kernel<Conv1Loader|ConvLoader> (implicit GEMM) + wino_conv_kernel "
+                    "(Winograd F(2x2,3x3) on the 64/128-channel blocks), 9 launches per step, fp32 MFMA")
     else:
         dom = [r for r in stats if r["name"].startswith("p.lstm")]
         dom_name = "lstm_recurrent_kernel<128|160> (2 launches per step)"
@@ -124,9 +125,19 @@ def run_workload(name, args, rank, world, local):
     fl = sum(r["flops"] for r in dom)
     launches = sum(r["launches"] for r in dom)
     achieved = fl / ms / 1e9 if ms > 0 else 0.0
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if kind == syn.FULL_ALIGNMENT and os.path.exists(tpath):
+        # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2
+        # + WRITE_SIZE, collected in their own runs by tools/gpu_round.sh `pmc`; bench.py cannot run rocprof on itself)
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        traffic = tj["hbm_bytes_per_launch"]
+        traffic_note = {"source": "profiles/pmc_traffic.json (%s)" % tj.get("tag", ""), "unit": "bytes per launch (PMC)",
+                        "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"]}
     res["roofline"] = {
         "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom_name,
+        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note, "kernel": dom_name,
         "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
         "share_of_step_time": ms / max(sum(r["total_ms"] for r in stats), 1e-9),
         "whole_forward_frac": res["value"] / world * flop_w / (FP32_MFMA_PEAK_TFLOPS * 1e12),

@@ -38,6 +38,16 @@ struct LstmParams {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global
+// store (vmcnt(0)); in the recurrence the h_t stores to HBM are consumed by a later kernel, so waiting for
+// their ~1-2 us write latency at every step is pure serialisation.  LDS writes are complete at lgkmcnt(0).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+
 // Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Absolute error
 // of a gate value <= ~2e-7, two orders of magnitude inside the 1e-4 parity budget even after 66 steps; the
 // libm forms (expf / tanhf) cost ~10x the instructions and sit on the per-step critical path.
@@ -149,7 +159,151 @@ __global__ __launch_bounds__(H * 4) void lstm_recurrent_kernel(LstmParams p) {
             hbuf[cur ^ 1][4 * s + v][wave * 16 + col] = h;
             if (rowok[v]) p.hout[(rowbase[v] + t) * (2 * H) + h_col] = h;
         }
+        lds_barrier();
+    }
+}
+
+// Variant for hidden sizes whose 16-unit blocks do not divide evenly over the SIMDs (H = 160: 10 blocks).
+// The 4H/16 gate-column blocks (natural PyTorch order n = gate*H + unit) are dealt evenly to 8 waves
+// (H/32 blocks each), which balances the matrix pipes exactly and lets EVERY wave keep its W_hh fragments
+// resident (H/32 * H/16 * 4 = 200 VGPRs at H = 160: the whole 400 KiB matrix lives in the CU's register file
+// instead of being re-streamed from L2 every step, which was bandwidth-bound at ~15 B/clk/CU).
+// The price is that i/f/g/o of one unit now sit in different waves: the gate pre-activations go through LDS
+// once per step (16 x 4H floats), then thread (window, unit) applies the cell.  The x-projection of step t+1
+// is loaded straight into the accumulators right after they were stored, so it flies during the cell phase.
+struct Lstm2Params {
+    const float *gx;   // [B*T][ld_gx]; column = dir*4H + gate*H + unit  (PyTorch gate-row order)
+    const float *whh;  // [dir][gate block 4H/16][q = H/16][lane][4]
+    float *hout;       // [B][T][2H]; column = dir*H + unit
+    int B, T;
+    int64_t ld_gx;
+};
+
+template <int H>
+__global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p) {
+    constexpr int NB = H / 32;        // gate-column blocks per wave (8 waves)
+    constexpr int NQ = H / 16;        // k groups of 16
+    constexpr int NQL = 2;            // k groups of W_hh kept in LDS; the other NQ-2 (160 VGPRs at H=160) in registers
+    constexpr int NQR = NQ - NQL;
+    constexpr int LDH = H + 4;        // h tile row stride (floats)
+    constexpr int LDG = 4 * H + 4;    // gate tile row stride (floats, 16-byte multiple)
+    constexpr int NP = 16 * H / 512;  // (window, unit) pairs per thread in the cell phase
+    constexpr int WCOLS = NB * 16;    // gate columns owned by one wave
+    static_assert((WCOLS * 4) % 16 == 0 && WCOLS * 4 <= 1024, "one DMA piece per row");
+    // ONE LDS object (a second one makes the compiler drain the DMA before every ds_read): manual carve-up
+    constexpr int OFF_H = 0;                                 // float hbuf[2][16][LDH]
+    constexpr int OFF_G = OFF_H + 2 * 16 * LDH * 4;          // float gbuf[16][LDG]: x-projection, then gate pre-activations
+    constexpr int OFF_W = OFF_G + 16 * LDG * 4;              // float wlds[NQL][8][NB][64][4]
+    constexpr int LDS_BYTES = OFF_W + NQL * 8 * NB * 64 * 16;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    auto hb = [&](int buf, int row, int k) -> float * { return reinterpret_cast<float *>(smem + OFF_H) + (buf * 16 + row) * LDH + k; };
+    auto gb = [&](int row, int n) -> float * { return reinterpret_cast<float *>(smem + OFF_G) + row * LDG + n; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane >> 4, col = lane & 15;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * 16;
+
+    for (int i = tid; i < 16 * LDH; i += 512) reinterpret_cast<float *>(smem + OFF_H)[i] = 0.f;
+
+    // W_hh fragments of this wave's NB blocks: k-groups 0..NQR-1 resident in VGPRs, the last NQL in LDS
+    f32x4v wres[NB][NQR];
+    float *wl = reinterpret_cast<float *>(smem + OFF_W) + ((wave * NB) * 64 + lane) * 4;  // + (ql*8*NB + b)*256
+    {
+        const float *wb = p.whh + ((int64_t)(dir * (4 * H / 16) + wave * NB) * NQ * 64 + lane) * 4;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int q = 0; q < NQR; ++q) wres[b][q] = *reinterpret_cast<const f32x4v *>(wb + (int64_t)(b * NQ + q) * 256);
+#pragma unroll
+            for (int ql = 0; ql < NQL; ++ql)
+                *reinterpret_cast<f32x4v *>(wl + (ql * 8 * NB + b) * 256) =
+                    *reinterpret_cast<const f32x4v *>(wb + (int64_t)(b * NQ + NQR + ql) * 256);
+        }
+    }
+
+    // x-projection of a step: every wave DMAs exactly the 16 rows x WCOLS columns it will itself add to its
+    // accumulators (global_load_lds_dwordx4, WCOLS/4 active lanes per row): no registers, lands during the MFMAs,
+    // and only the issuing wave's own vmcnt orders it.
+    const int xlane = lane < WCOLS / 4 ? lane : WCOLS / 4 - 1;
+    const float *xsrc = p.gx + dir * 4 * H + wave * WCOLS + xlane * 4;
+    auto copy_x = [&](int t) __attribute__((always_inline)) {
+        if (lane < WCOLS / 4) {
+#pragma unroll
+            for (int row = 0; row < 16; ++row) {
+                int b = b0 + row;
+                if (b >= p.B) b = p.B - 1;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(xsrc + ((int64_t)b * p.T + t) * p.ld_gx),
+                    (__attribute__((address_space(3))) void *)gb(row, wave * WCOLS), 16, 0, 0);
+            }
+        }
+    };
+
+    float c[NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) c[r] = 0.f;
+    __syncthreads();
+
+    for (int step = 0; step < p.T; ++step) {
+        const int t = dir ? p.T - 1 - step : step;
+        const int cur = step & 1;
+        copy_x(t);
+        __builtin_amdgcn_sched_barrier(0);  // the DMA is issued first, before any MFMA of the step
+        f32x4v acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {  // h_{-1} = 0
+            f32x4v a[2];
+            a[0] = *reinterpret_cast<const f32x4v *>(hb(cur, col, 4 * s));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) a[(q + 1) & 1] = *reinterpret_cast<const f32x4v *>(hb(cur, col, 16 * (q + 1) + 4 * s));
+                if (q < NQR) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][e], wres[b][q][e], acc[b], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const f32x4v w = *reinterpret_cast<const f32x4v *>(wl + ((q - NQR) * 8 * NB + b) * 256);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][e], w[e], acc[b], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // gate pre-activations = x-projection (DMA, own columns) + recurrent part, in place
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float *g = gb(4 * s + v, (wave * NB + b) * 16 + col);
+                *g = *g + acc[b][v];
+            }
         __syncthreads();
+        // cell: c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')   (rows i, f, g, o)
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int pi = tid + 512 * r;
+            const int row = pi / H, unit = pi - row * H;
+            const float *g = gb(row, unit);
+            const float ig = fast_sigmoid(g[0]);
+            const float fg = fast_sigmoid(g[H]);
+            const float gg = fast_tanh(g[2 * H]);
+            const float og = fast_sigmoid(g[3 * H]);
+            c[r] = fg * c[r] + ig * gg;
+            const float h = og * fast_tanh(c[r]);
+            *hb(cur ^ 1, row, unit) = h;
+            const int b = b0 + row;
+            if (b < p.B) p.hout[((int64_t)b * p.T + t) * (2 * H) + dir * H + unit] = h;
+        }
+        lds_barrier();
     }
 }
 

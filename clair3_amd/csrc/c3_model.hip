@@ -102,6 +102,8 @@ struct c3_model {
     // input transform is recomputed for 8 N-tiles; v2 (1 workgroup/CU, transform in the MFMA shadows) is bound by the
     // ~10 B/clk/CU L2->CU path (96 KB of patch + V traffic per 4096 MFMA cycles) and is kept for experiments only.
     int wino_version = 1;        // env C3HIP_WINOGRAD_VERSION (1 | 2)
+    bool lstm2_v2 = true;        // env C3HIP_LSTM2_V2=0 selects the streaming 10-wave kernel
+    int wino_stagger = 0;        // env C3HIP_WINOGRAD_STAGGER (units of 64 clocks)
     unsigned wino_mask = 0x36;   // layers run as Winograd (bit l); env C3HIP_WINOGRAD overrides (0x1b6 = all stride-1)
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
@@ -297,9 +299,39 @@ static int pack_tail(c3_model *m, const TensorMap &tm) {
 // LSTM layer `layer` (0/1): hidden H, input size `in`.
 //   proj_w row n = dir*4H + wave*64 + gate*16 + unit  <->  PyTorch gate row gate*H + wave*16 + unit
 //   whh fragments: [dir][wave][gate][q][lane][e] = W_hh[gate*H + wave*16 + (lane&15)][16q + 4*(lane>>4) + e]
-static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in, int Kp) {
+static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in, int Kp, bool v2) {
     const std::string base = layer == 0 ? "LSTM1" : "LSTM2";
     const int NW = H / 16, NQ = H / 16;
+    if (v2) {
+        // lstm_recurrent_kernel_v2: projection rows in PyTorch order (n = dir*4H + gate*H + unit); W_hh fragments
+        // [dir][block = n/16][q][lane][e] = W_hh[block*16 + (lane&15)][16q + 4*(lane>>4) + e]
+        std::vector<float> pw((size_t)2 * 4 * H * Kp, 0.f), pb((size_t)2 * 4 * H), wf((size_t)2 * 4 * H * H);
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = dir ? "_reverse" : "";
+            const float *wih, *whh, *bih, *bhh;
+            TRY(want(tm, base + ".weight_ih_l0" + sfx, {4 * H, in}, &wih));
+            TRY(want(tm, base + ".weight_hh_l0" + sfx, {4 * H, H}, &whh));
+            TRY(want(tm, base + ".bias_ih_l0" + sfx, {4 * H}, &bih));
+            TRY(want(tm, base + ".bias_hh_l0" + sfx, {4 * H}, &bhh));
+            for (int r = 0; r < 4 * H; ++r) {
+                const size_t n = (size_t)dir * 4 * H + r;
+                pb[n] = (float)((double)bih[r] + (double)bhh[r]);
+                for (int k = 0; k < in; ++k) pw[n * Kp + k] = wih[(size_t)r * in + k];
+            }
+            for (int blk = 0; blk < 4 * H / 16; ++blk)
+                for (int q = 0; q < NQ; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = blk * 16 + (lane & 15);
+                            const int k = 16 * q + 4 * (lane >> 4) + e;
+                            wf[((((size_t)dir * (4 * H / 16) + blk) * NQ + q) * 64 + lane) * 4 + e] = whh[(size_t)r * H + k];
+                        }
+        }
+        TRY(upload(m, &m->proj_w[layer], pw));
+        TRY(upload(m, &m->proj_b[layer], pb));
+        TRY(upload(m, &m->whh[layer], wf));
+        return 0;
+    }
     std::vector<float> pw((size_t)2 * 4 * H * Kp, 0.f), pb((size_t)2 * 4 * H), wf((size_t)2 * 4 * H * H);
     for (int dir = 0; dir < 2; ++dir) {
         const std::string sfx = dir ? "_reverse" : "";
@@ -437,6 +469,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             wp.B = (int)n, wp.H = hh[l], wp.W = ww[l], wp.Cin = cin, wp.Cout = Cout;
             wp.th = (hh[l] + 1) / 2, wp.tw = (ww[l] + 1) / 2, wp.P = (int)n * wp.th * wp.tw;
             wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
+            wp.stagger = m->wino_stagger;
             if (m->wino_version == 1) {
                 if (wp.res)
                     hipLaunchKernelGGL(wino_conv_kernel<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
@@ -533,8 +566,13 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
-        LstmParams lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
-        hipLaunchKernelGGL((lstm_recurrent_kernel<160, false>), dim3((unsigned)((n + 15) / 16), 2), dim3(640), 0, s, lp);
+        if (m->lstm2_v2) {
+            Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
+            hipLaunchKernelGGL(lstm_recurrent_kernel_v2<160>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+        } else {
+            LstmParams lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
+            hipLaunchKernelGGL((lstm_recurrent_kernel<160, false>), dim3((unsigned)((n + 15) / 16), 2), dim3(640), 0, s, lp);
+        }
         HIP_TRY(hipGetLastError());
     }
     return run_tail(m, s, m->h2, m->K4, n, y, "p.l4", "p.tail");
@@ -636,6 +674,8 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_VERSION")) m->wino_version = atoi(e);
+    if (const char *e = getenv("C3HIP_WINOGRAD_STAGGER")) m->wino_stagger = atoi(e);
+    if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
         c3_model_destroy(m);
@@ -684,8 +724,8 @@ int c3_model_load(c3_model *m, const c3_tensor_desc *tensors, int n_tensors) {
     }
     size_t expected = 0;
     if (m->kind == C3_KIND_PILEUP) {
-        TRY(pack_lstm(m, tm, 0, 128, m->C, 32));
-        TRY(pack_lstm(m, tm, 1, 160, 256, 256));
+        TRY(pack_lstm(m, tm, 0, 128, m->C, 32, false));
+        TRY(pack_lstm(m, tm, 1, 160, 256, 256, m->lstm2_v2));
         expected = 16;
     } else {
         int cin = m->C;

@@ -39,6 +39,7 @@ struct WinoParams {
     int B, H, W, Cin, Cout;
     int th, tw, P;       // tiles per column / row, total tiles
     int tiles_n, tiles;  // Cout/32, ceil(P/64)*tiles_n
+    int stagger;         // s_sleep units (64 clk) the second workgroup of a CU waits at start, 0 = off
 };
 
 constexpr int kWinoPT = 64;  // tiles per workgroup
@@ -56,6 +57,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
     const int tile = xcd_tile_index(blockIdx.x, p.tiles);
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int p0 = tm * kWinoPT, n0 = tn * kWinoNT;
+    // Two workgroups share a CU and each alternates a transform phase (VALU + memory) with an MFMA phase.
+    // Started together they stay in lockstep (both transform, then both fight for the matrix pipe); delaying
+    // every other workgroup of an XCD's dispatch sequence by about one phase lets them settle in anti-phase.
+    if (p.stagger > 0 && (((blockIdx.x >> 3) >> 5) & 1)) {
+        for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
 
     // ---- transform role: thread (tl, q) = (tile within block, cin quad within the chunk)
     const int tl = tid >> 2, q = tid & 3;

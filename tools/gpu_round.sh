@@ -21,6 +21,17 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']))
 for k,v in d['kernels'].items(): print('   %-9s %7.1f us %6.1f TF' % (k, v['avg_us'], v['tflops'] or 0))
 "; done; unset C3HIP_WINOGRAD_VERSION ;;
+    stagger) for st in 0 32 64 128 256; do echo "== stagger=$st"; C3HIP_WINOGRAD_STAGGER=$st timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline 2> gpurun_out/benchfa.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items() if k.startswith('fa.res')))
+"; done ;;
+    diagp) timeout 600 python tools/gpu_diag.py pileup pileup32 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
+    benchp) for v in 0 1; do echo "== C3HIP_LSTM2_V2=$v"; C3HIP_LSTM2_V2=$v timeout 600 python bench.py --gpus 1 --workload pileup --no-cpu-baseline 2> gpurun_out/benchp.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
+"; done ;;
     diagfa) timeout 600 python tools/gpu_diag.py fa fa9 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
     counters) rocprofv3 -L > gpurun_out/counters.txt 2>&1; echo "counters rc=$?"; wc -l gpurun_out/counters.txt ;;
     pmcsq) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_sq" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq.err"); echo "pmc sq rc=$?" ;;

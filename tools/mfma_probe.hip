@@ -26,6 +26,26 @@ __global__ __launch_bounds__(256) void pure_mfma(float *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+template <int NACC, int NB>
+__global__ __launch_bounds__(512, 2) void pure_mfma16(float *out, const float *w, int iters) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float bw[NB];
+    for (int i = 0; i < NB; ++i) bw[i] = w[threadIdx.x + 512 * i];   // distinct resident B registers
+    float a = threadIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < NB / NACC; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[u * NACC + i], acc[i], 0, 0, 0);
+        asm volatile("" : "+v"(a));
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 template <class K>
 static float time_it(K launch, int reps = 10) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -50,11 +70,64 @@ static float run_wino(const float *x, const float *zeros, const float *v, const 
     wp.B = B, wp.H = H, wp.W = W, wp.Cin = Cin, wp.Cout = Cout;
     wp.th = (H + 1) / 2, wp.tw = (W + 1) / 2, wp.P = B * wp.th * wp.tw;
     wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
+    wp.stagger = 0;
     return time_it([&] { hipLaunchKernelGGL((wino_conv_kernel<false, ABL>), dim3(wp.tiles), dim3(256), 0, 0, wp); });
+}
+
+template <class K>
+static void occ(const char *name, K kern, int threads) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, 0);
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+    printf("occupancy API: %-28s blocks/CU=%d (%s) regs=%d lds=%zu scratch=%zu\n", name, nb, hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
+}
+
+// census: how many workgroups of a given (LDS, VGPR-like) footprint are really co-resident on one CU
+template <int LDS_BYTES>
+__global__ __launch_bounds__(256, 2) void census_kernel(int *maxres, int *cur, int spin) {
+    __shared__ char buf[LDS_BYTES];
+    buf[threadIdx.x] = (char)threadIdx.x;
+    __syncthreads();
+    unsigned cu = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(cu));  // CU id bits [11:8], SE [15:13] (gfx9)
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int slot = (int)(((xcc & 0xf) << 8) | ((cu >> 8) & 0xff));
+    if (threadIdx.x == 0) {
+        int v = atomicAdd(&cur[slot], 1) + 1;
+        atomicMax(&maxres[slot], v);
+    }
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(32);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicSub(&cur[slot], 1);
+    if (buf[(threadIdx.x * 7) & 255] == 77) maxres[4095] = 1;
 }
 
 int main() {
     const int B = 256;
+    occ("wino_conv_kernel<false,0>", wino_conv_kernel<false, 0>, 256);
+    occ("wino_conv_kernel2<false>", wino_conv_kernel2<false>, 256);
+    occ("gemm conv 128x64", gemm_mfma_kernel<ConvLoader<4>, EPI_BIAS_RELU, 128, 64, 0>, 256);
+    occ("gemm conv 128x128", gemm_mfma_kernel<ConvLoader<4>, EPI_BIAS_RELU, 128, 128, 0>, 256);
+    {
+        int *mx, *cur;
+        hipMalloc(&mx, 4096 * 4); hipMalloc(&cur, 4096 * 4);
+        auto run = [&](const char *name, auto kern) {
+            hipMemset(mx, 0, 4096 * 4); hipMemset(cur, 0, 4096 * 4);
+            hipLaunchKernelGGL(kern, dim3(2048), dim3(256), 0, 0, mx, cur, 200);
+            hipDeviceSynchronize();
+            std::vector<int> h(4096); hipMemcpy(h.data(), mx, 4096 * 4, hipMemcpyDeviceToHost);
+            int hist[16] = {0}; for (int i = 0; i < 4095; ++i) if (h[i] > 0 && h[i] < 16) hist[h[i]]++;
+            printf("census %-16s max co-resident WGs per (xcc,hw_id-cu) slot histogram:", name);
+            for (int i = 1; i < 8; ++i) printf(" %d:%d", i, hist[i]);
+            printf("\n");
+        };
+        run("LDS 66560", census_kernel<66560>);
+        run("LDS 49152", census_kernel<49152>);
+        run("LDS 65536", census_kernel<65536>);
+        run("LDS 81920", census_kernel<81920>);
+    }
     size_t act = (size_t)B * 45 * 17 * 64;
     float *x, *y, *w, *bias, *zeros;
     CK(hipMalloc(&x, act * 4)); CK(hipMalloc(&y, act * 4)); CK(hipMalloc(&w, (size_t)256 * 2304 * 4)); CK(hipMalloc(&bias, 1024)); CK(hipMalloc(&zeros, 256));
@@ -69,6 +142,18 @@ int main() {
             float us4 = time_it([&] { hipLaunchKernelGGL(pure_mfma<4>, dim3(wg), dim3(256), 0, 0, o, iters / 2); }, 3);
             double fl = (double)wg * 4 * iters * 16 * 4096.0;  // waves * iters * 8*NACC(=2) MFMAs * 4096 flop
             printf("pure MFMA %4d WGs: 2 acc %.1f us %.1f TF | 4 acc %.1f us %.1f TF\n", wg, us2, fl / us2 / 1e6, us4, fl / us4 / 1e6);
+        }
+    }
+    {
+        float *o; CK(hipMalloc(&o, 4096 * 512 * 4));
+        for (int wg : {128, 256}) {
+            int iters = 400;
+            float us = time_it([&] { hipLaunchKernelGGL((pure_mfma16<5, 200>), dim3(wg), dim3(512), 0, 0, o, x, iters); }, 3);
+            double nm = (double)wg * 8 * iters * 200;  // MFMAs
+            printf("pure MFMA16x16x4 %d WGs x 8 waves, 5 acc, 200 resident B regs: %.1f us  %.1f TF  (%.1f cycles/MFMA/SIMD @2.4GHz)\n", wg, us,
+                   nm * 2048 / us / 1e6, us * 2400.0 / (iters * 200.0 * 2));
+            float us4 = time_it([&] { hipLaunchKernelGGL((pure_mfma16<4, 128>), dim3(wg), dim3(512), 0, 0, o, x, iters); }, 3);
+            printf("pure MFMA16x16x4 %d WGs x 8 waves, 4 acc, 128 resident B regs: %.1f us  (%.1f cycles/MFMA/SIMD)\n", wg, us4, us4 * 2400.0 / (iters * 128.0 * 2));
         }
     }
     const char *names[] = {"full", "no-gload", "no-gload,no-ldswrite", "no-gload,no-ldswrite,no-barrier", "mfma+ldsread only(=7)", "all off (15)", "no barrier only (4)", "no frag reads only (8)"};

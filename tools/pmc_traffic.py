@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes of tools/gpu_round.sh (stage `pmc`: --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+separate runs, as MI355X_MICROARCH.md prescribes) into profiles/pmc_traffic.json, which bench.py reports as
+roofline.traffic.  gfx950 correction: FETCH_SIZE of wide coalesced reads is doubled."""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def agg(path):
+    a = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        a[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return a
+
+
+def main(tag):
+    f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch/c3_counter_collection.csv"))
+    w = agg(os.path.join(ROOT, "gpurun_out/pmc_write/c3_counter_collection.csv"))
+    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("wino_conv_kernel" in k)
+    tot_f = tot_w = n = 0
+    per = {}
+    for k in f:
+        if not conv(k):
+            continue
+        fs, ws = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
+        tot_f += sum(fs)
+        tot_w += sum(ws)
+        n += len(fs)
+        per[k[:90]] = {"launches": len(fs), "fetch_kb_avg_reported": sum(fs) / len(fs), "write_kb_avg": sum(ws) / len(ws)}
+    B = 256
+    a1, a2, a3 = 45 * 17 * 64 * 4, 23 * 9 * 128 * 4, 12 * 5 * 256 * 4
+    shapes = [(89 * 33 * 8, a1, 0), (a1, a1, 0), (a1, a1, a1), (a1, a2, 0), (a2, a2, 0), (a2, a2, a2), (a2, a3, 0), (a3, a3, 0),
+              (a3, a3, a3)]
+    out = {
+        "tag": tag,
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around "
+                  "`bench.py --gpus 1 --steps 5 --warmup 2 --workload full_alignment` (B=256)",
+        "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B",
+        "kernel_family": "the 9 convolution launches of one full-alignment step (direct implicit-GEMM + Winograd kernels)",
+        "launches": n,
+        "hbm_bytes_per_launch": (2 * tot_f + tot_w) * 1024 / n,
+        "fetch_bytes_per_launch_corrected": 2 * tot_f * 1024 / n,
+        "write_bytes_per_launch": tot_w * 1024 / n,
+        "algorithmic_bytes_per_launch": sum(B * (a + b + c) for a, b, c in shapes) / 9,
+        "per_kernel": per,
+    }
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print({k: v for k, v in out.items() if k != "per_kernel"})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "round1")
