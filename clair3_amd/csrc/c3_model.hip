@@ -97,14 +97,14 @@ struct c3_model {
     float *conv_b[9] = {};
     float *wino_v[9] = {};   // Winograd-domain weights of the stride-1 convs (layers 1,2,4,5,7,8)
     bool use_wino[9] = {};
-    // Measured on MI355X (B=256): Winograd v1 wins on the 64- and 128-channel blocks (res1: 123/141 vs 134/145 us,
-    // res2: 121/132 vs 164/174 us) and loses on the 256-channel block, whose 18 tiles/window quantise badly and whose
-    // input transform is recomputed for 8 N-tiles; v2 (1 workgroup/CU, transform in the MFMA shadows) is bound by the
-    // ~10 B/clk/CU L2->CU path (96 KB of patch + V traffic per 4096 MFMA cycles) and is kept for experiments only.
-    int wino_version = 1;        // env C3HIP_WINOGRAD_VERSION (1 | 2)
+    // Measured on MI355X (B=256), direct implicit GEMM -> Winograd v1: res1 134/144 -> 105/112 us, res2 163/172 ->
+    // 110/113 us, res3 171/179 -> 162/164 us (res3 gains little: 18 tiles per window quantise badly and its input
+    // transform is recomputed for each of 8 N-tiles).  v2 (one workgroup per CU, transform interleaved into the MFMA
+    // stream) is 10-15 % slower than v1 on res1/res2 and equal on res3; it stays selectable for experiments.
+    unsigned wino_v2_mask = 0;      // layers whose Winograd launch uses kernel v2 (experimental); env C3HIP_WINOGRAD_V2MASK
     bool lstm2_v2 = true;        // env C3HIP_LSTM2_V2=0 selects the streaming 10-wave kernel
     int wino_stagger = 0;        // env C3HIP_WINOGRAD_STAGGER (units of 64 clocks)
-    unsigned wino_mask = 0x36;   // layers run as Winograd (bit l); env C3HIP_WINOGRAD overrides (0x1b6 = all stride-1)
+    unsigned wino_mask = 0x1b6;  // layers run as Winograd (bit l): all six stride-1 convs; env C3HIP_WINOGRAD overrides
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
@@ -470,7 +470,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             wp.th = (hh[l] + 1) / 2, wp.tw = (ww[l] + 1) / 2, wp.P = (int)n * wp.th * wp.tw;
             wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
             wp.stagger = m->wino_stagger;
-            if (m->wino_version == 1) {
+            if (!(m->wino_v2_mask & (1u << l))) {
                 if (wp.res)
                     hipLaunchKernelGGL(wino_conv_kernel<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
                 else
@@ -673,7 +673,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     }
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("C3HIP_WINOGRAD_VERSION")) m->wino_version = atoi(e);
+    if (const char *e = getenv("C3HIP_WINOGRAD_V2MASK")) m->wino_v2_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_STAGGER")) m->wino_stagger = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {

@@ -46,12 +46,38 @@ constexpr int kWinoPT = 64;  // tiles per workgroup
 constexpr int kWinoNT = 32;  // couts per workgroup
 constexpr int kWinoBK = 16;  // cin per chunk
 
+// Output transform tail shared by both kernels: Y = (A^T M) A for one (tile, 4 consecutive couts), + bias
+// (+ residual), ReLU and the 2x2 x 16-byte stores.  All addressing is a 32-bit byte offset into buffer descriptors; pixels that fall outside an
+// odd-sized image (or tiles beyond P) get an out-of-range offset, which the hardware bounds check drops -- no
+// branches, no 64-bit address arithmetic (that arithmetic was ~60 % of the first version's kernel time).
+template <bool RES>
+__device__ __forceinline__ void wino_store4(const f32x4 (&s)[2][4], int2 tc, int n, f32x4 bias, __amdgpu_buffer_rsrc_t orsrc,
+                                            __amdgpu_buffer_rsrc_t rrsrc, int row_bytes, int px_bytes) {
+    const uint32_t o00 = (uint32_t)tc.x + (uint32_t)n * 4u;
+    const bool v = tc.y & 1, vr = (tc.y & 3) == 3, vc = (tc.y & 5) == 5, vrc = (tc.y & 7) == 7;
+    const uint32_t kOut = 0x80000000u;
+    const uint32_t off[2][2] = {{v ? o00 : kOut, vc ? o00 + px_bytes : kOut},
+                                {vr ? o00 + row_bytes : kOut, vrc ? o00 + row_bytes + px_bytes : kOut}};
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        f32x4 y[2] = {s[i][0] + s[i][1] + s[i][2] + bias, s[i][1] - s[i][2] - s[i][3] + bias};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (RES) y[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[i][j], 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[j][e] = fmaxf(y[j][e], 0.f);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[j]), orsrc, off[i][j], 0, 0);
+        }
+    }
+}
+
 // ABL (tools/mfma_probe only; 0 in the product): bit0 no patch loads, bit1 no transform+LDS writes, bit2 no V loads,
 // bit3 no epilogue exchange/stores, bit4 no MFMAs.
 template <bool RES, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
     __shared__ __attribute__((aligned(16))) char ubuf[16 * kWinoPT * kWinoBK * 4];  // 64 KiB: U_xi / M_xi exchange
-    __shared__ int4 tcoord[kWinoPT];                                                 // (b, 2ty, 2tx, valid)
+    __shared__ int2 tcoord[kWinoPT];  // (byte offset of output pixel (b,2ty,2tx) channel 0 ; flags: 1 tile valid, 2 row+1 < H, 4 col+1 < W)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_tile_index(blockIdx.x, p.tiles);
@@ -60,8 +86,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
     // Two workgroups share a CU and each alternates a transform phase (VALU + memory) with an MFMA phase.
     // Started together they stay in lockstep (both transform, then both fight for the matrix pipe); delaying
     // every other workgroup of an XCD's dispatch sequence by about one phase lets them settle in anti-phase.
-    if (p.stagger > 0 && (((blockIdx.x >> 3) >> 5) & 1)) {
-        for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+    if (p.stagger != 0) {
+        // stagger > 0: every other group of 32 workgroups of an XCD; stagger < 0: every other workgroup of an XCD
+        const int slot = blockIdx.x >> 3;
+        const bool late = p.stagger > 0 ? ((slot >> 5) & 1) : (slot & 1);
+        const int n = p.stagger > 0 ? p.stagger : -p.stagger;
+        if (late)
+            for (int i = 0; i < n; i += 64) __builtin_amdgcn_s_sleep(64);
     }
 
     // ---- transform role: thread (tl, q) = (tile within block, cin quad within the chunk)
@@ -70,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
     // the hardware bounds check returns 0 for the padding taps (their offset is forced out of range).
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.x), 0, p.B * p.H * p.W * p.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(RES ? p.res : p.out), 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
     uint32_t base;        // byte offset of pixel (b, 2ty-1, 2tx-1), channel 4q (wraps for the top/left halo: masked)
     uint32_t okmask = 0;  // bit dy*4+dx: that pixel of the 4x4 patch is inside the image
     {
@@ -86,7 +120,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx)
                 if (iy0 + dy >= 0 && iy0 + dy < p.H && ix0 + dx >= 0 && ix0 + dx < p.W) okmask |= 1u << (dy * 4 + dx);
-        if (q == 0) tcoord[tl] = make_int4(b, 2 * ty, 2 * tx, valid ? 1 : 0);
+        if (q == 0)
+            tcoord[tl] = make_int2((int)((((int64_t)b * p.H + 2 * ty) * p.W + 2 * tx) * p.Cout * 4),
+                                   (valid ? 1 : 0) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 4 : 0));
     }
     const int u_wr = tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4);  // byte offset inside one xi plane (4096 B)
 
@@ -214,43 +250,21 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
                     }
         }
         __syncthreads();
-#pragma unroll 1
-        for (int r = 0; r < 4; ++r) {  // not unrolled: the accumulators of pass 1 are still live
-            const int idx = tid + 256 * r;
-            const int c16 = idx & 15, t = idx >> 4;
-            const int4 tc = tcoord[t];
-            float m[4][4];
+        {   // one (tile, cout quad) per thread: 16 x ds_read_b128, A^T M A on 4 couts, 4 x 16-byte stores
+            const int cq = tid & 3, t = tid >> 2;
+            const int2 tc = tcoord[t];
+            f32x4 m[4][4];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = mbuf[(xi * kWinoPT + t) * 16 + c16];
-            // Y = A^T M A,  A^T = [[1,1,1,0],[0,1,-1,-1]]
-            float s[2][4];
+            for (int xi = 0; xi < 16; ++xi)
+                m[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4 *>(&mbuf[(xi * kWinoPT + t) * 16 + 4 * cq]);
+            f32x4 s4[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s[0][j] = m[0][j] + m[1][j] + m[2][j];
-                s[1][j] = m[1][j] - m[2][j] - m[3][j];
+                s4[0][j] = m[0][j] + m[1][j] + m[2][j];
+                s4[1][j] = m[1][j] - m[2][j] - m[3][j];
             }
-            const int n = n0 + 16 * h + c16;
-            const float bias = p.bias[n];
-            if (tc.w) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float y0 = s[i][0] + s[i][1] + s[i][2];
-                    const float y1 = s[i][1] - s[i][2] - s[i][3];
-                    const int oy = tc.y + i;
-                    if (oy < p.H) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int ox = tc.z + j;
-                            if (ox < p.W) {
-                                const int64_t o = (((int64_t)tc.x * p.H + oy) * p.W + ox) * p.Cout + n;
-                                float val = (j == 0 ? y0 : y1) + bias;
-                                if (RES) val += p.res[o];
-                                p.out[o] = fmaxf(val, 0.f);
-                            }
-                        }
-                    }
-                }
-            }
+            const int n = n0 + 16 * h + 4 * cq;
+            wino_store4<RES>(s4, tc, n, *reinterpret_cast<const f32x4 *>(p.bias + n), orsrc, rrsrc, p.W * p.Cout * 4, p.Cout * 4);
         }
     }
 }
@@ -263,13 +277,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
 //             64 MFMAs on U[c&1]                                                            (VALU/LDS/VMEM of the
 //             barrier                                                                        lines above fill the gaps)
 // The epilogue exchanges all 32 couts in one pass through the 128 KiB the two U stages occupy.
-template <bool RES>
+template <bool RES, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
     // two distinct LDS objects (not one array split in halves) so that alias analysis knows the U stores of
     // the next chunk cannot touch the fragments being read, and may schedule them among the MFMAs
     __shared__ __attribute__((aligned(16))) char ubuf0[65536];
     __shared__ __attribute__((aligned(16))) char ubuf1[65536];
-    __shared__ int4 tcoord[kWinoPT];
+    __shared__ int2 tcoord[kWinoPT];  // (byte offset of output pixel (b,2ty,2tx) channel 0 ; flags: 1 valid, 2 row+1 < H, 4 col+1 < W)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_tile_index(blockIdx.x, p.tiles);
@@ -278,6 +292,9 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.x), 0, p.B * p.H * p.W * p.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(RES ? p.res : p.out), 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
     const int tl = tid >> 2, q = tid & 3;
     uint32_t base, okmask = 0;
     {
@@ -294,7 +311,9 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx)
                 if (iy0 + dy >= 0 && iy0 + dy < p.H && ix0 + dx >= 0 && ix0 + dx < p.W) okmask |= 1u << (dy * 4 + dx);
-        if (q == 0) tcoord[tl] = make_int4(b, 2 * ty, 2 * tx, valid ? 1 : 0);
+        if (q == 0)
+            tcoord[tl] = make_int2((int)((((int64_t)b * p.H + 2 * ty) * p.W + 2 * tx) * p.Cout * 4),
+                                   (valid ? 1 : 0) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 4 : 0));
     }
     const int u_wr = tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4);
 
@@ -320,15 +339,18 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
             for (int dx = 0; dx < 4; ++dx) {
                 const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
                 const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
-                d[dy][dx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
+                if constexpr (ABL & 1) d[dy][dx] = f32x4{(float)off, 1.f, 2.f, 3.f};
+                else d[dy][dx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
             }
     };
     auto load_v = [&](f32x4 (&bf)[4][2], int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-                bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
+            for (int g = 0; g < 2; ++g) {
+                if constexpr (ABL & 4) bf[i][g] = f32x4{1.f, 2.f, 3.f, (float)c};
+                else bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
+            }
     };
     auto transform_store = [&](f32x4 (&d)[4][4], char *__restrict__ u) __attribute__((always_inline)) {
 #pragma unroll
@@ -382,12 +404,18 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
                 a[(st + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(plane + a_rd0 + coff);
                 a[(st + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(plane + a_rd1 + coff);
             }
+            if constexpr (!(ABL & 16)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][0][j], bCur[i][g][j], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][1][j], bCur[i][g][j], acc[i][1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][0][j], bCur[i][g][j], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][1][j], bCur[i][g][j], acc[i][1], 0, 0, 0);
+                }
+            } else {
+                asm volatile("" ::"v"(a[st & 1][0]), "v"(a[st & 1][1]), "v"(bCur[i][g]));
             }
-            if (st < 4) {
+            if constexpr (ABL & 2) {
+                asm volatile("" ::"v"(dCur[st & 3][st >> 1 & 3]));
+            } else if (st < 4) {
                 const int dx = st;  // t = B^T d, column dx
                 const f32x4 d0 = dCur[0][dx], d1 = dCur[1][dx], d2 = dCur[2][dx], d3 = dCur[3][dx];
                 dCur[0][dx] = d0 - d2, dCur[1][dx] = d1 + d2, dCur[2][dx] = d2 - d1, dCur[3][dx] = d1 - d3;
@@ -410,6 +438,17 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
     }
     if (c <= last) body(c, ubuf0, ubuf1, dB, dA, bfA, bfB);
 
+    if constexpr (ABL & 8) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sacc += acc[i][rb][v];
+        if (sacc == 123.456f) p.out[tid] = sacc;
+        return;
+    }
     // ---- epilogue: one exchange pass, [16 xi][64 tiles][32 couts] floats = the 128 KiB of both U stages
     // xi planes 0..7 live in ubuf0, 8..15 in ubuf1 (8 KiB per plane)
     float *mbuf0 = reinterpret_cast<float *>(ubuf0), *mbuf1 = reinterpret_cast<float *>(ubuf1);
@@ -427,43 +466,23 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
                 }
     }
     __syncthreads();
-#pragma unroll 2
-    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {  // (tile, cout quad) items: 64 x 8 = 2 per thread
         const int idx = tid + 256 * r;
-        const int c32 = idx & 31, t = idx >> 5;
-        const int4 tc = tcoord[t];
-        float m[4][4];
+        const int cq = idx & 7, t = idx >> 3;
+        const int2 tc = tcoord[t];
+        f32x4 m[4][4];
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi)
-            m[xi >> 2][xi & 3] = (xi < 8 ? mbuf0 : mbuf1)[((xi & 7) * kWinoPT + t) * 32 + c32];
-        float s[2][4];
+            m[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4 *>(&(xi < 8 ? mbuf0 : mbuf1)[((xi & 7) * kWinoPT + t) * 32 + 4 * cq]);
+        f32x4 s4[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s[0][j] = m[0][j] + m[1][j] + m[2][j];
-            s[1][j] = m[1][j] - m[2][j] - m[3][j];
+            s4[0][j] = m[0][j] + m[1][j] + m[2][j];
+            s4[1][j] = m[1][j] - m[2][j] - m[3][j];
         }
-        const int n = n0 + c32;
-        const float bias = p.bias[n];
-        if (tc.w) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float y0 = s[i][0] + s[i][1] + s[i][2];
-                const float y1 = s[i][1] - s[i][2] - s[i][3];
-                const int oy = tc.y + i;
-                if (oy < p.H) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int ox = tc.z + j;
-                        if (ox < p.W) {
-                            const int64_t o = (((int64_t)tc.x * p.H + oy) * p.W + ox) * p.Cout + n;
-                            float val = (j == 0 ? y0 : y1) + bias;
-                            if (RES) val += p.res[o];
-                            p.out[o] = fmaxf(val, 0.f);
-                        }
-                    }
-                }
-            }
-        }
+        const int n = n0 + 4 * cq;
+        wino_store4<RES>(s4, tc, n, *reinterpret_cast<const f32x4 *>(p.bias + n), orsrc, rrsrc, p.W * p.Cout * 4, p.Cout * 4);
     }
 }
 

@@ -1,0 +1,80 @@
+"""Tensor transport for one GPU worker.
+
+The reference worker reads a list of ``<name>.npy`` / ``<name>.info`` pairs written by the tensor-extraction
+stage, loads every file completely, slices it into batches and runs H2D -> forward -> D2H strictly in sequence
+(clair3/CallVariantsFromCffi.py:106-133 ``tensor_generator_for_chunk`` and the loop at :302-353).  This module
+keeps the file formats, the batch boundaries and the order of the rows exactly as the reference produces them,
+but
+  * memory-maps the ``.npy`` files instead of reading up to 235 MB per file up front,
+  * double-buffers through ``c3_predict_submit`` / ``c3_predict_wait``: while batch *i* is on the GPU, batch
+    *i+1* is being copied into the library's pinned staging buffer and its H2D transfer is already queued,
+  * hands every ``(positions, alt_info, Y)`` batch to a caller-supplied consumer -- in the reference pipeline
+    that is the unchanged ``batch_output`` (clair3/CallVariants.py:1069), run in the existing process pool.
+One persistent process per GPU replaces the reference's ``free_MB // 8000`` short-lived workers per device
+(clair3/CallVariantsFromCffiGPU.py:55-56,138-156).
+"""
+import os
+
+import numpy as np
+
+
+def read_info(path):
+    """``<ctg>:<pos>:<ref seq>\\t<depth>-<alt info>`` per line -> (positions, alt_infos); same parsing as
+    clair3/CallVariantsFromCffi.py:114-122."""
+    with open(path, "r") as f:
+        text = f.read().strip()
+    positions, alt_infos = [], []
+    if not text:
+        return positions, alt_infos
+    for line in text.split("\n"):
+        cols = line.split("\t")
+        positions.append(cols[0])
+        alt_infos.append(cols[1])
+    return positions, alt_infos
+
+
+def iter_tensor_files(list_fn):
+    """Yield (tensor, positions, alt_infos) for every entry of an ``--output_tensor_can_fn_list`` file; tensors are
+    memory-mapped.  Entries are relative to the list file's directory (CallVariantsFromCffi.py:112-113)."""
+    parent = os.path.dirname(list_fn)
+    with open(list_fn, "r") as f:
+        names = [n for n in f.read().strip().split("\n") if n != ""]
+    for name in names:
+        tensor = np.load(os.path.join(parent, name + ".npy"), mmap_mode="r")
+        positions, alt_infos = read_info(os.path.join(parent, name + ".info"))
+        if len(tensor) != len(positions) or len(tensor) != len(alt_infos):
+            raise ValueError(f"{name}: {len(tensor)} tensor rows but {len(positions)} .info rows")
+        yield tensor, positions, alt_infos
+
+
+def iter_batches(list_fn, batch_size):
+    """Same batch boundaries as the reference: batches never span files, the last batch of a file is short."""
+    for tensor, positions, alt_infos in iter_tensor_files(list_fn):
+        n = len(tensor)
+        for lo in range(0, n, batch_size):
+            hi = min(lo + batch_size, n)
+            yield tensor[lo:hi], positions[lo:hi], alt_infos[lo:hi]
+
+
+def predict_batches(model, batches, consume):
+    """Run ``model`` over an iterator of (X, positions, alt_infos) with a two-slot software pipeline and call
+    ``consume(positions, alt_infos, Y)`` for every batch, in order.  ``model`` needs ``submit(X, slot)`` /
+    ``wait(ticket)`` (clair3_amd.model._HipModel).  Returns the number of windows processed."""
+    total = 0
+    pending = None  # (ticket, positions, alt_infos)
+    slot = 0
+    for X, positions, alt_infos in batches:
+        ticket = model.submit(np.ascontiguousarray(X), slot=slot)  # staging copy + H2D + kernels + D2H enqueued
+        if pending is not None:
+            consume(pending[1], pending[2], model.wait(pending[0]))
+        pending = (ticket, positions, alt_infos)
+        total += len(positions)
+        slot ^= 1
+    if pending is not None:
+        consume(pending[1], pending[2], model.wait(pending[0]))
+    return total
+
+
+def predict_file_list(model, list_fn, consume, batch_size=1000):
+    """The reference's GPU batch size is predictBatchSize * 5 = 1000 (CallVariantsFromCffi.py:265-269)."""
+    return predict_batches(model, iter_batches(list_fn, batch_size), consume)

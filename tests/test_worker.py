@@ -1,0 +1,94 @@
+"""Transport logic of one GPU worker (clair3_amd/worker.py): file formats, batch boundaries, ordering and the
+two-slot pipeline.  The CPU tests drive it with a stand-in model whose submit/wait run the oracle; the GPU test
+checks the real asynchronous path against the synchronous one."""
+import os
+
+import numpy as np
+import pytest
+
+from clair3_amd import synthetic as syn, worker
+
+
+def write_chunk_files(tmp_path, sizes, kind=syn.PILEUP, seed=5):
+    """Tensor files exactly as the reference's GPU tensor stage writes them: int8 .npy + .info lines
+    "<ctg>:<pos>:<seq>\\t<depth>-<alt info>" (preprocess/CreateTensorPileupFromCffi.py:443-452)."""
+    names, xs = [], []
+    for i, n in enumerate(sizes):
+        x = syn.make_windows(kind, n, seed=seed + i)
+        name = f"chunk_{i}"
+        np.save(tmp_path / f"{name}.npy", x)
+        with open(tmp_path / f"{name}.info", "w") as f:
+            for j in range(n):
+                f.write(f"chr20:{1000 * i + j}:{'ACGT' * 8}A\t{30 + j % 7}-XA 3 RC 27 \n")
+        names.append(name)
+        xs.append(x)
+    lst = tmp_path / "gpu_chunk_0"
+    lst.write_text("\n".join(names) + "\n")
+    return str(lst), xs
+
+
+class OracleModel:
+    """submit/wait stand-in with the contract of _HipModel; records the call order."""
+
+    def __init__(self, sd):
+        from oracle import oracle
+        self.oracle, self.sd, self.log, self.inflight = oracle, sd, [], {}
+
+    def submit(self, x, slot=0):
+        assert slot in (0, 1) and slot not in self.inflight, "slot reused before wait"
+        assert x.flags["C_CONTIGUOUS"]
+        self.inflight[slot] = np.array(x)
+        self.log.append(("submit", slot, len(x)))
+        return slot
+
+    def wait(self, ticket):
+        x = self.inflight.pop(ticket)
+        self.log.append(("wait", ticket, len(x)))
+        return self.oracle.pileup_forward(self.sd, x, n_threads=1)
+
+
+def test_batches_follow_the_reference_boundaries(tmp_path):
+    lst, xs = write_chunk_files(tmp_path, [5, 0, 12, 1])
+    got = list(worker.iter_batches(lst, batch_size=5))
+    assert [len(b[0]) for b in got] == [5, 5, 5, 2, 1]  # never across files; empty file yields nothing
+    assert got[1][1][0] == "chr20:2000:" + "ACGT" * 8 + "A" and got[1][2][0].startswith("30-XA 3")
+    flat = np.concatenate([np.asarray(b[0]) for b in got])
+    assert np.array_equal(flat, np.concatenate([x for x in xs if len(x)]))
+
+
+def test_pipeline_keeps_order_and_overlaps(tmp_path):
+    from oracle import oracle
+    sd = syn.make_state_dict(syn.PILEUP, seed=3)
+    lst, xs = write_chunk_files(tmp_path, [7, 3, 9])
+    m = OracleModel(sd)
+    rows, pos = [], []
+    n = worker.predict_file_list(m, lst, lambda p, a, y: (rows.append(y), pos.extend(p)), batch_size=4)
+    assert n == 19 and len(pos) == 19
+    y = np.concatenate(rows)
+    assert np.array_equal(y, oracle.pileup_forward(sd, np.concatenate(xs), n_threads=1))
+    assert pos[7] == "chr20:1000:" + "ACGT" * 8 + "A"
+    # batch i+1 is submitted before batch i is waited for, on alternating slots
+    kinds = [e[0] for e in m.log]
+    assert kinds[:3] == ["submit", "submit", "wait"] and kinds[-1] == "wait"
+    assert [e[1] for e in m.log if e[0] == "submit"][:4] == [0, 1, 0, 1]
+
+
+def test_info_rows_must_match(tmp_path):
+    lst, _ = write_chunk_files(tmp_path, [4])
+    with open(tmp_path / "chunk_0.info", "a") as f:
+        f.write("chr20:9:ACGT\t30-RA 30 \n")
+    with pytest.raises(ValueError, match="4 tensor rows but 5"):
+        list(worker.iter_batches(lst, 10))
+
+
+@pytest.mark.gpu
+def test_async_file_pipeline_matches_sync_predict(tmp_path):
+    from clair3_amd.model import Clair3_F
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=13)
+    m = Clair3_F(add_indel_length=True, predict=True).to("cuda:0")
+    m.load_state_dict(sd)
+    lst, xs = write_chunk_files(tmp_path, [130, 1, 77], kind=syn.FULL_ALIGNMENT, seed=14)
+    rows = []
+    n = worker.predict_file_list(m, lst, lambda p, a, y: rows.append(y), batch_size=64)
+    assert n == 208
+    assert np.array_equal(np.concatenate(rows), m.predict_numpy(np.concatenate(xs)))
