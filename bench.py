@@ -13,7 +13,10 @@ probability rows to rank 0.  One process per GPU, windows sharded
 
   value        whole-job candidate-windows/s of the headline workload = BASELINE.json configs[2]
                "ONT r10.4.1 full-alignment model, synthetic (B=256, 89, 33, 8)" (the path the north-star target
-               is quoted on); the same measurement for configs[1] (pileup, B=1024) is in "pileup";
+               is quoted on); the same measurement for configs[1] (pileup, B=1024) is in "pileup".  By default two
+               batches are kept in flight per GPU (--streams 2: two model handles on two HIP streams, every step
+               still a complete forward over one full batch -- the reference runs several workers per GPU too);
+               "one_batch_in_flight" is the same K steps issued strictly one after the other;
   roofline     dominant kernel family (implicit-GEMM 3x3 convolutions on v_mfma_f32_32x32x2_f32), HIP-event
                timed per launch on the launch stream in a second, profiled pass over the same steps;
                achieved = algorithmic FLOP (2*MACs of the reference layer shapes) / kernel time;
@@ -69,12 +72,14 @@ def run_workload(name, args, rank, world, local):
     x_host = syn.make_windows(kind, batch, seed=1000 + rank, channels=channels)
     x = torch.from_numpy(x_host).to(dev)  # inputs resident in HBM before the timed region
     n_total = batch * world
-
-    def step():
-        y = model(x)  # c3_predict_device on torch's current stream
-        if world > 1:
-            return c3dist.gather_rows(y, n_total, dst=0)
-        return y
+    # --streams S > 1: S model handles (own workspace each) on S HIP streams, steps issued round-robin -- a worker
+    # that keeps S batches in flight, which is how the reference itself drives a GPU (free_MB // 8000 concurrent
+    # workers per device, clair3/CallVariantsFromCffiGPU.py:55-56).  Kernels that cannot fill 256 CUs on their own
+    # (the 33-step LSTM recurrences on 128 workgroups, the 12x5 stage, the FC tail) then overlap the next batch's
+    # large kernels.  Every step is still one complete forward pass over one full batch.
+    S = max(args.streams, 1)
+    models = [model] + [build_model(kind, channels, indel, local)[0] for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in models]
 
     def fence():
         torch.cuda.synchronize()
@@ -82,24 +87,46 @@ def run_workload(name, args, rank, world, local):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        assert out is not None and out.shape == (n_total, 90 if indel else 24)
-        assert bool(torch.isfinite(out).all())
+    def timed(n_streams):
+        counter = [0]
+
+        def step():
+            i = counter[0] % n_streams
+            counter[0] += 1
+            if n_streams == 1:
+                y = model(x)  # c3_predict_device on torch's current stream
+            else:
+                with torch.cuda.stream(streams[i]):
+                    y = models[i](x)
+            if world > 1:
+                if n_streams > 1:
+                    torch.cuda.current_stream(dev).wait_stream(streams[i])
+                return c3dist.gather_rows(y, n_total, dst=0)
+            return y
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            assert out is not None and out.shape == (n_total, 90 if indel else 24)
+            assert bool(torch.isfinite(out).all())
+        return elapsed
+
+    single = timed(1)
+    elapsed = timed(S) if S > 1 else single
     res = {
-        "workload": cfg, "batch_per_gpu": batch, "windows_per_step": n_total,
+        "workload": cfg, "batch_per_gpu": batch, "windows_per_step": n_total, "batches_in_flight": S,
         "value": n_total * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+        "one_batch_in_flight": {"value": n_total * args.steps / single, "ms_per_step": 1e3 * single / args.steps},
         "flop_per_window": flop_w, "bytes_per_window": bytes_w,
     }
 
@@ -213,6 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=["all"] + list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/experiments only)")
+    ap.add_argument("--streams", type=int, default=2, help="batches kept in flight per GPU (model handles x HIP streams)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", nargs=4, metavar=("WORKLOAD", "THREADS", "BUDGET", "BATCH"), help=argparse.SUPPRESS)
@@ -241,7 +269,8 @@ def main():
             "config": {"workload": head["workload"], "batch_per_gpu": head["batch_per_gpu"],
                        "windows_per_step": head["windows_per_step"], "weights": "seeded random (no checkpoints offline)",
                        "sharding": f"windows x{world}, gather of probability rows to rank 0" if world > 1 else "single GPU",
-                       "inputs": "resident in HBM before the timed region"},
+                       "inputs": "resident in HBM before the timed region", "batches_in_flight": head["batches_in_flight"]},
+            "one_batch_in_flight": head["one_batch_in_flight"],
             "roofline": head["roofline"], "kernels": head["kernels"],
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -251,6 +280,7 @@ def main():
         for n in names[1:]:
             r = results[n]
             sub = {"value": r["value"], "unit": "candidate-windows/s", "ms_per_step": r["ms_per_step"],
+                   "batches_in_flight": r["batches_in_flight"], "one_batch_in_flight": r["one_batch_in_flight"],
                    "config": {"workload": r["workload"], "batch_per_gpu": r["batch_per_gpu"]},
                    "roofline": r["roofline"], "kernels": r["kernels"]}
             if world == 1 and not args.no_cpu_baseline:

@@ -89,6 +89,34 @@ def quick_timing():
         m.profile(False)
 
 
+def host_path():
+    """PCIe-inclusive rates of the host-buffer entry points (pageable numpy in / out), never bench.py's `value`."""
+    from clair3_amd import worker
+    print("== host-buffer path (H2D + kernels + D2H, pageable numpy buffers)")
+    for kind, B, ch, indel, nb in ((syn.FULL_ALIGNMENT, 256, 8, True, 24), (syn.PILEUP, 1024, 18, False, 24)):
+        sd = syn.make_state_dict(kind, ch, indel, seed=0)
+        cls = Clair3_P if kind == syn.PILEUP else Clair3_F
+        ms = []
+        for _ in range(2):
+            m = cls(add_indel_length=indel, predict=True, input_channels=ch).to("cuda:0")
+            m.load_state_dict(sd)
+            ms.append(m)
+        x = syn.make_windows(kind, B, seed=1)
+        batches = [(x, ["p"] * B, ["a"] * B)] * nb
+        ms[0].predict_numpy(x), ms[1].predict_numpy(x)
+        t = time.time()
+        for _ in range(nb):
+            ms[0].predict_numpy(x)
+        sync = nb * B / (time.time() - t)
+        t = time.time()
+        worker.predict_batches(ms[0], iter(batches), lambda p, a, y: None)
+        one = nb * B / (time.time() - t)
+        t = time.time()
+        worker.predict_batches(ms, iter(batches), lambda p, a, y: None)
+        two = nb * B / (time.time() - t)
+        print(f"  {kind:15s} B={B}: c3_predict (sync) {sync:,.0f} | submit/wait, 1 handle {one:,.0f} | submit/wait, 2 handles {two:,.0f} windows/s", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["fa", "fa9", "pileup", "pileup32", "time"]
     for w in what:
@@ -103,5 +131,7 @@ if __name__ == "__main__":
                 pileup(n=20, seed=1, dtype=np.int32)
             elif w == "time":
                 quick_timing()
+            elif w == "host":
+                host_path()
         except Exception as e:  # keep going: the point is to collect as much as possible per GPU call
             print(f"!! {w} failed: {type(e).__name__}: {e}", flush=True)
