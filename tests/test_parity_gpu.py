@@ -221,3 +221,43 @@ def test_multiple_micro_batches(oracle_mod):
         n = min(64, len(x) - i)
         assert np.array_equal(y[i:i + n], y64[:n])
     util.assert_rows_match(y64[:8], oracle_mod.fa_forward(sd, base[:8], False), what="fa 24-col")
+
+
+def test_other_window_geometry(oracle_mod):
+    """depth-55 matrices (shared/param_f.py:11 matrix_depth_dict hifi/ilmn): (55,33)->(28,17)->(14,9)->(7,5); exercises
+    even-sized stride-2 stages, clipped Winograd edge tiles in both dimensions and the run-time pyramid-bin table
+    (top/bottom zero padding of the 3-bin level)."""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=101)
+    m = Clair3_F(add_indel_length=True, predict=True, input_channels=8)
+    m.set_geometry(55, 33)
+    m.keep_activations(True)
+    m.to("cuda:0")
+    m.load_state_dict(sd)
+    x = syn.make_fa_windows(5, seed=102, depth=55)
+    y = m.predict_numpy(x)
+    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+    for l in range(9):
+        a = m.debug_fetch(f"act{l}", d[f"act{l}"].shape)
+        scale = max(1.0, float(np.abs(d[f"act{l}"]).max()))
+        assert float(np.abs(a - d[f"act{l}"]).max()) / scale < 2e-5, f"layer {l}"
+    a = m.debug_fetch("spp", d["spp"].shape)
+    assert float(np.abs(a - d["spp"]).max()) < 2e-5 * max(1.0, float(np.abs(d["spp"]).max()))
+    util.assert_rows_match(y, y_o, what="depth-55 geometry")
+
+
+def test_two_handles_share_a_gpu():
+    """two model handles with the same weights (what bench.py --streams 2 and worker.predict_batches use) give the
+    same rows as one, whatever the interleaving"""
+    import torch
+    sd = syn.make_state_dict(syn.PILEUP, seed=111)
+    ms = [make_model(syn.PILEUP, 18, False, sd) for _ in range(2)]
+    xs = [torch.from_numpy(syn.make_pileup_windows(300, seed=112 + i)).cuda() for i in range(4)]
+    ref = [ms[0](x).cpu().numpy() for x in xs]
+    streams = [torch.cuda.Stream() for _ in ms]
+    outs = []
+    for i, x in enumerate(xs):
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append(ms[i % 2](x))
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        assert np.array_equal(o.cpu().numpy(), r)
