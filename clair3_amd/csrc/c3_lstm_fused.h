@@ -1,0 +1,126 @@
+// c3_lstm_fused.h -- first pileup LSTM layer with its input projection fused into the recurrence.
+//
+// LSTM1 reads only C = 18 counts per (window, position) (clair3/model.py:96-101, shared/param_p.py:32-36).  Hoisting
+// its x-projection into a GEMM, as the generic path does, writes and re-reads a (B*33) x 1024 fp32 tensor -- 135 KB
+// per window for 594 bytes of input, 276 MB of HBM traffic per 1024 windows and a 70 us write-bound launch.  Here the
+// projection rides in the recurrent kernel instead: K = 18 pads to 5 MFMA k-steps of 4, i.e. 20 extra
+// v_mfma_f32_16x16x4_f32 per step next to the 128 of the recurrence, W_ih fragments (20 VGPRs) and the bias stay in
+// registers, and the 5 counts each lane needs for the next step are fetched (as bytes) during the current one.
+// Everything else is lstm_recurrent_kernel<128, true>: wave w owns hidden units [16w, 16w+16) as four gate
+// accumulators, W_hh resident in 128 VGPRs, h_t exchanged through a double-buffered LDS tile, one LDS-only barrier
+// per step, cell state in registers.
+#pragma once
+#include "c3_kernels.h"
+
+namespace c3 {
+
+template <typename TX>
+struct LstmFusedParams {
+    const TX *x;        // [B][T][C] window counts
+    const float *wih;   // [dir][wave][gate][ks = 5][lane]: W_ih[gate*H + wave*16 + (lane&15)][4*ks + (lane>>4)], 0 beyond C
+    const float *bias;  // [dir][wave][gate][16]: b_ih + b_hh of row gate*H + wave*16 + u
+    const float *whh;   // [dir][wave][gate][q = H/16][lane][4]   (same packing as lstm_recurrent_kernel)
+    float *hout;        // [B][T][2H]; column = dir*H + unit
+    int B, T, C;
+};
+
+constexpr int kFusedKS = 5;  // k-steps of 4 covering C <= 20 input channels
+
+template <typename TX>
+__global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p) {
+    constexpr int H = 128, NW = 8, NQ = 8, LDH = H + 4;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][16][LDH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane >> 4, col = lane & 15;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * 16;
+
+    for (int i = tid; i < 16 * LDH; i += NW * 64) (&hbuf[0][0][0])[i] = 0.f;
+
+    // resident weights: W_hh fragments (128 VGPRs), W_ih fragments (20), bias (4)
+    const float *wbase = p.whh + ((int64_t)(dir * NW + wave) * 4 * NQ * 64 + lane) * 4;
+    f32x4v wres[4 * NQ];
+#pragma unroll
+    for (int i = 0; i < 4 * NQ; ++i) wres[i] = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)i * 256);
+    float wih[4][kFusedKS], bias[4];
+    {
+        const float *wi = p.wih + ((int64_t)(dir * NW + wave) * 4 * kFusedKS) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int ks = 0; ks < kFusedKS; ++ks) wih[g][ks] = wi[(g * kFusedKS + ks) * 64];
+            bias[g] = p.bias[((dir * NW + wave) * 4 + g) * 16 + col];
+        }
+    }
+
+    // A operand of the projection: lane (window = lane&15, s) supplies x[window][t][4*ks + s]
+    int xb = b0 + col;
+    if (xb >= p.B) xb = p.B - 1;
+    const TX *xrow = p.x + (int64_t)xb * p.T * p.C;
+    auto load_x = [&](int t, float (&xa)[kFusedKS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < kFusedKS; ++ks) {
+            const int k = 4 * ks + s;
+            const TX v = xrow[t * p.C + (k < p.C ? k : 0)];
+            xa[ks] = k < p.C ? (float)v : 0.f;
+        }
+    };
+
+    const int h_col = dir * H + wave * 16 + col;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    bool rowok[4];
+    int64_t rowbase[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        int b = b0 + 4 * s + v;
+        rowok[v] = b < p.B;
+        if (!rowok[v]) b = p.B - 1;
+        rowbase[v] = (int64_t)b * p.T;
+    }
+    float xn[kFusedKS];
+    load_x(dir ? p.T - 1 : 0, xn);
+    __syncthreads();
+
+    for (int step = 0; step < p.T; ++step) {
+        const int t = dir ? p.T - 1 - step : step;
+        const int cur = step & 1;
+        float xa[kFusedKS];
+#pragma unroll
+        for (int ks = 0; ks < kFusedKS; ++ks) xa[ks] = xn[ks];
+        if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1, xn);  // next step's counts: in flight during the MFMAs
+        f32x4v acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4v{bias[g], bias[g], bias[g], bias[g]};
+        // gates += x_t W_ih^T   (clair3/model.py:131-132: x.float() then LSTM1)
+#pragma unroll
+        for (int ks = 0; ks < kFusedKS; ++ks)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wih[g][ks], acc[g], 0, 0, 0);
+        if (step > 0) {  // gates += h_{t-1} W_hh^T, h_{-1} = 0
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wres[g * NQ + q][e], acc[g], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float ig = fast_sigmoid(acc[0][v]);
+            const float fg = fast_sigmoid(acc[1][v]);
+            const float gg = fast_tanh(acc[2][v]);
+            const float og = fast_sigmoid(acc[3][v]);
+            c[v] = fg * c[v] + ig * gg;
+            const float h = og * fast_tanh(c[v]);
+            hbuf[cur ^ 1][4 * s + v][wave * 16 + col] = h;
+            if (rowok[v]) p.hout[(rowbase[v] + t) * (2 * H) + h_col] = h;
+        }
+        lds_barrier();
+    }
+}
+
+}  // namespace c3

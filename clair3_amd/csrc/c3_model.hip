@@ -17,6 +17,7 @@
 #include "c3_gemm.h"
 #include "c3_kernels.h"
 #include "c3_wino.h"
+#include "c3_lstm_fused.h"
 
 using namespace c3;
 
@@ -92,6 +93,8 @@ struct c3_model {
     float *proj_w[2] = {nullptr, nullptr};  // [2*4H][Kp]
     float *proj_b[2] = {nullptr, nullptr};  // [2*4H]
     float *whh[2] = {nullptr, nullptr};     // fragment-packed W_hh
+    float *l1_wih = nullptr, *l1_bias = nullptr;  // LSTM1 input projection as MFMA fragments (fused kernel)
+    bool lstm1_fused = true;                // env C3HIP_LSTM1_FUSED=0 selects GEMM + recurrence
     // full alignment
     float *conv_w[9] = {};
     float *conv_b[9] = {};
@@ -361,6 +364,31 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
     TRY(upload(m, &m->proj_w[layer], pw));
     TRY(upload(m, &m->proj_b[layer], pb));
     TRY(upload(m, &m->whh[layer], wf));
+    if (layer == 0 && in <= 4 * kFusedKS) {
+        // fused kernel: W_ih as 16x16x4 B fragments [dir][wave][gate][ks][lane] = W_ih[g*H + w*16 + (lane&15)][4ks + (lane>>4)]
+        std::vector<float> fw((size_t)2 * NW * 4 * kFusedKS * 64, 0.f), fb((size_t)2 * NW * 4 * 16);
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = dir ? "_reverse" : "";
+            const float *wih, *bih, *bhh;
+            TRY(want(tm, base + ".weight_ih_l0" + sfx, {4 * H, in}, &wih));
+            TRY(want(tm, base + ".bias_ih_l0" + sfx, {4 * H}, &bih));
+            TRY(want(tm, base + ".bias_hh_l0" + sfx, {4 * H}, &bhh));
+            for (int w = 0; w < NW; ++w)
+                for (int g = 0; g < 4; ++g) {
+                    for (int u = 0; u < 16; ++u) {
+                        const int r = g * H + w * 16 + u;
+                        fb[(((size_t)dir * NW + w) * 4 + g) * 16 + u] = (float)((double)bih[r] + (double)bhh[r]);
+                    }
+                    for (int ks = 0; ks < kFusedKS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int r = g * H + w * 16 + (lane & 15), k = 4 * ks + (lane >> 4);
+                            if (k < in) fw[((((size_t)dir * NW + w) * 4 + g) * kFusedKS + ks) * 64 + lane] = wih[(size_t)r * in + k];
+                        }
+                }
+        }
+        TRY(upload(m, &m->l1_wih, fw));
+        TRY(upload(m, &m->l1_bias, fb));
+    }
     return 0;
 }
 
@@ -546,13 +574,20 @@ template <typename T>
 static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float *y) {
     const int Tn = m->positions;
     const int M = (int)(n * Tn);
-    {
+    const bool fused1 = m->lstm1_fused && m->l1_wih != nullptr;
+    if (fused1) {
+        ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
+        LstmFusedParams<T> lp{x, m->l1_wih, m->l1_bias, m->whh[0], m->h1, (int)n, Tn, m->C};
+        hipLaunchKernelGGL(lstm1_fused_kernel<T>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!fused1) {
         ProfScope ps(m, s, "p.proj1", 2.0 * M * 1024.0 * m->C, sizeof(T) * (double)M * m->C + 4.0 * M * 1024);
         IntRowLoaderParams<T> lp{x, m->C};
         EpilogueParams ep{m->gx1, m->proj_b[0], nullptr, 1024, 0};
         TRY((launch_gemm<IntRowLoader<4, T>, EPI_BIAS, 128, 128>(s, lp, m->proj_w[0], 32, M, 1024, 1, 1, ep)));
     }
-    {
+    if (!fused1) {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 2.0 * 512.0 * 128.0, 4.0 * M * (1024.0 + 256.0));
         LstmParams lp{m->gx1, m->whh[0], m->h1, (int)n, Tn, 1024};
         hipLaunchKernelGGL((lstm_recurrent_kernel<128, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
@@ -676,6 +711,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_WINOGRAD_V2MASK")) m->wino_v2_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_STAGGER")) m->wino_stagger = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
         c3_model_destroy(m);
@@ -838,7 +874,7 @@ int c3_model_destroy(c3_model *m) {
     (void)hipDeviceSynchronize();
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
-                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros};
+                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     for (int l = 0; l < 9; ++l) {
