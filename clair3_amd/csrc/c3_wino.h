@@ -143,10 +143,49 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][rb][v] = 0.f;
 
+    // input transform helpers: thread (tile, cin quad), two channels ("half") at a time
+    auto load_half = [&](f32x2 (&d)[4][4], int c, int half) __attribute__((always_inline)) {
+        const uint32_t choff = base + (uint32_t)(c * kWinoBK + 2 * half) * 4u;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
+                const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
+                if constexpr (ABL & 1) d[dy][dx] = f32x2{(float)off, 1.f};
+                else d[dy][dx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0));
+            }
+    };
+    auto col_pass = [&](f32x2 (&d)[4][4]) __attribute__((always_inline)) {  // t = B^T d (over rows)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const f32x2 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
+            d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
+        }
+    };
+    auto row_pass_store = [&](f32x2 (&d)[4][4], int half) __attribute__((always_inline)) {  // U = t B, xi = 4i + j
+        if constexpr (ABL & 2) {
+            asm volatile("" ::"v"(d[0][0]), "v"(d[1][1]), "v"(d[2][2]), "v"(d[3][3]));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
+            char *dst = ubuf + u_wr + 8 * half;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 0) * 4096) = t0 - t2;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 1) * 4096) = t1 + t2;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 2) * 4096) = t2 - t1;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 3) * 4096) = t1 - t3;
+        }
+    };
+
+    // channels 0-1 of the quad ("half 0") of the NEXT chunk are fetched during the MFMA phase of the current one,
+    // so each transform phase waits for only one batch of 16 loads instead of two back to back
+    f32x2 dpre[4][4];
+    load_half(dpre, 0, 0);
     for (int c = 0; c < nchunks; ++c) {
         // V fragments of this chunk, [xi][g]: the first two xi are fetched now (in flight during the transform),
-        // the other two after the barrier (in flight during the first 32 MFMAs) -- keeps 16 registers free
-        // while the patch is live
+        // the other two after the barrier (in flight during the first 32 MFMAs)
         f32x4 bf[4][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -155,42 +194,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
                 if constexpr (ABL & 4) bf[i][g] = f32x4{1.f, 2.f, 3.f, (float)c};
                 else bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
             }
-
-        // input transform of this thread's (tile, 4 channels): d -> B^T d B, two channels at a time (16 x 8-byte
-        // loads per half keep the live patch at 32 registers next to the 128 accumulators)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x2 d[4][4];
-            const uint32_t choff = base + (uint32_t)(c * kWinoBK + 2 * half) * 4u;
-#pragma unroll
-            for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 4; ++dx) {
-                    const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
-                    const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
-                    if constexpr (ABL & 1) d[dy][dx] = f32x2{(float)off, 1.f};
-                    else d[dy][dx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0));
-                }
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {  // t = B^T d (over rows)
-                const f32x2 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
-                d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
-            }
-            if (half == 0 && c > 0) __syncthreads();  // every wave finished reading the previous chunk's U
-            if constexpr (ABL & 2) {
-                asm volatile("" ::"v"(d[0][0]), "v"(d[1][1]), "v"(d[2][2]), "v"(d[3][3]));
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {  // U = t B (over columns), xi = 4i + j
-                const f32x2 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
-                char *dst = ubuf + u_wr + 8 * half;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 0) * 4096) = t0 - t2;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 1) * 4096) = t1 + t2;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 2) * 4096) = t2 - t1;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 3) * 4096) = t1 - t3;
-            }
-        }
+        f32x2 d1[4][4];
+        load_half(d1, c, 1);
+        col_pass(dpre);
+        if (c > 0) __syncthreads();  // every wave finished reading the previous chunk's U
+        row_pass_store(dpre, 0);
+        col_pass(d1);
+        row_pass_store(d1, 1);
         __syncthreads();
 #pragma unroll
         for (int i = 2; i < 4; ++i)
@@ -199,6 +209,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
                 if constexpr (ABL & 4) bf[i][g] = f32x4{1.f, 2.f, 3.f, (float)c};
                 else bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
             }
+        load_half(dpre, c + 1 < nchunks ? c + 1 : c, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (ABL & 16) {
             asm volatile("" ::"v"(bf[0][0]), "v"(bf[1][1]), "v"(bf[2][0]), "v"(bf[3][1]));
             continue;
