@@ -6,6 +6,9 @@
 // projection rides in the recurrent kernel instead: K = 18 pads to 5 MFMA k-steps of 4, i.e. 20 extra
 // v_mfma_f32_16x16x4_f32 per step next to the 128 of the recurrence, W_ih fragments (20 VGPRs) and the bias stay in
 // registers, and the 5 counts each lane needs for the next step are fetched (as bytes) during the current one.
+// With `starts` the kernel gathers its windows straight out of a region-wide pileup matrix: the
+// reference slices 33 overlapping columns per candidate on the host (preprocess/CreateTensorPileupFromCffi.py:
+// 362-371), a 16x duplication that never has to exist on the device.
 // Everything else is lstm_recurrent_kernel<128, true>: wave w owns hidden units [16w, 16w+16) as four gate
 // accumulators, W_hh resident in 128 VGPRs, h_t exchanged through a double-buffered LDS tile, one LDS-only barrier
 // per step, cell state in registers.
@@ -16,7 +19,8 @@ namespace c3 {
 
 template <typename TX>
 struct LstmFusedParams {
-    const TX *x;        // [B][T][C] window counts
+    const TX *x;        // [B][T][C] window counts, or -- with `starts` -- one [n_cols][C] region matrix
+    const int32_t *starts;  // optional [B]: first region column of each window (window b = columns starts[b] .. +T-1)
     const float *wih;   // [dir][wave][gate][ks = 5][lane]: W_ih[gate*H + wave*16 + (lane&15)][4*ks + (lane>>4)], 0 beyond C
     const float *bias;  // [dir][wave][gate][16]: b_ih + b_hh of row gate*H + wave*16 + u
     const float *whh;   // [dir][wave][gate][q = H/16][lane][4]   (same packing as lstm_recurrent_kernel)
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
     // A operand of the projection: lane (window = lane&15, s) supplies x[window][t][4*ks + s]
     int xb = b0 + col;
     if (xb >= p.B) xb = p.B - 1;
-    const TX *xrow = p.x + (int64_t)xb * p.T * p.C;
+    const TX *xrow = p.starts ? p.x + (int64_t)p.starts[xb] * p.C : p.x + (int64_t)xb * p.T * p.C;
     auto load_x = [&](int t, float (&xa)[kFusedKS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < kFusedKS; ++ks) {

@@ -571,13 +571,14 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
 }
 
 template <typename T>
-static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float *y) {
+static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float *y, const int32_t *starts = nullptr) {
     const int Tn = m->positions;
     const int M = (int)(n * Tn);
     const bool fused1 = m->lstm1_fused && m->l1_wih != nullptr;
+    if (starts && !fused1) return fail("region gathering needs the fused LSTM1 kernel (input_channels <= 20, C3HIP_LSTM1_FUSED != 0)");
     if (fused1) {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
-        LstmFusedParams<T> lp{x, m->l1_wih, m->l1_bias, m->whh[0], m->h1, (int)n, Tn, m->C};
+        LstmFusedParams<T> lp{x, starts, m->l1_wih, m->l1_bias, m->whh[0], m->h1, (int)n, Tn, m->C};
         hipLaunchKernelGGL(lstm1_fused_kernel<T>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
         HIP_TRY(hipGetLastError());
     }
@@ -613,7 +614,8 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     return run_tail(m, s, m->h2, m->K4, n, y, "p.l4", "p.tail");
 }
 
-static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype, int64_t batch, float *y) {
+static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype, int64_t batch, float *y,
+                          const int32_t *starts = nullptr) {
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
     if (batch < 0) return fail("negative batch");
     if (batch == 0) return 0;
@@ -625,14 +627,15 @@ static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype
     const int64_t wbytes = c3_model_window_bytes(m, x_dtype);
     for (int64_t off = 0; off < batch; off += m->cap) {
         const int64_t n = std::min<int64_t>(m->cap, batch - off);
-        const char *xp = (const char *)x + off * wbytes;
+        const char *xp = starts ? (const char *)x : (const char *)x + off * wbytes;  // region matrix is shared
+        const int32_t *sp = starts ? starts + off : nullptr;
         float *yp = y + off * m->nout;
         if (m->kind == C3_KIND_FULL_ALIGNMENT)
             TRY(run_fa(m, s, (const int8_t *)xp, n, yp));
         else if (x_dtype == C3_DTYPE_I8)
-            TRY(run_pileup_t<int8_t>(m, s, (const int8_t *)xp, n, yp));
+            TRY(run_pileup_t<int8_t>(m, s, (const int8_t *)xp, n, yp, sp));
         else
-            TRY(run_pileup_t<int32_t>(m, s, (const int32_t *)xp, n, yp));
+            TRY(run_pileup_t<int32_t>(m, s, (const int32_t *)xp, n, yp, sp));
         m->last_n = n;
     }
     return 0;
@@ -786,7 +789,10 @@ int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch
     if (!m) return fail("null model");
     if (batch > 0 && (!x_dev || !y_dev)) return fail("null buffer");
     HIP_TRY(hipSetDevice(m->device));
-    return forward_device(m, stream ? (hipStream_t)stream : m->stream, x_dev, x_dtype, batch, y_dev);
+    // NULL is the HIP null stream itself (what torch's default stream is): work queued there is ordered with the
+    // caller's other default-stream work.  Mapping NULL to the model's private non-blocking stream would let a
+    // following torch op (y.cpu(), an RCCL gather) overtake the kernels.
+    return forward_device(m, (hipStream_t)stream, x_dev, x_dtype, batch, y_dev);
 }
 
 static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
@@ -860,6 +866,36 @@ int c3_predict_wait(c3_model *m, int slot) {
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host) {
     TRY(c3_predict_submit(m, x_host, x_dtype, batch, y_host, 0));
     return c3_predict_wait(m, 0);
+}
+
+int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, int64_t n_cols, const int32_t *starts_host,
+                             int64_t batch, float *y_host) {
+    if (!m) return fail("null model");
+    if (m->kind != C3_KIND_PILEUP) return fail("c3_predict_pileup_region needs a pileup model");
+    if (batch < 0 || n_cols < 0) return fail("negative size");
+    if (batch == 0) return 0;
+    if (!region_host || !starts_host || !y_host) return fail("null buffer");
+    if (x_dtype != C3_DTYPE_I8 && x_dtype != C3_DTYPE_I32) return fail("pileup regions must be int8 or int32");
+    for (int64_t i = 0; i < batch; ++i)
+        if (starts_host[i] < 0 || (int64_t)starts_host[i] + m->positions > n_cols)
+            return fail("window %lld starts at column %d: outside the %lld-column region", (long long)i, starts_host[i], (long long)n_cols);
+    HostSlot &sl = m->slot[0];
+    if (sl.busy) return fail("slot 0 still in flight: call c3_predict_wait first");
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->loaded) return fail("model has no weights: call c3_model_load first");
+    const size_t item = x_dtype == C3_DTYPE_I32 ? 4 : 1;
+    const size_t rb = ((size_t)n_cols * m->C * item + 255) & ~(size_t)255;
+    const size_t sb = (size_t)batch * sizeof(int32_t);
+    const size_t yb = (size_t)batch * m->nout * sizeof(float);
+    TRY(ensure_slot(m, sl, rb + sb, yb));
+    memcpy(sl.pin_x, region_host, (size_t)n_cols * m->C * item);
+    memcpy((char *)sl.pin_x + rb, starts_host, sb);
+    HIP_TRY(hipMemcpyAsync(sl.dev_x, sl.pin_x, rb + sb, hipMemcpyHostToDevice, m->stream));
+    TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y, (const int32_t *)((char *)sl.dev_x + rb)));
+    HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    memcpy(y_host, sl.pin_y, yb);
+    return 0;
 }
 
 int c3_model_synchronize(c3_model *m) {

@@ -236,6 +236,21 @@ class Clair3_P(_HipModel):
     KIND = _lib.KIND_PILEUP
     DEFAULT_CHANNELS = 18  # shared/param_p.py:32-36
 
+    def predict_region(self, region, starts):
+        """Rows for the windows region[starts[b] : starts[b] + 33] without materialising them: ``region`` is the
+        (n_cols, 18) matrix of one pileup region, ``starts`` the per-candidate offsets the reference slices at
+        (preprocess/CreateTensorPileupFromCffi.py:362-364).  Same rows, bit for bit, as predict_numpy on the slices."""
+        region = np.ascontiguousarray(region)
+        dt = _NP_DTYPE.get(region.dtype)
+        if dt is None or region.ndim != 2 or region.shape[1] != self.input_channels:
+            raise _lib.C3Error(f"region must be (n_cols, {self.input_channels}) int8/int32, got {region.dtype} {region.shape}")
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        y = np.empty((len(starts), self.output_size), dtype=np.float32)
+        _lib.check(_lib.lib().c3_predict_pileup_region(self._handle, region.ctypes.data, dt, region.shape[0],
+                                                       starts.ctypes.data, len(starts), y.ctypes.data),
+                   "c3_predict_pileup_region")
+        return y
+
 
 class Clair3_F(_HipModel):
     """Full-alignment network: residual 3x3-conv stack + pyramid pooling + FC heads (clair3/model.py:282-416)."""

@@ -92,8 +92,17 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);
 int c3_predict_wait(c3_model *m, int slot);
 /* device-resident forward: x_dev / y_dev are device pointers on the model's device, stream is a
- * hipStream_t (NULL = the model's own stream).  Asynchronous with respect to the host. */
+ * hipStream_t (NULL = the HIP null stream, i.e. PyTorch's default stream).  Asynchronous with respect to the
+ * host; ordered like any other work on that stream.  Calls on one handle must not overlap each other (one
+ * workspace per handle): keep several batches in flight with several handles. */
 int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, void *stream);
+/* Pileup only: windows gathered on the device out of ONE region matrix instead of `batch` pre-sliced
+ * copies.  region_host: (n_cols, C) int8|int32 counts exactly as calculate_clair3_pileup returns them for a region
+ * (src/clair3_pileup.h:113; preprocess/CreateTensorPileupFromCffi.py:143-146); starts_host[b] = first column of window
+ * b, i.e. the `offset` the reference slices at (CreateTensorPileupFromCffi.py:362-364: result[0][offset:offset+33]).
+ * Equivalent to c3_predict on the sliced windows, bit for bit; candidate filtering stays with the caller. */
+int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, int64_t n_cols, const int32_t *starts_host,
+                             int64_t batch, float *y_host);
 /* blocks until everything enqueued on the model's own stream has finished */
 int c3_model_synchronize(c3_model *m);
 int c3_model_destroy(c3_model *m);

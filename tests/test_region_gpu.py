@@ -1,0 +1,28 @@
+"""On-device pileup window gathering against explicit host slicing."""
+import numpy as np
+import pytest
+
+from clair3_amd import _lib, synthetic as syn
+from clair3_amd.model import Clair3_P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int32])
+def test_region_gather_equals_sliced_windows(dtype):
+    sd = syn.make_state_dict(syn.PILEUP, seed=201)
+    m = Clair3_P(predict=True).to("cuda:0")
+    m.load_state_dict(sd)
+    rng = np.random.default_rng(202)
+    n_cols = 5000
+    # a region-wide matrix as calculate_clair3_pileup returns it: one row of 18 counts per reference position
+    region = syn.make_pileup_windows(n_cols // 33 + 1, seed=203, dtype=dtype).reshape(-1, 18)[:n_cols]
+    starts = np.sort(rng.choice(n_cols - 33, size=700, replace=False)).astype(np.int32)
+    starts[:3] = [0, 1, n_cols - 33]  # both ends and overlapping neighbours
+    windows = np.stack([region[s:s + 33] for s in starts])  # the reference's host-side slicing (:362-364)
+    y_ref = m.predict_numpy(windows)
+    y = m.predict_region(region, starts)
+    assert np.array_equal(y, y_ref)
+    with pytest.raises(_lib.C3Error, match="outside"):
+        m.predict_region(region, np.array([n_cols - 32], np.int32))
+    assert m.predict_region(region, np.zeros(0, np.int32)).shape == (0, 24)
