@@ -105,6 +105,7 @@ struct c3_model {
     // transform is recomputed for each of 8 N-tiles).  v2 (one workgroup per CU, transform interleaved into the MFMA
     // stream) is 10-15 % slower than v1 on res1/res2 and equal on res3; it stays selectable for experiments.
     unsigned wino_v2_mask = 0;      // layers whose Winograd launch uses kernel v2 (experimental); env C3HIP_WINOGRAD_V2MASK
+    unsigned wino_n64_mask = 0x1b6; // layers using the 32-tile x 64-cout workgroup shape; env C3HIP_WINOGRAD_N64MASK
     bool lstm2_v2 = true;        // env C3HIP_LSTM2_V2=0 selects the streaming 10-wave kernel
     int wino_stagger = 0;        // env C3HIP_WINOGRAD_STAGGER (units of 64 clocks)
     unsigned wino_mask = 0x1b6;  // layers run as Winograd (bit l): all six stride-1 convs; env C3HIP_WINOGRAD overrides
@@ -498,7 +499,13 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             wp.th = (hh[l] + 1) / 2, wp.tw = (ww[l] + 1) / 2, wp.P = (int)n * wp.th * wp.tw;
             wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
             wp.stagger = m->wino_stagger;
-            if (!(m->wino_v2_mask & (1u << l))) {
+            if ((m->wino_n64_mask & (1u << l)) && Cout % 64 == 0) {  // 32 tiles x 64 couts per workgroup
+                wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
+                if (wp.res)
+                    hipLaunchKernelGGL(wino_conv_kernel_n64<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
+                else
+                    hipLaunchKernelGGL(wino_conv_kernel_n64<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
+            } else if (!(m->wino_v2_mask & (1u << l))) {
                 if (wp.res)
                     hipLaunchKernelGGL(wino_conv_kernel<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
                 else
@@ -712,6 +719,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_V2MASK")) m->wino_v2_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_WINOGRAD_N64MASK")) m->wino_n64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_STAGGER")) m->wino_stagger = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;

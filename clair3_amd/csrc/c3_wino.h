@@ -282,6 +282,162 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------------
+// 32 tiles x 64 couts per workgroup: the shape for the wide (128/256-channel) blocks.  With 32-cout workgroups the
+// 256-channel block recomputes its input transform for 8 N-tiles; here it is 4, each transform phase handles half as
+// many tiles with all 256 threads (thread = tile, cin quad, channel pair), and every A fragment feeds two column
+// blocks.  Accumulators are the same 128 registers (4 xi x 1 row block x 2 column blocks).
+template <bool RES>
+__global__ __launch_bounds__(256, 2) void wino_conv_kernel_n64(WinoParams p) {
+    constexpr int PT = 32, NT = 64;
+    __shared__ __attribute__((aligned(16))) char ubuf[65536];  // U: [16][32][16] floats (32 KiB); epilogue [16][32][32] (64 KiB)
+    __shared__ int2 tcoord[PT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_tile_index(blockIdx.x, p.tiles);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int p0 = tm * PT, n0 = tn * NT;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x), 0, p.B * p.H * p.W * p.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(RES ? p.res : p.out), 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
+
+    // ---- transform role: thread (tile, cin quad, channel pair)
+    const int tl = tid >> 3, q = (tid >> 1) & 3, half = tid & 1;
+    uint32_t base, okmask = 0;
+    {
+        int pp = p0 + tl;
+        const bool valid = pp < p.P;
+        if (!valid) pp = p.P - 1;
+        const int tpw = p.th * p.tw;
+        const int b = pp / tpw, r = pp - b * tpw;
+        const int ty = r / p.tw, tx = r - ty * p.tw;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        base = (uint32_t)(((((int64_t)b * p.H + iy0) * p.W + ix0) * p.Cin + q * 4 + half * 2) * 4);
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx)
+                if (iy0 + dy >= 0 && iy0 + dy < p.H && ix0 + dx >= 0 && ix0 + dx < p.W) okmask |= 1u << (dy * 4 + dx);
+        if ((tid & 7) == 0)
+            tcoord[tl] = make_int2((int)((((int64_t)b * p.H + 2 * ty) * p.W + 2 * tx) * p.Cout * 4),
+                                   (valid ? 1 : 0) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 4 : 0));
+    }
+    constexpr int kPlane = PT * 64;  // bytes of one xi plane of U
+    const int u_wr = tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4) + 8 * half;
+
+    // ---- MFMA role: wave owns xi = 4*wave .. 4*wave+3, one row block (32 tiles) x two column blocks (64 couts)
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int a_rd = frow * 64, a_sw = (frow >> 2) & 3;
+    const int nchunks = p.Cin / kWinoBK;
+    const float *vbase0 = p.v + ((int64_t)((tn * 2 + 0) * 16 + wave * 4) * nchunks * 2 * 64 + lane) * 4;
+    const float *vbase1 = p.v + ((int64_t)((tn * 2 + 1) * 16 + wave * 4) * nchunks * 2 * 64 + lane) * 4;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][cb][v] = 0.f;
+
+    auto load_patch = [&](f32x2 (&d)[4][4], int c) __attribute__((always_inline)) {
+        const uint32_t choff = base + (uint32_t)(c * kWinoBK) * 4u;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
+                const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
+                d[dy][dx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0));
+            }
+    };
+    auto load_v = [&](f32x4 (&bf)[2][2], int i, int c) __attribute__((always_inline)) {  // [cb][g] of xi i
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf[0][g] = *reinterpret_cast<const f32x4 *>(vbase0 + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
+            bf[1][g] = *reinterpret_cast<const f32x4 *>(vbase1 + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
+        }
+    };
+
+    f32x2 d[4][4];
+    load_patch(d, 0);
+    for (int c = 0; c < nchunks; ++c) {
+        f32x4 bf[4][2][2];
+        load_v(bf[0], 0, c);
+        load_v(bf[1], 1, c);
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {  // t = B^T d
+            const f32x2 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
+            d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
+        }
+        if (c > 0) __syncthreads();  // every wave finished reading the previous chunk's U
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // U = t B, xi = 4i + j
+            const f32x2 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
+            char *dst = ubuf + u_wr;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 0) * kPlane) = t0 - t2;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 1) * kPlane) = t1 + t2;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 2) * kPlane) = t2 - t1;
+            *reinterpret_cast<f32x2 *>(dst + (4 * i + 3) * kPlane) = t1 - t3;
+        }
+        __syncthreads();
+        load_v(bf[2], 2, c);
+        load_v(bf[3], 3, c);
+        load_patch(d, c + 1 < nchunks ? c + 1 : c);  // next chunk's patch flies during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char *plane = ubuf + (wave * 4 + i) * kPlane;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(plane + a_rd + (((2 * g + fhi) ^ a_sw) << 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[i][0][g][j], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[i][1][g][j], acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: one pass per column block (32 couts): exchange M_xi through LDS, A^T M A, bias (+res), ReLU, store
+    float *mbuf = reinterpret_cast<float *>(ubuf);  // [16 xi][32 tiles][32 couts]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        {
+            const int c32 = lane & 31;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int t = (v & 3) + 8 * (v >> 2) + 4 * fhi;
+                    mbuf[((wave * 4 + i) * PT + t) * 32 + c32] = acc[i][h][v];
+                }
+        }
+        __syncthreads();
+        {
+            const int cq = tid & 7, t = tid >> 3;
+            const int2 tc = tcoord[t];
+            f32x4 m[4][4];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+                m[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4 *>(&mbuf[(xi * PT + t) * 32 + 4 * cq]);
+            f32x4 s4[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s4[0][j] = m[0][j] + m[1][j] + m[2][j];
+                s4[1][j] = m[1][j] - m[2][j] - m[3][j];
+            }
+            const int n = n0 + 32 * h + 4 * cq;
+            wino_store4<RES>(s4, tc, n, *reinterpret_cast<const f32x4 *>(p.bias + n), orsrc, rrsrc, p.W * p.Cout * 4, p.Cout * 4);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // Version 2: one workgroup per CU (4 waves, one per SIMD, the whole 512-entry register file each), the
 // input transform software-pipelined INTO the MFMA stream instead of relying on a second workgroup:
 //   body(c):  issue the 16 patch loads of chunk c+2 and the V fragments of chunk c+1      (2 register stages)

@@ -15,12 +15,12 @@ for s in $STAGES; do
     prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err"); echo "prof rc=$?"; find gpurun_out/prof -name '*stats*' | head ;;
     pmc)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_fetch.err"); echo "pmc fetch rc=$?"
            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OLDPWD/gpurun_out/pmc_write" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_write.err"); echo "pmc write rc=$?" ;;
-    benchfa) for cfg in "0x36 0" "0x1b6 0" "0x1b6 0x180" "0x1b6 0x1b6"; do set -- $cfg; mask=$1; export C3HIP_WINOGRAD_V2MASK=$2; echo "== C3HIP_WINOGRAD=$mask v2mask=$2"; C3HIP_WINOGRAD=$mask timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline 2> gpurun_out/benchfa.err | python -c "
+    benchfa) for cfg in "0x1b6 0" "0x1b6 0x180" "0x1b6 0x1b0" "0x1b6 0x1b6"; do set -- $cfg; mask=$1; export C3HIP_WINOGRAD_N64MASK=$2; echo "== C3HIP_WINOGRAD=$mask n64mask=$2"; C3HIP_WINOGRAD=$mask timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchfa.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']))
 for k,v in d['kernels'].items(): print('   %-9s %7.1f us %6.1f TF' % (k, v['avg_us'], v['tflops'] or 0))
-"; done; unset C3HIP_WINOGRAD_V2MASK ;;
+"; done; unset C3HIP_WINOGRAD_N64MASK ;;
     stagger) for st in 0 -64 -128 -192 64; do echo "== stagger=$st"; C3HIP_WINOGRAD_STAGGER=$st timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline 2> gpurun_out/benchfa.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
