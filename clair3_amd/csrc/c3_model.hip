@@ -17,6 +17,7 @@
 #include "c3_gemm.h"
 #include "c3_kernels.h"
 #include "c3_wino.h"
+#include "c3_wino_p.h"
 #include "c3_lstm_fused.h"
 
 using namespace c3;
@@ -104,6 +105,8 @@ struct c3_model {
     // 110/113 us, res3 171/179 -> 162/164 us (res3 gains little: 18 tiles per window quantise badly and its input
     // transform is recomputed for each of 8 N-tiles).  v2 (one workgroup per CU, transform interleaved into the MFMA
     // stream) is 10-15 % slower than v1 on res1/res2 and equal on res3; it stays selectable for experiments.
+    unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
+    int wg_slots = 512;             // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
     unsigned wino_v2_mask = 0;      // layers whose Winograd launch uses kernel v2 (experimental); env C3HIP_WINOGRAD_V2MASK
     unsigned wino_n64_mask = 0x1b6; // layers using the 32-tile x 64-cout workgroup shape; env C3HIP_WINOGRAD_N64MASK
     bool lstm2_v2 = true;        // env C3HIP_LSTM2_V2=0 selects the streaming 10-wave kernel
@@ -499,7 +502,14 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             wp.th = (hh[l] + 1) / 2, wp.tw = (ww[l] + 1) / 2, wp.P = (int)n * wp.th * wp.tw;
             wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
             wp.stagger = m->wino_stagger;
-            if ((m->wino_n64_mask & (1u << l)) && Cout % 64 == 0) {  // 32 tiles x 64 couts per workgroup
+            if ((m->wino_p_mask & (1u << l)) && Cout % 64 == 0) {  // persistent 32 x 64 workgroups
+                wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
+                const int grid = std::min(wp.tiles, m->wg_slots / wp.tiles_n * wp.tiles_n);
+                if (wp.res)
+                    hipLaunchKernelGGL(wino_conv_kernel_p<true>, dim3(grid), dim3(256), 0, s, wp);
+                else
+                    hipLaunchKernelGGL(wino_conv_kernel_p<false>, dim3(grid), dim3(256), 0, s, wp);
+            } else if ((m->wino_n64_mask & (1u << l)) && Cout % 64 == 0) {  // 32 tiles x 64 couts per workgroup
                 wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
                 if (wp.res)
                     hipLaunchKernelGGL(wino_conv_kernel_n64<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
@@ -718,6 +728,12 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     }
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_WINOGRAD_PMASK")) m->wino_p_mask = (unsigned)strtoul(e, nullptr, 0);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            m->wg_slots = 2 * prop.multiProcessorCount;
+    }
     if (const char *e = getenv("C3HIP_WINOGRAD_V2MASK")) m->wino_v2_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_N64MASK")) m->wino_n64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_STAGGER")) m->wino_stagger = atoi(e);

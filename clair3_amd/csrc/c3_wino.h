@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
 // 256-channel block recomputes its input transform for 8 N-tiles; here it is 4, each transform phase handles half as
 // many tiles with all 256 threads (thread = tile, cin quad, channel pair), and every A fragment feeds two column
 // blocks.  Accumulators are the same 128 registers (4 xi x 1 row block x 2 column blocks).
-template <bool RES>
+template <bool RES, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel_n64(WinoParams p) {
     constexpr int PT = 32, NT = 64;
     __shared__ __attribute__((aligned(16))) char ubuf[65536];  // U: [16][32][16] floats (32 KiB); epilogue [16][32][32] (64 KiB)
@@ -350,12 +350,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_n64(WinoParams p) {
             for (int dx = 0; dx < 4; ++dx) {
                 const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
                 const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
-                d[dy][dx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0));
+                if constexpr (ABL & 1) d[dy][dx] = f32x2{(float)off, 1.f};
+                else d[dy][dx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0));
             }
     };
     auto load_v = [&](f32x4 (&bf)[2][2], int i, int c) __attribute__((always_inline)) {  // [cb][g] of xi i
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+            if constexpr (ABL & 4) {
+                bf[0][g] = f32x4{1.f, 2.f, 3.f, (float)c}, bf[1][g] = f32x4{3.f, 2.f, 1.f, (float)i};
+                continue;
+            }
             bf[0][g] = *reinterpret_cast<const f32x4 *>(vbase0 + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
             bf[1][g] = *reinterpret_cast<const f32x4 *>(vbase1 + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
         }
@@ -373,8 +378,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_n64(WinoParams p) {
             d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
         }
         if (c > 0) __syncthreads();  // every wave finished reading the previous chunk's U
+        if constexpr (ABL & 2) asm volatile("" ::"v"(d[0][0]), "v"(d[1][1]), "v"(d[2][2]), "v"(d[3][3]));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // U = t B, xi = 4i + j
+        for (int i = 0; i < (ABL & 2 ? 0 : 4); ++i) {  // U = t B, xi = 4i + j
             const f32x2 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
             char *dst = ubuf + u_wr;
             *reinterpret_cast<f32x2 *>(dst + (4 * i + 0) * kPlane) = t0 - t2;
@@ -387,6 +393,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_n64(WinoParams p) {
         load_v(bf[3], 3, c);
         load_patch(d, c + 1 < nchunks ? c + 1 : c);  // next chunk's patch flies during the MFMAs
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ABL & 16) {
+            asm volatile("" ::"v"(bf[0][0][0]), "v"(bf[1][1][1]), "v"(bf[2][0][0]), "v"(bf[3][1][1]));
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const char *plane = ubuf + (wave * 4 + i) * kPlane;
@@ -404,6 +414,15 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_n64(WinoParams p) {
 
     // ---- epilogue: one pass per column block (32 couts): exchange M_xi through LDS, A^T M A, bias (+res), ReLU, store
     float *mbuf = reinterpret_cast<float *>(ubuf);  // [16 xi][32 tiles][32 couts]
+    if constexpr (ABL & 8) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) sacc += acc[i][0][v] + acc[i][1][v];
+        if (sacc == 12345.678f) p.out[tid] = sacc;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
