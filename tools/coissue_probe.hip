@@ -76,6 +76,55 @@ static float time_it(K launch, int reps = 5) {
     float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms / reps * 1e3f;
 }
 
+// Intra-wave interleave: K instructions of one class after every MFMA of a back-to-back stream (256-thread workgroups,
+// one wave per SIMD).  CLASS: 0 none, 1 v_add_f32, 2 v_pk_add_f32, 3 ds_read_b128, 4 buffer_load_dwordx4 (L2 hits),
+// 5 s_add_u32 (SALU), 6 ds_write_b64, 7 v_cndmask+v_add (address-select idiom)
+template <int CLASS, int K>
+__global__ __launch_bounds__(256) void intra(float *out, const float *src, int iters) {
+    __shared__ float lds[8192];
+    const int tid = threadIdx.x;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    float a = tid * 1e-3f, b = blockIdx.x * 1e-3f;
+    float x0 = a, x1 = b;
+    f32x2 y0 = {a, b}, y1 = {b, a};
+    f32x4 l = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+    unsigned sacc = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, 1 << 20, 0x00020000);
+    lds[tid] = a; lds[tid + 256] = b;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if constexpr (CLASS == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(x1));
+                    if constexpr (CLASS == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y0) : "v"(y1));
+                    if constexpr (CLASS == 3) { f32x4 t = *reinterpret_cast<f32x4 *>(&lds[(tid * 4 + k * 1024 + i * 64) & 8191]); l += t; }
+                    if constexpr (CLASS == 4) g += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(tid * 16 + ((i * 4 + k) & 63) * 4096), 0, 0));
+                    if constexpr (CLASS == 5) asm volatile("s_add_u32 %0, %0, 7" : "+s"(sacc));
+                    if constexpr (CLASS == 6) *reinterpret_cast<f32x2 *>(&lds[(tid * 2 + k * 512 + i * 32) & 8191]) = y0;
+                    if constexpr (CLASS == 7) { asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(x1), "v"(a) : "vcc"); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    }
+    float res = x0 + y0[0] + y0[1] + l[0] + l[1] + l[2] + l[3] + g[0] + g[1] + g[2] + g[3] + (float)sacc;
+    for (int i = 0; i < 8; ++i) for (int v = 0; v < 16; ++v) res += acc[i][v];
+    if (res == 12345.678f) out[blockIdx.x * 256 + tid] = res;
+}
+template <int CLASS, int K>
+static void run_intra(const char *name, float *out, const float *src, float base) {
+    const int iters = 2000;
+    float t = time_it([&] { hipLaunchKernelGGL((intra<CLASS, K>), dim3(256), dim3(256), 0, 0, out, src, iters); });
+    const double per = (t - base) * 1e-6 * 2.4e9 / (iters * 16.0 * (K ? K : 1));
+    printf("intra-wave: %-28s x%d per MFMA: %8.1f us  (+%.1f cycles per inserted instruction; MFMA-only %.1f us)\n", name, K, t, K ? per : 0.0, base);
+}
+
 template <int PART, int ACC, int NOPS = 0, int NACC = 8>
 static void run(const char *name, float *out, const float *src, int nwork) {
     const int iters = 2000;
@@ -95,16 +144,24 @@ int main() {
     (void)hipMalloc(&out, 256 * 512 * 4);
     (void)hipMalloc(&src, 1 << 20);
     (void)hipMemset(src, 0, 1 << 20);
+    {
+        float base = time_it([&] { hipLaunchKernelGGL((intra<0, 0>), dim3(256), dim3(256), 0, 0, out, src, 2000); });
+        run_intra<0, 0>("nothing", out, src, base);
+        run_intra<1, 1>("v_add_f32", out, src, base);
+        run_intra<1, 4>("v_add_f32", out, src, base);
+        run_intra<1, 12>("v_add_f32", out, src, base);
+        run_intra<2, 1>("v_pk_add_f32", out, src, base);
+        run_intra<2, 4>("v_pk_add_f32", out, src, base);
+        run_intra<3, 1>("ds_read_b128", out, src, base);
+        run_intra<3, 2>("ds_read_b128", out, src, base);
+        run_intra<4, 1>("buffer_load_dwordx4", out, src, base);
+        run_intra<4, 2>("buffer_load_dwordx4", out, src, base);
+        run_intra<5, 4>("s_add_u32", out, src, base);
+        run_intra<5, 12>("s_add_u32", out, src, base);
+        run_intra<6, 1>("ds_write_b64", out, src, base);
+        run_intra<6, 2>("ds_write_b64", out, src, base);
+        run_intra<7, 2>("v_cmp+v_cndmask", out, src, base);
+    }
     run<0, 0, 0, 8>("VALU", out, src, 8);
-    run<0, 0, 8, 8>("VALU", out, src, 8);
-    run<0, 0, 10, 8>("VALU", out, src, 8);
-    run<0, 0, 12, 8>("VALU", out, src, 8);
-    run<0, 0, 13, 8>("VALU", out, src, 8);
-    run<0, 0, 14, 8>("VALU", out, src, 8);
-    run<0, 0, 15, 8>("VALU", out, src, 8);
-    run<0, 0, 16, 8>("VALU", out, src, 8);
-    run<3, 0, 12, 8>("mix", out, src, 2);
-    run<3, 0, 14, 8>("mix", out, src, 2);
-    run<3, 0, 15, 8>("mix", out, src, 2);
     return 0;
 }

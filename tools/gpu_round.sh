@@ -15,7 +15,7 @@ for s in $STAGES; do
     prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err"); echo "prof rc=$?"; find gpurun_out/prof -name '*stats*' | head ;;
     pmc)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_fetch.err"); echo "pmc fetch rc=$?"
            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OLDPWD/gpurun_out/pmc_write" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --workload full_alignment > /dev/null 2> "$OLDPWD/gpurun_out/pmc_write.err"); echo "pmc write rc=$?" ;;
-    benchfa) for cfg in "0x1b6 0" "0x1b6 0x1b6" "0x1b6 0x36" "0x1b6 0x180"; do set -- $cfg; mask=$1; export C3HIP_WINOGRAD_PMASK=$2; echo "== C3HIP_WINOGRAD=$mask pmask=$2"; C3HIP_WINOGRAD=$mask timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchfa.err | python -c "
+    benchfa) for cfg in "0x1b6 0" "0x1b6 0x1b6"; do set -- $cfg; mask=$1; export C3HIP_WINOGRAD_PMASK=$2; echo "== C3HIP_WINOGRAD=$mask qmask=$2"; C3HIP_WINOGRAD=$mask timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchfa.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']))
@@ -23,6 +23,7 @@ for k,v in d['kernels'].items(): print('   %-9s %7.1f us %6.1f TF' % (k, v['avg_
 "; done; unset C3HIP_WINOGRAD_PMASK ;;
     wprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w tools/wino_probe.hip -o /tmp/wino_probe && timeout 300 /tmp/wino_probe > gpurun_out/wino_probe.txt 2>&1; echo "wprobe rc=$?"; cat gpurun_out/wino_probe.txt ;;
     coprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -w tools/coissue_probe.hip -o /tmp/coissue_probe && timeout 300 /tmp/coissue_probe > gpurun_out/coissue_probe.txt 2>&1; echo "coprobe rc=$?"; cat gpurun_out/coissue_probe.txt ;;
+    cmpq) timeout 600 python tools/cmp_variants.py "C3HIP_WINOGRAD_PMASK=0" "C3HIP_WINOGRAD_PMASK=0x1b6" 300 > gpurun_out/cmpq.txt 2>&1; echo "cmpq rc=$?"; grep -E "differ|^y" gpurun_out/cmpq.txt ;;
     diagfap) C3HIP_WINOGRAD_PMASK=0x1b6 timeout 600 python tools/gpu_diag.py fa fa9 > gpurun_out/diagp.txt 2>&1; echo "diag(pmask) rc=$?"; grep -E "act|y " gpurun_out/diagp.txt | head -30 ;;
     stagger) for st in 0 16 32 48 64 96 160; do echo "== stagger=$st"; C3HIP_WINOGRAD_STAGGER=$st timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchfa.err | python -c "
 import sys,json
