@@ -18,6 +18,7 @@
 #include "c3_kernels.h"
 #include "c3_wino.h"
 #include "c3_wino_p.h"
+#include "c3_conv1.h"
 #include "c3_lstm_fused.h"
 
 using namespace c3;
@@ -105,6 +106,9 @@ struct c3_model {
     // 110/113 us, res3 171/179 -> 162/164 us (res3 gains little: 18 tiles per window quantise badly and its input
     // transform is recomputed for each of 8 N-tiles).  v2 (one workgroup per CU, transform interleaved into the MFMA
     // stream) is 10-15 % slower than v1 on res1/res2 and equal on res3; it stays selectable for experiments.
+    unsigned conv_bn64_mask = 0x40; // direct-conv layers on 128x64 tiles instead of 128x128 (conv5: 480 workgroups fill 2 per CU); env C3HIP_CONV_BN64MASK
+    bool conv1_direct = true;       // 8-channel conv1 through conv1_i8_kernel (c3_conv1.h); env C3HIP_CONV1_DIRECT
+    float *conv1_wfrag = nullptr;   // its resident B fragments [36][2][64]
     unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
     int wg_slots = 512;             // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
     unsigned wino_v2_mask = 0;      // layers whose Winograd launch uses kernel v2 (experimental); env C3HIP_WINOGRAD_V2MASK
@@ -426,6 +430,18 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     }
     TRY(upload(m, &m->conv_w[l], pw));
     TRY(upload(m, &m->conv_b[l], pb));
+    if (l == 0 && Cin == 8) {
+        // conv1_i8_kernel: k-step s = 4 tap + j of lane (n = lane & 31, kk = lane >> 5) multiplies channel 4 kk + j of tap s / 4
+        std::vector<float> pf((size_t)36 * 2 * 64);
+        for (int s = 0; s < 36; ++s)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = 32 * cb + (lane & 31), ci = 4 * (lane >> 5) + s % 4, kh = (s / 4) / 3, kw = (s / 4) % 3;
+                    const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+                    pf[((size_t)s * 2 + cb) * 64 + lane] = (float)((double)w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] * scale / 100.0);
+                }
+        TRY(upload(m, &m->conv1_wfrag, pf));
+    }
     if (kConvStride[l] == 1 && Cin % kWinoBK == 0 && Cout % kWinoNT == 0) {
         // Winograd F(2x2,3x3) weights V = G g' G^T (g' = BN-folded), in MFMA B-fragment order
         //   [Cout/32][xi = 4i+j][Cin/16][g][lane][e] = V_xi[n = nt*32 + (lane&31)][k = 16c + 8g + 4(lane>>5) + e]
@@ -527,6 +543,13 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
                     hipLaunchKernelGGL(wino_conv_kernel2<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
             }
             HIP_TRY(hipGetLastError());
+        } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_wfrag) {
+            Conv1Params cp;
+            cp.x = x, cp.wfrag = m->conv1_wfrag, cp.bias = m->conv_b[0], cp.out = m->act[0];
+            cp.B = (int)n, cp.H = hh[0], cp.W = ww[0], cp.OH = hh[1], cp.OW = ww[1], cp.M = M, cp.groups = (M + 31) / 32;
+            const int grid = std::min((cp.groups + 3) / 4, m->wg_slots);
+            hipLaunchKernelGGL(conv1_i8_kernel, dim3(grid), dim3(256), 0, s, cp);
+            HIP_TRY(hipGetLastError());
         } else if (l == 0) {
             Conv1LoaderParams lp{x, (const int8_t *)m->zeros, hh[0], ww[0], cin, hh[1], ww[1]};
             TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU, 128, 64>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep)));
@@ -535,7 +558,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             const int nk = 9 * cin / kBK;
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
-            if (Cout == 64) {
+            if (Cout == 64 || (m->conv_bn64_mask & (1u << l))) {
                 if (res)
                     TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RES_RELU, 128, 64>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep)));
                 else
@@ -728,6 +751,8 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     }
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_CONV_BN64MASK")) m->conv_bn64_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_CONV1_DIRECT")) m->conv1_direct = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_WINOGRAD_PMASK")) m->wino_p_mask = (unsigned)strtoul(e, nullptr, 0);
     {
         hipDeviceProp_t prop;
@@ -934,7 +959,8 @@ int c3_model_destroy(c3_model *m) {
     (void)hipDeviceSynchronize();
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
-                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias};
+                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias,
+                   m->conv1_wfrag};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     for (int l = 0; l < 9; ++l) {
