@@ -13,8 +13,8 @@ probability rows to rank 0.  One process per GPU, windows sharded
 
   value        whole-job candidate-windows/s of the headline workload = BASELINE.json configs[2]
                "ONT r10.4.1 full-alignment model, synthetic (B=256, 89, 33, 8)" (the path the north-star target
-               is quoted on); the same measurement for configs[1] (pileup, B=1024) is in "pileup".  By default two
-               batches are kept in flight per GPU (--streams 2: two model handles on two HIP streams, every step
+               is quoted on); the same measurement for configs[1] (pileup, B=1024) is in "pileup".  By default three
+               batches are kept in flight per GPU (--streams 3: three model handles on three HIP streams, every step
                still a complete forward over one full batch -- the reference runs several workers per GPU too);
                "one_batch_in_flight" is the same K steps issued strictly one after the other;
   roofline     dominant kernel family (implicit-GEMM 3x3 convolutions on v_mfma_f32_32x32x2_f32), HIP-event
@@ -143,11 +143,11 @@ def run_workload(name, args, rank, world, local):
                       for r in stats}
     if kind == syn.FULL_ALIGNMENT:
         dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res"))]
-        dom_name = ("3x3 convolution family: gemm_mfma_kernel<Conv1Loader|ConvLoader> (implicit GEMM) + wino_conv_kernel "
-                    "(Winograd F(2x2,3x3) on the 64/128-channel blocks), 9 launches per step, fp32 MFMA")
+        dom_name = ("3x3 convolution family: conv1_i8_kernel + gemm_mfma_kernel<ConvLoader> (stride-2 implicit GEMM) + "
+                    "wino_conv_kernel_p (persistent Winograd F(2x2,3x3) on the six stride-1 convs), 9 launches per step, fp32 MFMA")
     else:
         dom = [r for r in stats if r["name"].startswith("p.lstm")]
-        dom_name = "lstm_recurrent_kernel<128|160> (2 launches per step)"
+        dom_name = "lstm1_fused_kernel + lstm_recurrent_kernel_v2<160> (the two BiLSTM recurrences, 2 launches per step, fp32 MFMA 16x16x4)"
     ms = sum(r["total_ms"] for r in dom)
     fl = sum(r["flops"] for r in dom)
     launches = sum(r["launches"] for r in dom)
@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=["all"] + list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/experiments only)")
-    ap.add_argument("--streams", type=int, default=2, help="batches kept in flight per GPU (model handles x HIP streams)")
+    ap.add_argument("--streams", type=int, default=3, help="batches kept in flight per GPU (model handles x HIP streams)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", nargs=4, metavar=("WORKLOAD", "THREADS", "BUDGET", "BATCH"), help=argparse.SUPPRESS)

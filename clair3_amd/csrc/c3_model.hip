@@ -111,7 +111,6 @@ struct c3_model {
     float *conv1_wfrag = nullptr;   // its resident B fragments [36][2][64]
     unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
     int wg_slots = 512;             // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
-    unsigned wino_v2_mask = 0;      // layers whose Winograd launch uses kernel v2 (experimental); env C3HIP_WINOGRAD_V2MASK
     unsigned wino_n64_mask = 0x1b6; // layers using the 32-tile x 64-cout workgroup shape; env C3HIP_WINOGRAD_N64MASK
     bool lstm2_v2 = true;        // env C3HIP_LSTM2_V2=0 selects the streaming 10-wave kernel
     int wino_stagger = 0;        // env C3HIP_WINOGRAD_STAGGER (units of 64 clocks)
@@ -531,16 +530,11 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
                     hipLaunchKernelGGL(wino_conv_kernel_n64<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
                 else
                     hipLaunchKernelGGL(wino_conv_kernel_n64<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
-            } else if (!(m->wino_v2_mask & (1u << l))) {
+            } else {
                 if (wp.res)
                     hipLaunchKernelGGL(wino_conv_kernel<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
                 else
                     hipLaunchKernelGGL(wino_conv_kernel<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
-            } else {
-                if (wp.res)
-                    hipLaunchKernelGGL(wino_conv_kernel2<true>, dim3(wp.tiles), dim3(256), 0, s, wp);
-                else
-                    hipLaunchKernelGGL(wino_conv_kernel2<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
             }
             HIP_TRY(hipGetLastError());
         } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_wfrag) {
@@ -759,7 +753,6 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             m->wg_slots = 2 * prop.multiProcessorCount;
     }
-    if (const char *e = getenv("C3HIP_WINOGRAD_V2MASK")) m->wino_v2_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_N64MASK")) m->wino_n64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_WINOGRAD_STAGGER")) m->wino_stagger = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;

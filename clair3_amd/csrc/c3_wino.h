@@ -456,221 +456,4 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_n64(WinoParams p) {
     }
 }
 
-// ----------------------------------------------------------------------------------------------------
-// Version 2: one workgroup per CU (4 waves, one per SIMD, the whole 512-entry register file each), the
-// input transform software-pipelined INTO the MFMA stream instead of relying on a second workgroup:
-//   body(c):  issue the 16 patch loads of chunk c+2 and the V fragments of chunk c+1      (2 register stages)
-//             transform the patch of chunk c+1 (loaded one iteration ago) -> U[(c+1)&1]      (2 LDS stages)
-//             64 MFMAs on U[c&1]                                                            (VALU/LDS/VMEM of the
-//             barrier                                                                        lines above fill the gaps)
-// The epilogue exchanges all 32 couts in one pass through the 128 KiB the two U stages occupy.
-template <bool RES, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void wino_conv_kernel2(WinoParams p) {
-    // two distinct LDS objects (not one array split in halves) so that alias analysis knows the U stores of
-    // the next chunk cannot touch the fragments being read, and may schedule them among the MFMAs
-    __shared__ __attribute__((aligned(16))) char ubuf0[65536];
-    __shared__ __attribute__((aligned(16))) char ubuf1[65536];
-    __shared__ int2 tcoord[kWinoPT];  // (byte offset of output pixel (b,2ty,2tx) channel 0 ; flags: 1 valid, 2 row+1 < H, 4 col+1 < W)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = xcd_tile_index(blockIdx.x, p.tiles);
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int p0 = tm * kWinoPT, n0 = tn * kWinoNT;
-
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.x), 0, p.B * p.H * p.W * p.Cin * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(RES ? p.res : p.out), 0, p.B * p.H * p.W * p.Cout * 4, 0x00020000);
-    const int tl = tid >> 2, q = tid & 3;
-    uint32_t base, okmask = 0;
-    {
-        int pp = p0 + tl;
-        const bool valid = pp < p.P;
-        if (!valid) pp = p.P - 1;
-        const int tpw = p.th * p.tw;
-        const int b = pp / tpw, r = pp - b * tpw;
-        const int ty = r / p.tw, tx = r - ty * p.tw;
-        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
-        base = (uint32_t)(((((int64_t)b * p.H + iy0) * p.W + ix0) * p.Cin + q * 4) * 4);
-#pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx)
-                if (iy0 + dy >= 0 && iy0 + dy < p.H && ix0 + dx >= 0 && ix0 + dx < p.W) okmask |= 1u << (dy * 4 + dx);
-        if (q == 0)
-            tcoord[tl] = make_int2((int)((((int64_t)b * p.H + 2 * ty) * p.W + 2 * tx) * p.Cout * 4),
-                                   (valid ? 1 : 0) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 4 : 0));
-    }
-    const int u_wr = tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4);
-
-    const int frow = lane & 31, fhi = lane >> 5;
-    const int a_rd0 = frow * 64, a_rd1 = (32 + frow) * 64;
-    const int a_sw = (frow >> 2) & 3;
-    const int nchunks = p.Cin / kWinoBK, last = nchunks - 1;
-    const float *vbase = p.v + ((int64_t)(tn * 16 + wave * 4) * nchunks * 2 * 64 + lane) * 4;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][rb][v] = 0.f;
-
-    auto load_patch = [&](f32x4 (&d)[4][4], int c) __attribute__((always_inline)) {
-        const uint32_t choff = base + (uint32_t)(c * kWinoBK) * 4u;
-#pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
-                const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
-                if constexpr (ABL & 1) d[dy][dx] = f32x4{(float)off, 1.f, 2.f, 3.f};
-                else d[dy][dx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
-            }
-    };
-    auto load_v = [&](f32x4 (&bf)[4][2], int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                if constexpr (ABL & 4) bf[i][g] = f32x4{1.f, 2.f, 3.f, (float)c};
-                else bf[i][g] = *reinterpret_cast<const f32x4 *>(vbase + ((int64_t)(i * nchunks + c) * 2 + g) * 256);
-            }
-    };
-    auto transform_store = [&](f32x4 (&d)[4][4], char *__restrict__ u) __attribute__((always_inline)) {
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {  // t = B^T d
-            const f32x4 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
-            d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // U = t B, xi = 4i + j
-            const f32x4 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
-            *reinterpret_cast<f32x4 *>(u + (4 * i + 0) * 4096 + u_wr) = t0 - t2;
-            *reinterpret_cast<f32x4 *>(u + (4 * i + 1) * 4096 + u_wr) = t1 + t2;
-            *reinterpret_cast<f32x4 *>(u + (4 * i + 2) * 4096 + u_wr) = t2 - t1;
-            *reinterpret_cast<f32x4 *>(u + (4 * i + 3) * 4096 + u_wr) = t1 - t3;
-        }
-    };
-
-    f32x4 dA[4][4], dB[4][4], bfA[4][2], bfB[4][2];
-    load_patch(dA, 0);
-    load_v(bfA, 0);
-    load_patch(dB, last < 1 ? last : 1);
-    transform_store(dA, ubuf0);
-    __syncthreads();
-
-    // dCur holds the patch of chunk c+1, bCur the V fragments of chunk c
-    // cur / nxt are the two halves of ubuf; __restrict__ tells the scheduler that the U stores of the next chunk
-    // never alias the fragment reads of the current one, so they may interleave with the MFMAs
-    auto body = [&](int c, const char *__restrict__ cur, char *__restrict__ nxt, f32x4 (&dCur)[4][4], f32x4 (&dNext)[4][4],
-                    f32x4 (&bCur)[4][2], f32x4 (&bNext)[4][2]) __attribute__((always_inline)) {
-        load_patch(dNext, c + 2 < last ? c + 2 : last);
-        load_v(bNext, c + 1 < last ? c + 1 : last);
-        __builtin_amdgcn_sched_barrier(0);
-        // 8 steps (xi i = st>>1, k-group g = st&1) of 8 MFMAs.  Pinned per step (sched_barrier): the A fragments of
-        // step st+1 are read first, then the 8 MFMAs are issued, then one eighth of the NEXT chunk's input
-        // transform (steps 0-3: B^T d for patch column st; steps 4-7: row st-4 of (.)B and its four U stores) --
-        // ~16 VALU ops that execute in the shadow of the step's last MFMAs.
-        f32x4 a[2][2];
-        {
-            const char *plane = cur + (wave * 4) * 4096;
-            const int coff = (fhi ^ a_sw) << 4;
-            a[0][0] = *reinterpret_cast<const f32x4 *>(plane + a_rd0 + coff);
-            a[0][1] = *reinterpret_cast<const f32x4 *>(plane + a_rd1 + coff);
-        }
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            const int i = st >> 1, g = st & 1;
-            if (st < 7) {
-                const int i2 = (st + 1) >> 1, g2 = (st + 1) & 1;
-                const char *plane = cur + (wave * 4 + i2) * 4096;
-                const int coff = ((2 * g2 + fhi) ^ a_sw) << 4;
-                a[(st + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(plane + a_rd0 + coff);
-                a[(st + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(plane + a_rd1 + coff);
-            }
-            if constexpr (!(ABL & 16)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][0][j], bCur[i][g][j], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][1][j], bCur[i][g][j], acc[i][1], 0, 0, 0);
-                }
-            } else {
-                asm volatile("" ::"v"(a[st & 1][0]), "v"(a[st & 1][1]), "v"(bCur[i][g]));
-            }
-            if constexpr (ABL & 2) {
-                asm volatile("" ::"v"(dCur[st & 3][st >> 1 & 3]));
-            } else if (st < 4) {
-                const int dx = st;  // t = B^T d, column dx
-                const f32x4 d0 = dCur[0][dx], d1 = dCur[1][dx], d2 = dCur[2][dx], d3 = dCur[3][dx];
-                dCur[0][dx] = d0 - d2, dCur[1][dx] = d1 + d2, dCur[2][dx] = d2 - d1, dCur[3][dx] = d1 - d3;
-            } else {
-                const int r = st - 4;  // U = t B, row r: xi = 4r + j
-                const f32x4 t0 = dCur[r][0], t1 = dCur[r][1], t2 = dCur[r][2], t3 = dCur[r][3];
-                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 0) * 4096 + u_wr) = t0 - t2;
-                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 1) * 4096 + u_wr) = t1 + t2;
-                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 2) * 4096 + u_wr) = t2 - t1;
-                *reinterpret_cast<f32x4 *>(nxt + (4 * r + 3) * 4096 + u_wr) = t1 - t3;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    };
-    int c = 0;
-    for (; c + 1 <= last; c += 2) {
-        body(c, ubuf0, ubuf1, dB, dA, bfA, bfB);
-        body(c + 1, ubuf1, ubuf0, dA, dB, bfB, bfA);
-    }
-    if (c <= last) body(c, ubuf0, ubuf1, dB, dA, bfA, bfB);
-
-    if constexpr (ABL & 8) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) sacc += acc[i][rb][v];
-        if (sacc == 123.456f) p.out[tid] = sacc;
-        return;
-    }
-    // ---- epilogue: one exchange pass, [16 xi][64 tiles][32 couts] floats = the 128 KiB of both U stages
-    // xi planes 0..7 live in ubuf0, 8..15 in ubuf1 (8 KiB per plane)
-    float *mbuf0 = reinterpret_cast<float *>(ubuf0), *mbuf1 = reinterpret_cast<float *>(ubuf1);
-    {
-        const int c32 = lane & 31;
-        float *mw = wave < 2 ? mbuf0 : mbuf1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int t = rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * fhi;
-                    mw[(((wave & 1) * 4 + i) * kWinoPT + t) * 32 + c32] = acc[i][rb][v];
-                }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {  // (tile, cout quad) items: 64 x 8 = 2 per thread
-        const int idx = tid + 256 * r;
-        const int cq = idx & 7, t = idx >> 3;
-        const int2 tc = tcoord[t];
-        f32x4 m[4][4];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi)
-            m[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4 *>(&(xi < 8 ? mbuf0 : mbuf1)[((xi & 7) * kWinoPT + t) * 32 + 4 * cq]);
-        f32x4 s4[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s4[0][j] = m[0][j] + m[1][j] + m[2][j];
-            s4[1][j] = m[1][j] - m[2][j] - m[3][j];
-        }
-        const int n = n0 + 4 * cq;
-        wino_store4<RES>(s4, tc, n, *reinterpret_cast<const f32x4 *>(p.bias + n), orsrc, rrsrc, p.W * p.Cout * 4, p.Cout * 4);
-    }
-}
-
 }  // namespace c3

@@ -104,21 +104,9 @@ __global__ __launch_bounds__(256, 2) void census_kernel(int *maxres, int *cur, i
     if (buf[(threadIdx.x * 7) & 255] == 77) maxres[4095] = 1;
 }
 
-template <int ABL>
-static float run_wino2(const float *x, const float *zeros, const float *v, const float *bias, float *out, int B, int H, int W, int Cin, int Cout) {
-    WinoParams wp;
-    wp.x = x, wp.zeros = zeros, wp.v = v, wp.bias = bias, wp.res = nullptr, wp.out = out;
-    wp.B = B, wp.H = H, wp.W = W, wp.Cin = Cin, wp.Cout = Cout;
-    wp.th = (H + 1) / 2, wp.tw = (W + 1) / 2, wp.P = B * wp.th * wp.tw;
-    wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
-    wp.stagger = 0;
-    return time_it([&] { hipLaunchKernelGGL((wino_conv_kernel2<false, ABL>), dim3(wp.tiles), dim3(256), 0, 0, wp); });
-}
-
 int main() {
     const int B = 256;
     occ("wino_conv_kernel<false,0>", wino_conv_kernel<false, 0>, 256);
-    occ("wino_conv_kernel2<false>", wino_conv_kernel2<false>, 256);
     occ("gemm conv 128x64", gemm_mfma_kernel<ConvLoader<4>, EPI_BIAS_RELU, 128, 64, 0>, 256);
     occ("gemm conv 128x128", gemm_mfma_kernel<ConvLoader<4>, EPI_BIAS_RELU, 128, 128, 0>, 256);
     {
@@ -195,21 +183,6 @@ int main() {
         for (int i = 0; i < 8; ++i) printf("res3a 128x128 %-34s %.1f us %.1f TF\n", names[i], t[i], fl / t[i] / 1e6);
         float t64 = run_conv<64, 0>(x, zeros, w, bias, y, B, 12, 5, 256, 256);
         printf("res3a 128x64  full %.1f us %.1f TF\n", t64, fl / t64 / 1e6);
-    }
-    {
-        struct { int H, W, C; const char *name; } shp2[] = {{45, 17, 64, "res1"}, {23, 9, 128, "res2"}};
-        for (auto &sh : shp2) {
-            double fl = 2.0 * B * sh.H * sh.W * sh.C * 9.0 * sh.C;
-            float t0 = run_wino2<0>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            float t1 = run_wino2<1>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            float t4 = run_wino2<4>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            float t5 = run_wino2<5>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            float t8 = run_wino2<8>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            float t16 = run_wino2<16>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            float t2 = run_wino2<2>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            float t15 = run_wino2<15>(x, zeros, w, bias, y, B, sh.H, sh.W, sh.C, sh.C);
-            printf("wino2 %s full %.1f us (%.1f TF-eq) | no patch loads %.1f | no V loads %.1f | neither %.1f | no epilogue %.1f | no MFMA %.1f | no xform %.1f | MFMA+frag only %.1f\n", sh.name, t0, fl / t0 / 1e6, t1, t4, t5, t8, t16, t2, t15);
-        }
     }
     {
         const char *wn[] = {"full", "no patch loads(1)", "no patch loads,no xform/LDS wr(3)", "no V loads(4)", "no epilogue(8)", "no MFMA(16)",
