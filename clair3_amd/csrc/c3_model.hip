@@ -19,6 +19,7 @@
 #include "c3_wino.h"
 #include "c3_wino_p.h"
 #include "c3_conv1.h"
+#include "c3_tail.h"
 #include "c3_lstm_fused.h"
 
 using namespace c3;
@@ -118,6 +119,8 @@ struct c3_model {
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
+    float *w5f = nullptr, *whf = nullptr, *bh48 = nullptr;  // MFMA fragment packing of the same weights (c3_tail.h)
+    bool tail_mfma = true;                                   // env C3HIP_TAIL_MFMA
     float *zeros = nullptr;  // 256-byte zero page: padding taps of the conv loaders read from here
     int FC = 0, K4 = 0;
 
@@ -298,6 +301,34 @@ static int pack_tail(c3_model *m, const TensorMap &tm) {
             bh[br * 64 + i] = b[i];
             for (int k = 0; k < 128; ++k) wh[((size_t)br * 128 + k) * 64 + i] = w[(size_t)i * 128 + k];
         }
+    }
+    {
+        // fc_tail_mfma_kernel fragments: [br][wave][cb][q][lane][e] = L5_br[32 wave + 16 cb + (lane&15)][16 q + 4 (lane>>4) + e]
+        //                                [br][cb][q][lane][e]       = head_br[16 cb + (lane&15)][16 q + 4 (lane>>4) + e]
+        const int NQ = FC / 16;
+        std::vector<float> w5f((size_t)nb * 128 * FC), whf((size_t)nb * 3 * 8 * 64 * 4, 0.f), bh48((size_t)nb * 48, 0.f);
+        for (int br = 0; br < nb; ++br) {
+            for (int wv = 0; wv < 4; ++wv)
+                for (int cb = 0; cb < 2; ++cb)
+                    for (int q = 0; q < NQ; ++q)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int j = 32 * wv + 16 * cb + (lane & 15), k = 16 * q + 4 * (lane >> 4) + e;
+                                w5f[(((((size_t)br * 4 + wv) * 2 + cb) * NQ + q) * 64 + lane) * 4 + e] =
+                                    w5t[(size_t)k * nb * 128 + br * 128 + j];
+                            }
+            for (int cb = 0; cb < 3; ++cb)
+                for (int q = 0; q < 8; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 16 * cb + (lane & 15), k = 16 * q + 4 * (lane >> 4) + e;
+                            whf[((((size_t)br * 3 + cb) * 8 + q) * 64 + lane) * 4 + e] = wh[((size_t)br * 128 + k) * 64 + i];
+                        }
+            for (int i = 0; i < 48; ++i) bh48[br * 48 + i] = bh[br * 64 + i];
+        }
+        TRY(upload(m, &m->w5f, w5f));
+        TRY(upload(m, &m->whf, whf));
+        TRY(upload(m, &m->bh48, bh48));
     }
     TRY(upload(m, &m->w5t, w5t));
     TRY(upload(m, &m->b5, b5));
@@ -482,8 +513,20 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
         TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
     }
-    {
-        const double fl = 2.0 * n * (FC * 128.0 * m->nb + 128.0 * m->nout);
+    const double fl = 2.0 * n * (FC * 128.0 * m->nb + 128.0 * m->nout);
+    if (m->tail_mfma && m->w5f) {
+        ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
+        ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
+        hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
+        HIP_TRY(hipGetLastError());
+        Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->nout};
+        const dim3 grid((unsigned)((n + 15) / 16), m->nb);
+        if (FC == 256)
+            hipLaunchKernelGGL(fc_tail_mfma_kernel<256>, grid, dim3(256), 0, s, tp);
+        else
+            hipLaunchKernelGGL(fc_tail_mfma_kernel<128>, grid, dim3(256), 0, s, tp);
+        HIP_TRY(hipGetLastError());
+    } else {
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
         TailParams tp{m->part, m->l4_b, m->w5t, m->b5, m->wh, m->bh, y, m->keep ? m->l4dbg : nullptr,
                       (int)n, S, m->nb, m->nout};
@@ -746,6 +789,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_BN64MASK")) m->conv_bn64_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_DIRECT")) m->conv1_direct = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_WINOGRAD_PMASK")) m->wino_p_mask = (unsigned)strtoul(e, nullptr, 0);
     {
@@ -953,7 +997,7 @@ int c3_model_destroy(c3_model *m) {
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
                    m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias,
-                   m->conv1_wfrag};
+                   m->conv1_wfrag, m->w5f, m->whf, m->bh48};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     for (int l = 0; l < 9; ++l) {

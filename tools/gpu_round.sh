@@ -24,6 +24,12 @@ for k,v in d['kernels'].items(): print('   %-9s %7.1f us %6.1f TF' % (k, v['avg_
 "; done; unset C3HIP_WINOGRAD_PMASK ;;
     wprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w tools/wino_probe.hip -o /tmp/wino_probe && timeout 300 /tmp/wino_probe > gpurun_out/wino_probe.txt 2>&1; echo "wprobe rc=$?"; cat gpurun_out/wino_probe.txt ;;
     coprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -w tools/coissue_probe.hip -o /tmp/coissue_probe && timeout 300 /tmp/coissue_probe > gpurun_out/coissue_probe.txt 2>&1; echo "coprobe rc=$?"; cat gpurun_out/coissue_probe.txt ;;
+    tail) for v in 0 1; do echo "== C3HIP_TAIL_MFMA=$v"; C3HIP_TAIL_MFMA=$v timeout 600 python bench.py --gpus 1 --no-cpu-baseline --streams 1 2> gpurun_out/bencht.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  FA %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items() if k in ('fa.l4','fa.tail','fa.spp')))
+p=d['pileup']; print('  pileup %.0f windows/s  %.4f ms/step' % (p['value'], p['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in p['kernels'].items()))
+"; done ;;
     convbn) for v in 0 0x8 0x40 0x48; do echo "== C3HIP_CONV_BN64MASK=$v"; C3HIP_CONV_BN64MASK=$v timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchc1.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
