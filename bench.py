@@ -101,6 +101,7 @@ def run_workload(name, args, rank, world, local):
             if world > 1:
                 if n_streams > 1:
                     torch.cuda.current_stream(dev).wait_stream(streams[i])
+                    y.record_stream(torch.cuda.current_stream(dev))  # the gather below reads y on the default stream
                 return c3dist.gather_rows(y, n_total, dst=0)
             return y
 

@@ -20,6 +20,7 @@
 #include "c3_wino_p.h"
 #include "c3_conv1.h"
 #include "c3_tail.h"
+#include "c3_proj.h"
 #include "c3_lstm_fused.h"
 
 using namespace c3;
@@ -94,6 +95,8 @@ struct c3_model {
     // ---- packed weights (device) ----
     // pileup
     float *proj_w[2] = {nullptr, nullptr};  // [2*4H][Kp]
+    float *proj2_frag = nullptr;            // LSTM2 projection weights as proj_stream_kernel fragments (c3_proj.h)
+    bool proj2_stream = true;               // env C3HIP_PROJ2_STREAM
     float *proj_b[2] = {nullptr, nullptr};  // [2*4H]
     float *whh[2] = {nullptr, nullptr};     // fragment-packed W_hh
     float *l1_wih = nullptr, *l1_bias = nullptr;  // LSTM1 input projection as MFMA fragments (fused kernel)
@@ -367,6 +370,18 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                             const int k = 16 * q + 4 * (lane >> 4) + e;
                             wf[((((size_t)dir * (4 * H / 16) + blk) * NQ + q) * 64 + lane) * 4 + e] = whh[(size_t)r * H + k];
                         }
+        }
+        if (layer == 1 && Kp == 256 && (2 * 4 * H) % 32 == 0) {
+            // proj_stream_kernel: [cb][i][lane][e] = W[n = 32 cb + (lane&31)][k = 128 (lane>>5) + 4 i + e]
+            const int N = 2 * 4 * H;
+            std::vector<float> pf((size_t)N * 256);
+            for (int cb = 0; cb < N / 32; ++cb)
+                for (int i = 0; i < 32; ++i)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e)
+                            pf[((((size_t)cb * 32 + i) * 64) + lane) * 4 + e] =
+                                pw[(size_t)(32 * cb + (lane & 31)) * Kp + 128 * (lane >> 5) + 4 * i + e];
+            TRY(upload(m, &m->proj2_frag, pf));
         }
         TRY(upload(m, &m->proj_w[layer], pw));
         TRY(upload(m, &m->proj_b[layer], pb));
@@ -673,9 +688,17 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.proj2", 2.0 * M * 1280.0 * 256.0, 4.0 * M * (256.0 + 1280.0));
-        DenseLoaderParams lp{m->h1, 256};
-        EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
-        TRY((launch_gemm<DenseLoader<4>, EPI_BIAS, 128, 128>(s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep)));
+        if (m->proj2_stream && m->proj2_frag && m->lstm2_v2) {
+            ProjParams pp{m->h1, m->proj2_frag, m->proj_b[1], m->gx2, M, 1280, (M + 31) / 32, 40};
+            const int64_t units = (int64_t)pp.row_blocks * pp.col_blocks;
+            const int grid = (int)std::min<int64_t>(m->wg_slots, (units + 3) / 4);
+            hipLaunchKernelGGL(proj_stream_kernel, dim3(grid), dim3(256), 0, s, pp);
+            HIP_TRY(hipGetLastError());
+        } else {
+            DenseLoaderParams lp{m->h1, 256};
+            EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
+            TRY((launch_gemm<DenseLoader<4>, EPI_BIAS, 128, 128>(s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep)));
+        }
     }
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
@@ -789,6 +812,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_BN64MASK")) m->conv_bn64_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_PROJ2_STREAM")) m->proj2_stream = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_DIRECT")) m->conv1_direct = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_WINOGRAD_PMASK")) m->wino_p_mask = (unsigned)strtoul(e, nullptr, 0);
@@ -997,7 +1021,7 @@ int c3_model_destroy(c3_model *m) {
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
                    m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias,
-                   m->conv1_wfrag, m->w5f, m->whf, m->bh48};
+                   m->conv1_wfrag, m->w5f, m->whf, m->bh48, m->proj2_frag};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     for (int l = 0; l < 9; ++l) {

@@ -30,6 +30,25 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  FA %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items() if k in ('fa.l4','fa.tail','fa.spp')))
 p=d['pileup']; print('  pileup %.0f windows/s  %.4f ms/step' % (p['value'], p['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in p['kernels'].items()))
 "; done ;;
+    batches) for cfg in "full_alignment 256" "full_alignment 1024" "full_alignment 2048" "pileup 1024" "pileup 4096" "pileup 16384"; do set -- $cfg; echo "== $1 B=$2"; timeout 600 python bench.py --gpus 1 --no-cpu-baseline --workload $1 --batch $2 --steps 20 --warmup 3 2> gpurun_out/benchb.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  %.0f windows/s with %d in flight (%.4f ms/step) | one in flight %.0f windows/s | whole-forward frac %.3f' % (d['value'], d['config']['batches_in_flight'], d['ms_per_step'], d['one_batch_in_flight']['value'], d['roofline']['whole_forward_frac']))
+"; done ;;
+    bigp) timeout 600 python bench.py --gpus 1 --no-cpu-baseline --workload pileup --batch 16384 --steps 10 --warmup 2 --streams 1 2> gpurun_out/benchb.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  pileup B=16384: %.0f windows/s' % d['value'], ' '.join('%s=%.1f(%.0fTF)' % (k, v['avg_us'], v['tflops'] or 0) for k,v in d['kernels'].items()))
+"; timeout 600 python bench.py --gpus 1 --no-cpu-baseline --workload full_alignment --batch 2048 --steps 10 --warmup 2 --streams 1 2> gpurun_out/benchb.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  FA B=2048: %.0f windows/s' % d['value'], ' '.join('%s=%.1f(%.0fTF)' % (k, v['avg_us'], v['tflops'] or 0) for k,v in d['kernels'].items()))
+" ;;
+    proj2) for v in 0 1; do echo "== C3HIP_PROJ2_STREAM=$v"; for b in 1024 16384; do C3HIP_PROJ2_STREAM=$v timeout 600 python bench.py --gpus 1 --workload pileup --batch $b --steps 20 --warmup 3 --no-cpu-baseline --streams 1 2> gpurun_out/benchp.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  B=%d value %.0f windows/s  %.4f ms/step' % (d['config']['batch_per_gpu'], d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
+"; done; done ;;
     convbn) for v in 0 0x8 0x40 0x48; do echo "== C3HIP_CONV_BN64MASK=$v"; C3HIP_CONV_BN64MASK=$v timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchc1.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
