@@ -34,14 +34,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_selu_kernel(ReduceParams p)
     const float *src = p.part + i;
     float v = p.bias[k];
     int s = 0;
-    for (; s + 8 <= p.S; s += 8) {  // 8 independent loads in flight, summed in order
+    for (; s < p.S; s += 8) {  // 8 independent loads in flight (the last batch clamps its surplus), summed in order
         float t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(s + u) * total];
+        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(s + u < p.S ? s + u : p.S - 1) * total];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v += t[u];
+        for (int u = 0; u < 8; ++u)
+            if (s + u < p.S) v += t[u];
     }
-    for (; s < p.S; ++s) v += src[(int64_t)s * total];
     p.out[i] = selu_f(v);
 }
 
@@ -78,6 +78,15 @@ __global__ __launch_bounds__(256) void fc_tail_mfma_kernel(Tail2Params p) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) wf[cb][q] = w[(cb * NQ + q) * 64];
     }
+    // the head's fragments and bias too (waves 0..2): nothing below has to wait for a load it could have had already
+    f32x4v hf[8];
+    float hb = 0.f;
+    if (wave < 3) {
+        const f32x4v *w = reinterpret_cast<const f32x4v *>(p.whf) + ((int64_t)(br * 3 + wave) * 8) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hf[q] = w[q * 64];
+        hb = p.bh[br * 48 + wave * 16 + col];
+    }
     // the 16 activation rows -> LDS (rows beyond B repeat the last window; their results are never written)
 #pragma unroll
     for (int i = 0; i < 16 * FC / 4 / 256; ++i) {
@@ -110,12 +119,7 @@ __global__ __launch_bounds__(256) void fc_tail_mfma_kernel(Tail2Params p) {
 
     // head_b on waves 0..2: 16 outputs each (48 >= 33), K = 128
     if (wave < 3) {
-        const f32x4v *w = reinterpret_cast<const f32x4v *>(p.whf) + ((int64_t)(br * 3 + wave) * 8) * 64 + lane;
-        f32x4v hf[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) hf[q] = w[q * 64];
-        const float b = p.bh[br * 48 + wave * 16 + col];
-        f32x4v ah = f32x4v{b, b, b, b};
+        f32x4v ah = f32x4v{hb, hb, hb, hb};
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const f32x4v a = *reinterpret_cast<const f32x4v *>(&h5[col][16 * q + 4 * s]);

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256) void intra(float *out, const float *src, int i
     f32x2 y0 = {a, b}, y1 = {b, a};
     f32x4 l = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
     unsigned sacc = blockIdx.x;
+    f32x4 gq[16], lq[16];
+    for (int i = 0; i < 16; ++i) gq[i] = f32x4{0.f, 0.f, 0.f, 0.f}, lq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, 1 << 20, 0x00020000);
     lds[tid] = a; lds[tid + 256] = b;
     __syncthreads();
@@ -108,10 +110,16 @@ __global__ __launch_bounds__(256) void intra(float *out, const float *src, int i
                     if constexpr (CLASS == 4) g += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(tid * 16 + ((i * 4 + k) & 63) * 4096), 0, 0));
                     if constexpr (CLASS == 5) asm volatile("s_add_u32 %0, %0, 7" : "+s"(sacc));
                     if constexpr (CLASS == 6) *reinterpret_cast<f32x2 *>(&lds[(tid * 2 + k * 512 + i * 32) & 8191]) = y0;
+                    // 8/9/10: loads whose results are only consumed after the 16 MFMAs of the iteration (issue cost alone)
+                    if constexpr (CLASS == 8) gq[(u * 8 + i) & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(tid * 16 + ((i * 4 + k) & 63) * 4096), 0, 0));
+                    if constexpr (CLASS == 9) lq[(u * 8 + i) & 15] = *reinterpret_cast<f32x4 *>(&lds[(tid * 4 + k * 1024 + i * 64) & 8191]);
+                    if constexpr (CLASS == 10) { f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(tid * 8 + ((i * 4 + k) & 63) * 4096), 0, 0)); gq[(u * 8 + i) & 15][0] = t2[0]; gq[(u * 8 + i) & 15][1] = t2[1]; }
                     if constexpr (CLASS == 7) { asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(x1), "v"(a) : "vcc"); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        if constexpr (CLASS == 8 || CLASS == 10) for (int i = 0; i < 16; ++i) g += gq[i];
+        if constexpr (CLASS == 9) for (int i = 0; i < 16; ++i) l += lq[i];
     }
     float res = x0 + y0[0] + y0[1] + l[0] + l[1] + l[2] + l[3] + g[0] + g[1] + g[2] + g[3] + (float)sacc;
     for (int i = 0; i < 8; ++i) for (int v = 0; v < 16; ++v) res += acc[i][v];
@@ -161,7 +169,11 @@ int main() {
         run_intra<6, 1>("ds_write_b64", out, src, base);
         run_intra<6, 2>("ds_write_b64", out, src, base);
         run_intra<7, 2>("v_cmp+v_cndmask", out, src, base);
+        run_intra<8, 1>("buffer_load_dwordx4 (deferred use)", out, src, base);
+        run_intra<10, 1>("buffer_load_dwordx2 (deferred use)", out, src, base);
+        run_intra<9, 1>("ds_read_b128 (deferred use)", out, src, base);
     }
     run<0, 0, 0, 8>("VALU", out, src, 8);
+    run<3, 0, 0, 8>("mix", out, src, 2);
     return 0;
 }
