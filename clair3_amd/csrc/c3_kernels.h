@@ -51,8 +51,11 @@ __device__ __forceinline__ void lds_barrier() {
 // Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Absolute error
 // of a gate value <= ~2e-7, two orders of magnitude inside the 1e-4 parity budget even after 66 steps; the
 // libm forms (expf / tanhf) cost ~10x the instructions and sit on the per-step critical path.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+// The reciprocal is the bare v_rcp_f32 (1 ulp): __frcp_rn is a correctly rounded 1/x, i.e. the ten-instruction
+// v_div_scale / v_div_fmas / v_div_fixup sequence -- 200 of the 330 vector instructions of an LSTM step, and under an
+// fp32 MFMA stream every vector instruction costs matrix-pipe time.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 // RESIDENT: keep this wave's W_hh fragments (4 gates x H/16 k-groups = H registers) in VGPRs for all T steps
 // (H = 128: 8 waves x 2 per SIMD fit the 512-entry file).  Otherwise stream them from L2 every step through
@@ -222,37 +225,47 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
         }
     }
 
-    // x-projection of a step: every wave DMAs exactly the 16 rows x WCOLS columns it will itself add to its
-    // accumulators (global_load_lds_dwordx4, WCOLS/4 active lanes per row): no registers, lands during the MFMAs,
-    // and only the issuing wave's own vmcnt orders it.
-    const int xlane = lane < WCOLS / 4 ? lane : WCOLS / 4 - 1;
-    const float *xsrc = p.gx + dir * 4 * H + wave * WCOLS + xlane * 4;
-    auto copy_x = [&](int t) __attribute__((always_inline)) {
-        if (lane < WCOLS / 4) {
+    // x-projection: lane (col, s) of this wave needs gx[window 4s+v][t][its NB column blocks] -- exactly the layout of
+    // its accumulators, so the values are loaded STRAIGHT INTO the accumulators (buffer loads: one loop-invariant
+    // vector offset per v, everything else scalar) right after the previous step's pre-activations have left them, and
+    // fly during the cell phase.  No staging, no register moves, no read-modify-write in LDS.
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gx), 0, (uint32_t)((int64_t)p.B * p.T * p.ld_gx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (uint32_t)((int64_t)p.B * p.T * 2 * H * 4), 0x00020000);
+    uint32_t xo[4];
 #pragma unroll
-            for (int row = 0; row < 16; ++row) {
-                int b = b0 + row;
-                if (b >= p.B) b = p.B - 1;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(xsrc + ((int64_t)b * p.T + t) * p.ld_gx),
-                    (__attribute__((address_space(3))) void *)gb(row, wave * WCOLS), 16, 0, 0);
-            }
-        }
+    for (int v = 0; v < 4; ++v) {
+        int b = b0 + 4 * s + v;
+        if (b >= p.B) b = p.B - 1;
+        xo[v] = (uint32_t)(((int64_t)b * p.T * p.ld_gx + col) * 4);
+    }
+    f32x4v acc[NB];
+    auto load_x = [&](int t) __attribute__((always_inline)) {
+        const int so = (int)((t * p.ld_gx + dir * 4 * H + swave * WCOLS) * 4);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc[b][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xo[v], so + b * 64, 0));
     };
+
+    // cell phase: thread (row = tid >> 5, units (tid & 31) + 32 r): every LDS / output address is one base + immediates
+    const int crow = tid >> 5, cu0 = tid & 31;
+    float *gbase = gb(crow, cu0);
+    uint32_t hobase = b0 + crow < p.B ? (uint32_t)((((int64_t)(b0 + crow) * p.T) * 2 * H + dir * H + cu0) * 4) : 0x80000000u;
+    float *gwr = gb(4 * s, (wave * NB) * 16 + col);  // + v * LDG + b * 16
 
     float c[NP];
 #pragma unroll
     for (int r = 0; r < NP; ++r) c[r] = 0.f;
+    load_x(dir ? p.T - 1 : 0);
     __syncthreads();
 
     for (int step = 0; step < p.T; ++step) {
         const int t = dir ? p.T - 1 - step : step;
         const int cur = step & 1;
-        copy_x(t);
-        __builtin_amdgcn_sched_barrier(0);  // the DMA is issued first, before any MFMA of the step
-        f32x4v acc[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
         if (step > 0) {  // h_{-1} = 0
             f32x4v a[2];
             a[0] = *reinterpret_cast<const f32x4v *>(hb(cur, col, 4 * s));
@@ -277,31 +290,27 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // gate pre-activations = x-projection (DMA, own columns) + recurrent part, in place
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // gate pre-activations (x-projection + recurrent part) -> LDS, then the next step's x-projection into the
+        // freed accumulators
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                float *g = gb(4 * s + v, (wave * NB + b) * 16 + col);
-                *g = *g + acc[b][v];
-            }
+            for (int v = 0; v < 4; ++v) gwr[v * LDG + b * 16] = acc[b][v];
+        if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1);
         __syncthreads();
         // cell: c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')   (rows i, f, g, o)
+        const uint32_t ho = hobase + (uint32_t)(t * 2 * H * 4);
 #pragma unroll
         for (int r = 0; r < NP; ++r) {
-            const int pi = tid + 512 * r;
-            const int row = pi / H, unit = pi - row * H;
-            const float *g = gb(row, unit);
+            const float *g = gbase + 32 * r;
             const float ig = fast_sigmoid(g[0]);
             const float fg = fast_sigmoid(g[H]);
             const float gg = fast_tanh(g[2 * H]);
             const float og = fast_sigmoid(g[3 * H]);
             c[r] = fg * c[r] + ig * gg;
             const float h = og * fast_tanh(c[r]);
-            *hb(cur ^ 1, row, unit) = h;
-            const int b = b0 + row;
-            if (b < p.B) p.hout[((int64_t)b * p.T + t) * (2 * H) + dir * H + unit] = h;
+            *hb(cur ^ 1, crow, cu0 + 32 * r) = h;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrsrc, ho + 128 * r, 0, 0);
         }
         lds_barrier();
     }

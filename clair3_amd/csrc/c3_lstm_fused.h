@@ -58,29 +58,42 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         }
     }
 
-    // A operand of the projection: lane (window = lane&15, s) supplies x[window][t][4*ks + s]
+    // A operand of the projection: lane (window = lane&15, s) supplies x[window][t][4*ks + s].  Buffer loads: one
+    // loop-invariant vector offset per k-step (out of range beyond C channels: the load returns the 0 the padding needs),
+    // the time step is the scalar offset -- no per-step address arithmetic.
     int xb = b0 + col;
     if (xb >= p.B) xb = p.B - 1;
-    const TX *xrow = p.starts ? p.x + (int64_t)p.starts[xb] * p.C : p.x + (int64_t)xb * p.T * p.C;
+    const int64_t xrow = p.starts ? (int64_t)p.starts[xb] * p.C : (int64_t)xb * p.T * p.C;
+    // region mode: the host has checked starts[b] + T <= n_cols, the descriptor only has to end below the redirect offset
+    const uint32_t xbytes = p.starts ? 0x7fffffffu : (uint32_t)((int64_t)p.B * p.T * p.C * sizeof(TX));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<TX *>(p.x), 0, xbytes, 0x00020000);
+    uint32_t xo[kFusedKS];
+#pragma unroll
+    for (int ks = 0; ks < kFusedKS; ++ks) {
+        const int k = 4 * ks + s;
+        xo[ks] = k < p.C ? (uint32_t)((xrow + k) * sizeof(TX)) : 0x80000000u;
+    }
     auto load_x = [&](int t, float (&xa)[kFusedKS]) __attribute__((always_inline)) {
+        const int so = t * p.C * (int)sizeof(TX);
 #pragma unroll
         for (int ks = 0; ks < kFusedKS; ++ks) {
-            const int k = 4 * ks + s;
-            const TX v = xrow[t * p.C + (k < p.C ? k : 0)];
-            xa[ks] = k < p.C ? (float)v : 0.f;
+            if constexpr (sizeof(TX) == 1) xa[ks] = (float)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(xrsrc, xo[ks], so, 0);
+            else xa[ks] = (float)(int32_t)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, xo[ks], so, 0);
         }
     };
 
+    f32x4v biasv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) biasv[g] = f32x4v{bias[g], bias[g], bias[g], bias[g]};
     const int h_col = dir * H + wave * 16 + col;
     float c[4] = {0.f, 0.f, 0.f, 0.f};
-    bool rowok[4];
-    int64_t rowbase[4];
+    const __amdgpu_buffer_rsrc_t hrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (uint32_t)((int64_t)p.B * p.T * 2 * H * 4), 0x00020000);
+    uint32_t ho[4];  // byte offset of hout[window 4s+v][0][h_col]; windows beyond B are out of range (store dropped)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        int b = b0 + 4 * s + v;
-        rowok[v] = b < p.B;
-        if (!rowok[v]) b = p.B - 1;
-        rowbase[v] = (int64_t)b * p.T;
+        const int b = b0 + 4 * s + v;
+        ho[v] = b < p.B ? (uint32_t)((((int64_t)b * p.T) * (2 * H) + h_col) * 4) : 0x80000000u;
     }
     float xn[kFusedKS];
     load_x(dir ? p.T - 1 : 0, xn);
@@ -94,13 +107,13 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         for (int ks = 0; ks < kFusedKS; ++ks) xa[ks] = xn[ks];
         if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1, xn);  // next step's counts: in flight during the MFMAs
         f32x4v acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4v{bias[g], bias[g], bias[g], bias[g]};
-        // gates += x_t W_ih^T   (clair3/model.py:131-132: x.float() then LSTM1)
+        // gates = bias + x_t W_ih^T   (clair3/model.py:131-132: x.float() then LSTM1); the bias is the C operand of the
+        // first MFMA (a resident 4-register vector per gate) instead of 16 register moves per step
 #pragma unroll
         for (int ks = 0; ks < kFusedKS; ++ks)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wih[g][ks], acc[g], 0, 0, 0);
+            for (int g = 0; g < 4; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wih[g][ks], ks == 0 ? biasv[g] : acc[g], 0, 0, 0);
         if (step > 0) {  // gates += h_{t-1} W_hh^T, h_{-1} = 0
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
             c[v] = fg * c[v] + ig * gg;
             const float h = og * fast_tanh(c[v]);
             hbuf[cur ^ 1][4 * s + v][wave * 16 + col] = h;
-            if (rowok[v]) p.hout[(rowbase[v] + t) * (2 * H) + h_col] = h;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrsrc, ho[v] + (uint32_t)(t * 2 * H * 4), 0, 0);
         }
         lds_barrier();
     }
