@@ -21,7 +21,8 @@ namespace c3 {
 
 // ABL (tools/wino_probe only; 0 in the product): bit0 no patch loads, bit1 no transform+LDS writes, bit2 no V loads,
 // bit3 no epilogue exchange/stores, bit4 no MFMAs.
-template <bool RES, int ABL = 0>
+// OPT bit1 (tools/wino_probe.hip only): workgroup 0 records the shader clock at its phase boundaries.
+template <bool RES, int ABL = 0, int OPT = 0>
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
     constexpr int PT = 32, NT = 64;
     // one LDS object: U [16][32][16] floats (32 KiB) / epilogue exchange [16][32][32] (64 KiB), then tcoord[2][PT]
@@ -77,6 +78,20 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
     const int v_cb0 = ((tn * 2) * 16 + wave * 4) * nchunks * 2048;
     const int v_cbs = 16 * nchunks * 2048, v_is = nchunks * 2048;
 
+    auto load_patch_rows = [&](f32x2 (&d)[4][4], uint32_t base, uint32_t okmask, int c, int dy0, int dy1) __attribute__((always_inline)) {
+        const uint32_t choff = base + (uint32_t)(c * kWinoBK) * 4u;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            if (dy < dy0 || dy >= dy1) continue;
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const bool ok = (okmask >> (dy * 4 + dx)) & 1u;
+                const uint32_t off = ok ? choff + (uint32_t)((dy * p.W + dx) * p.Cin) * 4u : 0x80000000u;
+                if constexpr (ABL & 1) d[dy][dx] = f32x2{(float)off, 1.f};
+                else d[dy][dx] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, off, 0, 0));
+            }
+        }
+    };
     auto load_patch = [&](f32x2 (&d)[4][4], uint32_t base, uint32_t okmask, int c) __attribute__((always_inline)) {
         const uint32_t choff = base + (uint32_t)(c * kWinoBK) * 4u;
 #pragma unroll
@@ -101,6 +116,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
             }
     };
 
+    // OPT bit1 (probe only): workgroup 0 records the shader clock at phase boundaries into p.zeros (unused otherwise)
+    int tr_n = 0;
+    auto trace = [&](int tag) __attribute__((always_inline)) {
+        if constexpr (OPT & 2) {
+            if (blockIdx.x == 0 && lane == 0 && tr_n < 250) {
+                long long *tb = reinterpret_cast<long long *>(const_cast<float *>(p.zeros)) + (wave * 256 + tr_n) * 2;
+                tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
+                ++tr_n;
+            }
+        }
+    };
     if (tm0 >= ngm) return;
     if (p.stagger > 0) {  // experiment: start the CU's second workgroup (LDS base != 0) late so the two run out of phase
         unsigned la;
@@ -134,7 +160,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                 const f32x2 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
                 d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
             }
+            trace(1);  // patch arrived, column transform done
             __syncthreads();  // every wave finished reading the previous chunk's U (or the previous group's exchange)
+            trace(2);
             if constexpr (ABL & 2) asm volatile("" ::"v"(d[0][0]), "v"(d[1][1]), "v"(d[2][2]), "v"(d[3][3]));
 #pragma unroll
             for (int i = 0; i < (ABL & 2 ? 0 : 4); ++i) {  // U = t B, xi = 4i + j
@@ -145,22 +173,23 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                 *reinterpret_cast<f32x2 *>(dst + (4 * i + 2) * kPlane) = t2 - t1;
                 *reinterpret_cast<f32x2 *>(dst + (4 * i + 3) * kPlane) = t1 - t3;
             }
+            trace(3);  // U written (issue)
             __syncthreads();
+            trace(4);
             if constexpr (LAST) {
                 // coordinates of the next row group (at the end of the walk: this one again -- its patch is never used);
                 // its first patch flies under these MFMAs and the epilogue
                 setup(tm + tstride < ngm ? tm + tstride : tm, buf ^ 1, base, okmask);
-                load_patch(d, base, okmask, 0);
-            } else {
-                load_patch(d, base, okmask, c + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            trace(5);  // prefetches issued
             if constexpr (ABL & 16) {
                 asm volatile("" ::"v"(bf[0][0][0]), "v"(bf[1][1][1]), "v"(bf[2][0][0]), "v"(bf[3][1][1]));
                 if constexpr (!LAST) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) load_v(bf[i], i, c + 1);
                 }
+                load_patch(d, base, okmask, LAST ? 0 : c + 1);
                 return;
             }
 #pragma unroll
@@ -176,11 +205,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                     }
                 }
                 if constexpr (!LAST) load_v(bf[i], i, c + 1);  // same registers, a whole chunk ahead of their use
+                // The next patch (chunk c+1, or the next group's chunk 0) is requested from INSIDE the MFMA stream, two
+                // patch rows after xi 0 and two after xi 1: a buffer_load costs ~60 cycles of issue when the wave has
+                // nothing else to do and next to nothing between two MFMAs (shader-clock trace in tools/wino_probe.hip:
+                // the 16 loads took 1000 of a chunk's 6450 cycles when issued before the MFMAs).
+                if (i < 2) load_patch_rows(d, base, okmask, LAST ? 0 : c + 1, 2 * i, 2 * i + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::false_type{});
         chunk(nchunks - 1, std::true_type{});
+        trace(6);  // all MFMAs of the group issued
 
         // ---- epilogue: one pass per column block (32 couts): exchange M_xi through LDS, A^T M A, bias (+res), ReLU, store
         float *mbuf = reinterpret_cast<float *>(ubuf);  // [16 xi][32 tiles][32 couts]
@@ -215,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
             }
             const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n);
             __syncthreads();
+            trace(7);
             {
                 const int c32 = lane & 31;
 #pragma unroll
@@ -225,7 +261,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                         mbuf[((wave * 4 + i) * PT + tt) * 32 + c32] = acc[i][h][vv];
                     }
             }
+            trace(8);  // exchange written (issue)
             __syncthreads();
+            trace(9);
             // the accumulators just written free the registers of two xi's fragments for the next group's chunk 0
             load_v(bf[2 * h], 2 * h, 0);
             load_v(bf[2 * h + 1], 2 * h + 1, 0);

@@ -51,6 +51,11 @@ print('  B=%d value %.0f windows/s  %.4f ms/step' % (d['config']['batch_per_gpu'
 "; done; done ;;
     pmcsq2) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_sq_a" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq_a.err"); echo "pmc sq a rc=$?"
            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM -d "$OLDPWD/gpurun_out/pmc_sq_b" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq_b.err"); echo "pmc sq b rc=$?" ;;
+    fa1) timeout 600 python tools/gpu_diag.py fa > gpurun_out/diag.txt 2>&1; grep -E "act2|act5|act8|^  y" gpurun_out/diag.txt | cut -c1-120; for i in 1 2; do timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchc1.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
+"; done ;;
     convbn) for v in 0 0x8 0x40 0x48; do echo "== C3HIP_CONV_BN64MASK=$v"; C3HIP_CONV_BN64MASK=$v timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchc1.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
