@@ -241,14 +241,17 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
         if (b >= p.B) b = p.B - 1;
         xo[v] = (uint32_t)(((int64_t)b * p.T * p.ld_gx + col) * 4);
     }
-    f32x4v acc[NB];
+    // xn holds the x-projection of the NEXT step: requested from inside the current step's MFMA stream (a load costs
+    // ~60 cycles of issue outside it, next to nothing between two MFMAs) and handed to the next step as the C operand of
+    // its first MFMA per block -- no register move.
+    f32x4v acc[NB], xn[NB];
     auto load_x = [&](int t) __attribute__((always_inline)) {
         const int so = (int)((t * p.ld_gx + dir * 4 * H + swave * WCOLS) * 4);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                acc[b][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xo[v], so + b * 64, 0));
+                xn[b][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xo[v], so + b * 64, 0));
     };
 
     // cell phase: thread (row = tid >> 5, units (tid & 31) + 32 r): every LDS / output address is one base + immediates
@@ -266,7 +269,11 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
     for (int step = 0; step < p.T; ++step) {
         const int t = dir ? p.T - 1 - step : step;
         const int cur = step & 1;
-        if (step > 0) {  // h_{-1} = 0
+        if (step == 0) {  // h_{-1} = 0: the pre-activations are the x-projection alone
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = xn[b];
+            if (p.T > 1) load_x(dir ? t - 1 : t + 1);
+        } else {
             f32x4v a[2];
             a[0] = *reinterpret_cast<const f32x4v *>(hb(cur, col, 4 * s));
 #pragma unroll
@@ -277,7 +284,8 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][e], wres[b][q][e], acc[b], 0, 0, 0);
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][e], wres[b][q][e], q == 0 && e == 0 ? xn[b] : acc[b], 0, 0, 0);
+                    if (q == 0 && step + 1 < p.T) load_x(dir ? t - 1 : t + 1);  // xn was consumed by the MFMAs just issued
                 } else {
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
@@ -296,7 +304,6 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int v = 0; v < 4; ++v) gwr[v * LDG + b * 16] = acc[b][v];
-        if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1);
         __syncthreads();
         // cell: c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')   (rows i, f, g, o)
         const uint32_t ho = hobase + (uint32_t)(t * 2 * H * 4);

@@ -105,7 +105,6 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         float xa[kFusedKS];
 #pragma unroll
         for (int ks = 0; ks < kFusedKS; ++ks) xa[ks] = xn[ks];
-        if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1, xn);  // next step's counts: in flight during the MFMAs
         f32x4v acc[4];
         // gates = bias + x_t W_ih^T   (clair3/model.py:131-132: x.float() then LSTM1); the bias is the C operand of the
         // first MFMA (a resident 4-register vector per gate) instead of 16 register moves per step
@@ -114,6 +113,9 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wih[g][ks], ks == 0 ? biasv[g] : acc[g], 0, 0, 0);
+        // next step's counts: requested from inside the MFMA stream (a load costs ~60 cycles of issue outside it)
+        if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1, xn);
+        __builtin_amdgcn_sched_barrier(0);
         if (step > 0) {  // gates += h_{t-1} W_hh^T, h_{-1} = 0
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
