@@ -81,40 +81,57 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_kernel(Conv1Params p) {
             }
     };
 
+    // Software pipeline over the groups of a wave: the 9 loads of group g+1 and the 32 stores of group g-1 are issued
+    // BETWEEN the MFMAs of group g (a vector-memory instruction costs ~60 cycles of issue when the wave has nothing else
+    // to do, next to nothing inside an MFMA stream -- DESIGN.md 3.7); the two accumulator sets swap roles by name.
+    // ReLU is a signed-integer max of the bit pattern (one v_max_i32; fmaxf would first canonicalise the MFMA result
+    // with a second v_max_f32).  The row offset stays in the VECTOR offset: (a) the descriptor's range check then drops
+    // the surplus rows of the last, partial group; (b) a store whose scalar offset is a REGISTER reads its data register
+    // late on gfx950 and the compiler does not pad that case (29 % of the outputs were wrong that way).
+    auto store_one = [&](const f32x16 (&r)[2], uint32_t o0, int idx) __attribute__((always_inline)) {
+        const int cb = idx >> 4, v = idx & 15;
+        const uint32_t off = o0 + (uint32_t)(((v & 3) + 8 * (v >> 2)) * 256 + cb * 128);
+        const float val = r[cb][v];  // (bit-casting the vector element expression directly is miscompiled: element 0 every time)
+        const int relu = max(__float_as_int(val), 0);
+        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)relu, orsrc, off, 0, 0);
+    };
     uint32_t d[9];
     request(gw, d);
-    for (int g = gw; g < p.groups; g += nw) {
+    auto body = [&](int g, f32x16 (&acc)[2], const f32x16 (&prev)[2], uint32_t prev_o0) __attribute__((always_inline)) {
         // int8 -> fp32: byte j of tap t is the A operand of k-step 4t + j
         float a[36];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[4 * t + j] = (float)(int8_t)(d[t] >> (8 * j));
-        if (g + nw < p.groups) request(g + nw, d);  // flies under the MFMAs below
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc[2];
 #pragma unroll
-        for (int s = 0; s < 36; ++s)
+        for (int s = 0; s < 36; ++s) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
                 acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wf[s][cb], s == 0 ? biasv[cb] : acc[cb], 0, 0, 0);
-        // ReLU + store: acc[cb][v] is pixel row (v & 3) + 8 (v >> 2) + 4 kk, cout 32 cb + m
-        const uint32_t o0 = (uint32_t)((g * 32 + 4 * kk) * 256 + m * 4);
-        const uint32_t o1 = o0 + 16 * 256;
-        // ReLU as a signed-integer max of the bit pattern (one v_max_i32; fmaxf would first canonicalise the MFMA result
-        // with a second v_max_f32).  The row offset stays in the VECTOR offset: (a) the descriptor's range check then drops
-        // the surplus rows of the last, partial group; (b) a store whose scalar offset is a REGISTER reads its data
-        // register late on gfx950 and the compiler does not pad that case -- the next v_max_i32 into the same register
-        // corrupted 29 % of the outputs when the row offset was passed as soffset.
+            if (s == 1 && g + nw < p.groups) request(g + nw, d);
+            if (s >= 2 && s < 34) store_one(prev, prev_o0, s - 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // acc[cb][v] is pixel row (v & 3) + 8 (v >> 2) + 4 kk of its group, cout 32 cb + m
+    auto out_base = [&](int g) { return (uint32_t)((g * 32 + 4 * kk) * 256 + m * 4); };
+    f32x16 accA[2], accB[2];
+    uint32_t prev_o0 = 0x80000000u;  // nothing to store yet: out of range, dropped
+    int g = gw;
+    for (; g + nw < p.groups; g += 2 * nw) {
+        body(g, accA, accB, prev_o0);
+        body(g + nw, accB, accA, out_base(g));
+        prev_o0 = out_base(g + nw);
+    }
+    if (g < p.groups) {
+        body(g, accA, accB, prev_o0);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int i = 0; i < 32; ++i) store_one(accA, out_base(g), i);
+    } else {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const uint32_t off = (v < 8 ? o0 : o1) + (uint32_t)(((v & 3) + 8 * ((v >> 2) & 1)) * 256 + cb * 128);
-                const float val = acc[cb][v];  // (bit-casting the vector element expression directly is miscompiled: element 0 every time)
-                const int relu = max(__float_as_int(val), 0);
-                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)relu, orsrc, off, 0, 0);
-            }
+        for (int i = 0; i < 32; ++i) store_one(accB, prev_o0, i);
     }
 }
 
