@@ -308,6 +308,18 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
+    // ABL bit6 (64, tools/mfma_probe only): workgroup 0 records the shader clock at phase boundaries into ep.res
+    int tr_n = 0;
+    auto trace = [&](int tag) __attribute__((always_inline)) {
+        if constexpr (ABL & 64) {
+            if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && tr_n < 250) {
+                long long *tb = reinterpret_cast<long long *>(const_cast<float *>(ep.res)) + ((threadIdx.x >> 6) * 256 + tr_n) * 2;
+                tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
+                ++tr_n;
+            }
+        }
+    };
+    trace(10);
     // Software pipeline over K chunks, two register stages + two LDS stages, branch-free body:
     //   iteration kc:  issue global loads of chunk kc+2          (-> rawB / rbB, land during this iteration)
     //                  write chunk kc+1 (loaded LAST iteration)   (rawA / rbA -> LDS[nxt], no wait needed)
@@ -345,6 +357,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
             for (int i = 0; i < RBt; ++i) bNext[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)k2 * kBK);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the global loads at the top: they must fly during the MFMAs
+        trace(1);  // global loads issued
         if constexpr (!(ABL & 2)) {
             loader.finish(rCur, ra);
 #pragma unroll
@@ -353,6 +366,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
             for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_b[i]) = bCur[i];
         }
 
+        trace(2);  // previous chunk's registers staged to LDS (issue)
         // fragments of k-group g+1 are read from LDS while the MFMAs of group g run
         f32x4 a[2][RB], b[2][CB];
         if constexpr (ABL & 8) {  // stale-register operands, kept opaque so nothing is folded away
@@ -385,9 +399,11 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int c = 0; c < CB; ++c)
-                        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][j], b[g & 1][c][j], acc[i][c], 0, 0, 0);
+                        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][c][j], a[g & 1][i][j], acc[i][c], 0, 0, 0);
         }
+        trace(3);  // MFMAs issued
         if constexpr (!(ABL & 4)) __syncthreads();
+        trace(4);
     };
     // unrolled by two so the register stages swap roles by name (no copies: a copy would be a use of the
     // in-flight loads and stall on them)
@@ -398,29 +414,37 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
     }
     if (kc <= last) body(kc, rawA, rbA, rawB, rbB);
 
-    // epilogue.  C/D map of 32x32x2: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+    // epilogue.  The MFMAs above take the weight fragment as the FIRST operand, so each accumulator holds its 32x32
+    // block transposed: C/D map of 32x32x2 = col lane&31 -> output ROW m, row (v&3) + 8*(v>>2) + 4*(lane>>5) -> output
+    // COLUMN n.  A lane therefore owns 4 consecutive n for one m per v>>2: 16-byte stores (4 per block instead of 16
+    // dword stores), f32x4 bias / residual loads, no per-element branch (rows beyond M get an out-of-range buffer
+    // offset), 32-bit offsets.  The tile epilogue was 18 of a conv3 tile's 110 kcycles (shader-clock trace).
     float *cbase = ep.c + (EPI == EPI_PARTIAL ? (int64_t)split * ep.split_stride : 0);
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, (uint32_t)((int64_t)gp.M * ep.ldc * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(EPI == EPI_BIAS_RES_RELU ? ep.res : ep.c), 0, (uint32_t)((int64_t)gp.M * ep.ldc * 4), 0x00020000);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int c = 0; c < CB; ++c) {
-        const int n = n0 + wn * (BN / 2) + c * 32 + (lane & 31);
-        float bias = 0.f;
-        if (EPI != EPI_PARTIAL) bias = ep.bias[n];
+    for (int i = 0; i < RB; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int mrow0 = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+        for (int c = 0; c < CB; ++c) {
+            const int nb = n0 + wn * (BN / 2) + c * 32 + 4 * (lane >> 5);
+            const uint32_t off = m < gp.M ? (uint32_t)(((int64_t)m * ep.ldc + nb) * 4) : 0x80000000u;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int m = mrow0 + (v & 3) + 8 * (v >> 2);
-                if (m < gp.M) {
-                    float val = acc[i][c][v] + bias;
-                    const int64_t idx = (int64_t)m * ep.ldc + n;
-                    if (EPI == EPI_BIAS_RES_RELU) val += ep.res[idx];
-                    if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) val = fmaxf(val, 0.f);
-                    cbase[idx] = val;
+            for (int q = 0; q < 4; ++q) {  // columns nb + 8q .. nb + 8q + 3
+                f32x4 val = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
+                if (EPI != EPI_PARTIAL) val += *reinterpret_cast<const f32x4 *>(ep.bias + nb + 8 * q);
+                if (EPI == EPI_BIAS_RES_RELU) val += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off + 32 * q, 0, 0));
+                if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __int_as_float(max(__float_as_int(val[e]), 0));
                 }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), crsrc, off + 32 * q, 0, 0);
             }
         }
     }
+    trace(12);  // epilogue stores issued
 }
 
 }  // namespace c3

@@ -56,6 +56,7 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
 "; done ;;
+    gtrace) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -w tools/gemm_trace.hip -o /tmp/gemm_trace && timeout 300 /tmp/gemm_trace > gpurun_out/gemm_trace.txt 2>&1; echo "gtrace rc=$?"; cut -c1-1200 gpurun_out/gemm_trace.txt ;;
     convbn) for v in 0 0x8 0x40 0x48; do echo "== C3HIP_CONV_BN64MASK=$v"; C3HIP_CONV_BN64MASK=$v timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchc1.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
