@@ -1,0 +1,134 @@
+// c3_decode.h -- SURVEY 8f N1, first slice: the arithmetic of the reference decoder on the device.
+//
+// For every probability row, clair3/CallVariants.py:510-659 (possible_outcome_probabilites_from) enumerates the joint
+// probabilities of ten outcome classes -- with the indel-length heads ~800 float32 products per row, in pure Python
+// (3.8 k rows/s/core measured in SURVEY 8a A7) -- and output_from (:676-741) only ever looks at the maximum of each
+// class list, at which class lists contain the overall maximum, and at the position of that maximum in its list.
+// This kernel produces exactly those: per row and class the maximum and the index of its FIRST occurrence in the
+// reference's enumeration order, plus the homo-reference early-exit test (:532-534 / :573-576).  Products are formed
+// in the reference's order with one float32 rounding each (numpy float32 scalars): bit-identical values, so
+// `maximum in class_list` in the reference is `class_max == overall_max` here.  Allele strings, alt_info handling and
+// the retry loop of output_from stay in Python.
+//
+// Classes, in the order of the reference's max(...) call (:722-733):
+//   0 homo_Ref (1)          1 homo_SNP (4: AA CC GG TT)      2 hetero_SNP (6: AC AG AT CG CT GT)
+//   3 homo_Ins (16|1)       4 homo_Del (16|1)                5 hetero_ACGT_Ins (64|4: length-major, base A C G T)
+//   6 hetero_InsIns (136|1: i <= j, i outer)                 7 hetero_ACGT_Del (64|4)
+//   8 hetero_DelDel (241|1: i, j in 1..16, i == j only for 16)   9 hetero_InsDel (256|1: deletion length outer)
+// (list lengths with | without --add_indel_length).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c3 {
+
+struct DecodeParams {
+    const float *y;         // [B][24 | 90]
+    const uint8_t *ref21;   // [B] gt21 index of (ref, ref): 0 AA, 4 CC, 7 GG, 9 TT
+    float *maxp;            // [B][10]
+    int32_t *argmax;        // [B][10]
+    uint8_t *early;         // [B] 1 = the reference returns [homo_Ref_probability] without enumerating
+    int B, indel;
+};
+
+constexpr int kDecodeClasses = 10;
+
+// one wave per row; candidates of a class are dealt to the lanes in enumeration order, then a 64-lane max with
+// smallest-index tie-break (key = value bits << 32 | ~index: probabilities are >= 0, so float order == bit order)
+__global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B) return;
+    const int ncol = p.indel ? 90 : 24;
+    const float *y = p.y + (int64_t)row * ncol;
+    const float *g = y, *z = y + 21, *p1 = y + 24, *p2 = y + 57;
+    const int ref = p.ref21[row];
+    const float hr = z[0], hv = z[1], ht = z[2];
+
+    auto reduce_store = [&](int cls, unsigned long long key) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned long long o = __shfl_xor(key, m);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) {
+            p.maxp[(int64_t)row * kDecodeClasses + cls] = __uint_as_float((unsigned)(key >> 32));
+            p.argmax[(int64_t)row * kDecodeClasses + cls] = (int32_t)(~(unsigned)key);
+        }
+    };
+    auto mk = [](float v, int idx) { return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)~idx; };
+    const unsigned long long none = 0ull;  // below every real candidate (idx 0xffffffff never occurs)
+
+    if (!p.indel) {
+        if (lane == 0) p.early[row] = hr >= 0.5f && g[ref] >= 0.5f;
+        const int hsnp[4] = {0, 4, 7, 9}, tsnp[6] = {1, 2, 3, 5, 6, 8};
+        reduce_store(0, lane == 0 ? mk(__fmul_rn(hr, g[ref]), 0) : none);
+        reduce_store(1, lane < 4 ? mk(__fmul_rn(hv, g[hsnp[lane & 3]]), lane) : none);
+        reduce_store(2, lane < 6 ? mk(__fmul_rn(ht, g[tsnp[lane < 6 ? lane : 0]]), lane) : none);
+        reduce_store(3, lane == 0 ? mk(__fmul_rn(hv, g[15]), 0) : none);
+        reduce_store(4, lane == 0 ? mk(__fmul_rn(hv, g[10]), 0) : none);
+        reduce_store(5, lane < 4 ? mk(__fmul_rn(g[16 + (lane & 3)], ht), lane) : none);
+        reduce_store(6, lane == 0 ? mk(__fmul_rn(ht, g[15]), 0) : none);
+        reduce_store(7, lane < 4 ? mk(__fmul_rn(g[11 + (lane & 3)], ht), lane) : none);
+        reduce_store(8, lane == 0 ? mk(__fmul_rn(ht, g[10]), 0) : none);
+        reduce_store(9, lane == 0 ? mk(__fmul_rn(ht, g[20]), 0) : none);
+        return;
+    }
+
+    const float v0 = __fmul_rn(p1[16], p2[16]);
+    if (lane == 0) p.early[row] = p1[16] >= 0.5f && p2[16] >= 0.5f && hr >= 0.5f && g[ref] >= 0.5f;
+    {
+        const int hsnp[4] = {0, 4, 7, 9}, tsnp[6] = {1, 2, 3, 5, 6, 8};
+        reduce_store(0, lane == 0 ? mk(__fmul_rn(__fmul_rn(v0, hr), g[ref]), 0) : none);
+        reduce_store(1, lane < 4 ? mk(__fmul_rn(__fmul_rn(v0, hv), g[hsnp[lane & 3]]), lane) : none);
+        reduce_store(2, lane < 6 ? mk(__fmul_rn(__fmul_rn(v0, ht), g[tsnp[lane < 6 ? lane : 0]]), lane) : none);
+    }
+    {   // homo_Ins / homo_Del: i = 1..16
+        const int i = (lane & 15) + 1;
+        const float xi = __fmul_rn(hv, g[15]), xd = __fmul_rn(hv, g[10]);
+        reduce_store(3, lane < 16 ? mk(__fmul_rn(__fmul_rn(p1[16 + i], p2[16 + i]), xi), lane) : none);
+        reduce_store(4, lane < 16 ? mk(__fmul_rn(__fmul_rn(p1[16 - i], p2[16 - i]), xd), lane) : none);
+    }
+    {   // hetero_ACGT_Ins / _Del: index = (i-1)*4 + base, 64 candidates = one per lane
+        const int i = (lane >> 2) + 1, b = lane & 3;
+        reduce_store(5, mk(__fmul_rn(__fmul_rn(__fmul_rn(p1[16], p2[16 + i]), g[16 + b]), ht), lane));
+        reduce_store(7, mk(__fmul_rn(__fmul_rn(__fmul_rn(p1[16 - i], p2[16]), g[11 + b]), ht), lane));
+    }
+    {   // hetero_InsIns: (i, j), j >= i, i outer: 136 candidates
+        const float x = __fmul_rn(ht, g[15]);
+        unsigned long long key = none;
+        for (int c = lane; c < 136; c += 64) {
+            int i = 1, rem = c;  // row i of the triangle has 17 - i entries
+            while (rem >= 17 - i) rem -= 17 - i, ++i;
+            const int j = i + rem;
+            const unsigned long long k2 = mk(__fmul_rn(__fmul_rn(p1[16 + i], p2[16 + j]), x), c);
+            key = k2 > key ? k2 : key;
+        }
+        reduce_store(6, key);
+    }
+    {   // hetero_DelDel: i outer, j inner, (i == j) skipped unless i == 16: 241 candidates
+        const float x = __fmul_rn(ht, g[10]);
+        unsigned long long key = none;
+        for (int c = lane; c < 256; c += 64) {
+            const int i = (c >> 4) + 1, j = (c & 15) + 1;
+            if (i == j && i != 16) continue;
+            // list position = c minus the diagonal entries skipped before (i, j): one per earlier row, plus this row's if j > i
+            const int skipped = (i - 1) + (j > i && i != 16 ? 1 : 0);
+            const unsigned long long k2 = mk(__fmul_rn(__fmul_rn(p1[16 - i], p2[16 - j]), x), c - skipped);
+            key = k2 > key ? k2 : key;
+        }
+        reduce_store(8, key);
+    }
+    {   // hetero_InsDel: deletion length i outer, insertion length j inner: 256 candidates
+        const float x = __fmul_rn(ht, g[20]);
+        unsigned long long key = none;
+        for (int c = lane; c < 256; c += 64) {
+            const int i = (c >> 4) + 1, j = (c & 15) + 1;
+            const unsigned long long k2 = mk(__fmul_rn(__fmul_rn(p1[16 - i], p2[16 + j]), x), c);
+            key = k2 > key ? k2 : key;
+        }
+        reduce_store(9, key);
+    }
+}
+
+}  // namespace c3

@@ -21,6 +21,7 @@
 #include "c3_conv1.h"
 #include "c3_tail.h"
 #include "c3_proj.h"
+#include "c3_decode.h"
 #include "c3_lstm_fused.h"
 
 using namespace c3;
@@ -111,6 +112,8 @@ struct c3_model {
     // transform is recomputed for each of 8 N-tiles).  v2 (one workgroup per CU, transform interleaved into the MFMA
     // stream) is 10-15 % slower than v1 on res1/res2 and equal on res3; it stays selectable for experiments.
     unsigned conv_bn64_mask = 0x40; // direct-conv layers on 128x64 tiles instead of 128x128 (conv5: 480 workgroups fill 2 per CU); env C3HIP_CONV_BN64MASK
+    void *decode_dev = nullptr;     // scratch of c3_outcome_maxima
+    size_t decode_bytes = 0;
     bool conv1_direct = true;       // 8-channel conv1 through conv1_i8_kernel (c3_conv1.h); env C3HIP_CONV1_DIRECT
     float *conv1_wfrag = nullptr;   // its resident B fragments [36][2][64]
     unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
@@ -1008,6 +1011,43 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
     return 0;
 }
 
+int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uint8_t *ref21_host, float *maxp_host,
+                      int32_t *argmax_host, uint8_t *early_host) {
+    if (!m) return fail("null model");
+    if (batch < 0) return fail("negative batch");
+    if (batch == 0) return 0;
+    if (!y_host || !ref21_host || !maxp_host || !argmax_host || !early_host) return fail("null buffer");
+    for (int64_t i = 0; i < batch; ++i)
+        if (ref21_host[i] != 0 && ref21_host[i] != 4 && ref21_host[i] != 7 && ref21_host[i] != 9)
+            return fail("row %lld: reference gt21 index %d is not one of AA=0, CC=4, GG=7, TT=9", (long long)i, (int)ref21_host[i]);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t yb = (size_t)batch * m->nout * sizeof(float), rb = ((size_t)batch + 255) & ~(size_t)255;
+    const size_t mb = (size_t)batch * kDecodeClasses * sizeof(float);
+    const size_t total = yb + rb + 2 * mb + rb;
+    if (m->decode_bytes < total) {
+        if (m->decode_dev) (void)hipFree(m->decode_dev);
+        m->decode_dev = nullptr, m->decode_bytes = 0;
+        HIP_TRY(hipMalloc(&m->decode_dev, total));
+        m->decode_bytes = total;
+    }
+    char *base = (char *)m->decode_dev;
+    float *y = (float *)base;
+    uint8_t *ref = (uint8_t *)(base + yb);
+    float *maxp = (float *)(base + yb + rb);
+    int32_t *arg = (int32_t *)(base + yb + rb + mb);
+    uint8_t *early = (uint8_t *)(base + yb + rb + 2 * mb);
+    HIP_TRY(hipMemcpyAsync(y, y_host, yb, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(ref, ref21_host, (size_t)batch, hipMemcpyHostToDevice, m->stream));
+    DecodeParams dp{y, ref, maxp, arg, early, (int)batch, m->nout == 90 ? 1 : 0};
+    hipLaunchKernelGGL(outcome_maxima_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(maxp_host, maxp, mb, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(argmax_host, arg, mb, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(early_host, early, (size_t)batch, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
 int c3_model_synchronize(c3_model *m) {
     if (!m) return fail("null model");
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1024,6 +1064,7 @@ int c3_model_destroy(c3_model *m) {
                    m->conv1_wfrag, m->w5f, m->whf, m->bh48, m->proj2_frag};
     for (float *p : ws)
         if (p) (void)hipFree(p);
+    if (m->decode_dev) (void)hipFree(m->decode_dev);
     for (int l = 0; l < 9; ++l) {
         if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);

@@ -103,6 +103,19 @@ int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch
  * Equivalent to c3_predict on the sliced windows, bit for bit; candidate filtering stays with the caller. */
 int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, int64_t n_cols, const int32_t *starts_host,
                              int64_t batch, float *y_host);
+/* SURVEY 8f N1 (first slice): the arithmetic of the reference decoder, clair3/CallVariants.py:510-659
+ * (possible_outcome_probabilites_from).  For every probability row y_host[b] (24 or 90 floats, as produced by
+ * c3_predict) and the gt21 index of its reference base pair ref21_host[b] (0 AA, 4 CC, 7 GG, 9 TT -- reference_gt21 at
+ * :520,:570), computes for the ten outcome classes in the order of the reference's max(...) call (:722-733: homo_Ref,
+ * homo_SNP, hetero_SNP, homo_Ins, homo_Del, hetero_ACGT_Ins, hetero_InsIns, hetero_ACGT_Del, hetero_DelDel,
+ * hetero_InsDel) the maximum of the class's probability list and the position of its first occurrence in the
+ * reference's enumeration order, plus early_host[b] = 1 where the reference takes the homo-reference early exit
+ * (:532-534, :573-576).  Products are float32 in the reference's multiplication order: the values are bit-identical
+ * to the numpy float32 scalars of the reference, so `maximum_probability in <class list>` (:741-749) equals
+ * `maxp[b][class] == max over classes`.  Allele strings, alt_info and the retry loop stay in Python.
+ * maxp_host: [batch][10] float, argmax_host: [batch][10] int32, early_host: [batch] bytes.  Synchronous. */
+int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uint8_t *ref21_host, float *maxp_host,
+                      int32_t *argmax_host, uint8_t *early_host);
 /* blocks until everything enqueued on the model's own stream has finished */
 int c3_model_synchronize(c3_model *m);
 int c3_model_destroy(c3_model *m);

@@ -1,0 +1,65 @@
+"""CPU restatement of the reference decoder's probability enumeration -- TEST INFRASTRUCTURE ONLY.
+
+Follows clair3/CallVariants.py:510-659 (possible_outcome_probabilites_from) and the tuple builders :303-372 with
+numpy float32 scalars, i.e. one float32 rounding per product in the reference's multiplication order, and reduces every
+class list the way output_from (:722-749) uses it: max() (first maximal element) and list.index().  Pinned: the golden
+fixture tests/golden/decode_*.npz holds the lists' maxima as computed by the REAL reference function
+(tests/golden/make_golden_decode.py); tests/test_decode.py checks this file against it bit for bit.
+"""
+import numpy as np
+
+OFF = 16  # VariantLength.index_offset
+
+
+def _first_max(values):
+    best, pos = values[0], 0
+    for i, v in enumerate(values):
+        if v > best:
+            best, pos = v, i
+    return best, pos
+
+
+def outcome_lists(row, ref21, add_indel_length):
+    """The ten class lists of one row, in the order of the reference's max(...) call."""
+    f = np.float32
+    g = [f(v) for v in row[:21]]
+    hr, hv, ht = f(row[21]), f(row[22]), f(row[23])
+    hs, ts = (0, 4, 7, 9), (1, 2, 3, 5, 6, 8)
+    if not add_indel_length:  # :526-566
+        return [[hr * g[ref21]], [hv * g[k] for k in hs], [ht * g[k] for k in ts], [hv * g[15]], [hv * g[10]],
+                [g[16 + b] * ht for b in range(4)], [ht * g[15]], [g[11 + b] * ht for b in range(4)], [ht * g[10]],
+                [ht * g[20]]]
+    p1 = [f(v) for v in row[24:57]]
+    p2 = [f(v) for v in row[57:90]]
+    v0 = p1[OFF] * p2[OFF]
+    xi, xd = hv * g[15], hv * g[10]
+    yi, yd, yx = ht * g[15], ht * g[10], ht * g[20]
+    R = range(1, 17)
+    return [
+        [v0 * hr * g[ref21]],                                                                   # :571-573
+        [v0 * hv * g[k] for k in hs],                                                           # :579-581
+        [v0 * ht * g[k] for k in ts],                                                           # :582-584
+        [p1[OFF + i] * p2[OFF + i] * xi for i in R],                                            # :303-308
+        [p1[OFF - i] * p2[OFF - i] * xd for i in R],                                            # :331-336
+        [p1[OFF] * p2[OFF + i] * g[16 + b] * ht for i in R for b in range(4)],                  # :311-316, :600-607
+        [p1[OFF + i] * p2[OFF + j] * yi for i in R for j in range(i, 17)],                      # :318-328
+        [p1[OFF - i] * p2[OFF] * g[11 + b] * ht for i in R for b in range(4)],                  # :339-345, :627-634
+        [p1[OFF - i] * p2[OFF - j] * yd for i in R for j in R if not (i == j and i != 16)],     # :348-359
+        [p1[OFF - i] * p2[OFF + j] * yx for i in R for j in R],                                 # :362-371
+    ]
+
+
+def outcome_maxima(y, ref21, add_indel_length):
+    y = np.asarray(y, dtype=np.float32)
+    maxp = np.zeros((len(y), 10), dtype=np.float32)
+    arg = np.zeros((len(y), 10), dtype=np.int32)
+    early = np.zeros(len(y), dtype=bool)
+    for r, row in enumerate(y):
+        k = int(ref21[r])
+        for c, lst in enumerate(outcome_lists(row, k, add_indel_length)):
+            maxp[r, c], arg[r, c] = _first_max(lst)
+        if add_indel_length:  # :573-576
+            early[r] = row[24 + OFF] >= 0.5 and row[57 + OFF] >= 0.5 and row[21] >= 0.5 and row[k] >= 0.5
+        else:                 # :532-534
+            early[r] = row[21] >= 0.5 and row[k] >= 0.5
+    return maxp, arg, early

@@ -1,0 +1,98 @@
+"""SURVEY 8f N1 (decode slice): the class maxima the reference's decoder derives from a probability row.
+
+CPU: the numpy restatement (oracle/decode_oracle.py) against goldens produced by the real reference function
+(tests/golden/make_golden_decode.py), bit for bit; the host-side tables of clair3_amd.decode against the enumeration.
+GPU: c3_outcome_maxima through the C ABI against the same goldens and against the oracle on larger seeded sets.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import decode_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def golden(indel):
+    return np.load(os.path.join(HERE, "golden", "decode_indel.npz" if indel else "decode_noindel.npz"))
+
+
+def check_against_golden(maxp, arg, early, g):
+    assert np.array_equal(early, g["early"])
+    live = ~g["early"]  # the reference returns before enumerating on an early exit: only class 0 is defined there
+    assert np.array_equal(maxp[live].view(np.uint32), g["maxp"][live].view(np.uint32)), "class maxima differ from the reference"
+    assert np.array_equal(arg[live], g["argmax"][live]), "positions of the maxima differ from the reference"
+    assert np.array_equal(maxp[~live, 0].view(np.uint32), g["maxp"][~live, 0].view(np.uint32))
+
+
+@pytest.mark.parametrize("indel", [True, False])
+def test_oracle_matches_reference_goldens(indel):
+    g = golden(indel)
+    maxp, arg, early = decode_oracle.outcome_maxima(g["y"], g["ref21"], indel)
+    assert early.sum() >= 5 and (~early).sum() >= 80  # both branches are exercised
+    check_against_golden(maxp, arg, early, g)
+
+
+def test_class_entry_tables_follow_the_reference_enumeration():
+    from clair3_amd import decode
+    assert len(decode._INSINS) == 136 and len(decode._DELDEL) == 241 and len(decode._INSDEL) == 256
+    assert decode.class_entry(6, 0) == (1, 1) and decode.class_entry(6, 135) == (16, 16)
+    assert decode.class_entry(8, 0) == (1, 2) and decode.class_entry(8, 240) == (16, 16)
+    assert decode.class_entry(8, 15) == (1, 2)  # (2, 1) is stored as (1, 2): CallVariants.py:354
+    assert decode.class_entry(5, 5) == ("C", 2) and decode.class_entry(3, 15) == 16
+    assert decode.class_entry(5, 2, add_indel_length=False) == "G" and decode.class_entry(1, 3) == 9
+    assert np.array_equal(decode.ref_gt21_indices("ACGT"), [0, 4, 7, 9])
+
+
+def _model(indel):
+    from clair3_amd import synthetic as syn
+    from clair3_amd.model import Clair3_F, Clair3_P
+    if indel:
+        m = Clair3_F(add_indel_length=True, predict=True, input_channels=8).to("cuda:0")
+        m.load_state_dict(syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=0))
+    else:
+        m = Clair3_P(add_indel_length=False, predict=True).to("cuda:0")
+        m.load_state_dict(syn.make_state_dict(syn.PILEUP, 18, False, seed=0))
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("indel", [True, False])
+def test_kernel_matches_reference_goldens(indel):
+    from clair3_amd import decode
+    g = golden(indel)
+    maxp, arg, early = decode.outcome_maxima(_model(indel), g["y"], g["ref21"])
+    check_against_golden(maxp, arg, early, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("indel", [True, False])
+def test_kernel_matches_oracle_on_model_rows(indel):
+    """Rows produced by the networks themselves (incl. a ragged count), reference bases cycling through ACGT."""
+    from clair3_amd import decode, synthetic as syn
+    m = _model(indel)
+    x = syn.make_windows(syn.FULL_ALIGNMENT if indel else syn.PILEUP, 203, seed=5, channels=8 if indel else 18)
+    y = m.predict_numpy(x)
+    ref = "".join("ACGT"[(3 * i) % 4] for i in range(len(y)))
+    maxp, arg, early = decode.outcome_maxima(m, y, ref)
+    o_maxp, o_arg, o_early = decode_oracle.outcome_maxima(y, decode.ref_gt21_indices(ref), indel)
+    assert np.array_equal(early, o_early)
+    assert np.array_equal(maxp.view(np.uint32), o_maxp.view(np.uint32))
+    assert np.array_equal(arg, o_arg)
+    # the overall maximum sits in at least one class, and the kernel agrees with the oracle on which
+    best = maxp.max(axis=1, keepdims=True)
+    assert np.array_equal(maxp == best, o_maxp == o_maxp.max(axis=1, keepdims=True))
+
+
+@pytest.mark.gpu
+def test_outcome_maxima_rejects_bad_arguments():
+    from clair3_amd import _lib, decode
+    m = _model(False)
+    y = np.full((3, 24), 1.0 / 24, dtype=np.float32)
+    with pytest.raises(_lib.C3Error):
+        decode.outcome_maxima(m, y, np.array([0, 1, 4], dtype=np.uint8))  # 1 = AC is not a reference base pair
+    with pytest.raises(_lib.C3Error):
+        decode.outcome_maxima(m, y[:, :20], "ACG")
+    maxp, arg, early = decode.outcome_maxima(m, y[:0], "")
+    assert maxp.shape == (0, 10) and early.shape == (0,)

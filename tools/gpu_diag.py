@@ -117,6 +117,29 @@ def host_path():
         print(f"  {kind:15s} B={B}: c3_predict (sync) {sync:,.0f} | submit/wait, 1 handle {one:,.0f} | submit/wait, 2 handles {two:,.0f} windows/s", flush=True)
 
 
+def decode_rate():
+    """Rows/s of c3_outcome_maxima (host rows in, class maxima out, copies included) next to the numpy restatement of the
+    reference's Python enumeration (oracle/decode_oracle.py, one core) on the same rows."""
+    from clair3_amd import decode
+    from oracle import decode_oracle
+    print("== decode slice (SURVEY 8f N1): class maxima per probability row")
+    for kind, ch, indel, n in ((syn.FULL_ALIGNMENT, 8, True, 16384), (syn.PILEUP, 18, False, 16384)):
+        cls = Clair3_P if kind == syn.PILEUP else Clair3_F
+        m = cls(add_indel_length=indel, predict=True, input_channels=ch).to("cuda:0")
+        m.load_state_dict(syn.make_state_dict(kind, ch, indel, seed=0))
+        y = np.tile(m.predict_numpy(syn.make_windows(kind, 512, seed=2)), (n // 512, 1))
+        ref = np.resize(np.array([0, 4, 7, 9], dtype=np.uint8), n)
+        decode.outcome_maxima(m, y, ref)
+        t = time.time()
+        for _ in range(10):
+            decode.outcome_maxima(m, y, ref)
+        gpu = 10 * n / (time.time() - t)
+        t = time.time()
+        decode_oracle.outcome_maxima(y[:256], ref[:256], indel)
+        cpu = 256 / (time.time() - t)
+        print(f"  {kind:15s} {n} rows x {y.shape[1]} floats: c3_outcome_maxima {gpu:,.0f} rows/s | python enumeration {cpu:,.0f} rows/s/core", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["fa", "fa9", "pileup", "pileup32", "time"]
     for w in what:
@@ -133,5 +156,7 @@ if __name__ == "__main__":
                 quick_timing()
             elif w == "host":
                 host_path()
+            elif w == "decode":
+                decode_rate()
         except Exception as e:  # keep going: the point is to collect as much as possible per GPU call
             print(f"!! {w} failed: {type(e).__name__}: {e}", flush=True)

@@ -80,6 +80,7 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  FA %.0f windows/s  %.4f ms/step | pileup %.0f windows/s %.4f ms/step' % (d['value'], d['ms_per_step'], d['pileup']['value'], d['pileup']['ms_per_step']))
 "; done ;;
+    decode) timeout 600 python tools/gpu_diag.py decode > gpurun_out/decode.txt 2>&1; echo "decode rc=$?"; cat gpurun_out/decode.txt ;;
     host) timeout 600 python tools/gpu_diag.py host > gpurun_out/host.txt 2>&1; echo "host rc=$?"; cat gpurun_out/host.txt ;;
     diagp) timeout 600 python tools/gpu_diag.py pileup pileup32 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
     benchp) for v in 0 1; do echo "== C3HIP_LSTM1_FUSED=$v"; C3HIP_LSTM1_FUSED=$v timeout 600 python bench.py --gpus 1 --workload pileup --no-cpu-baseline 2> gpurun_out/benchp.err | python -c "
