@@ -120,7 +120,6 @@ struct c3_model {
     int wg_slots = 512;             // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
     unsigned wino_n64_mask = 0x1b6; // layers using the 32-tile x 64-cout workgroup shape; env C3HIP_WINOGRAD_N64MASK
     bool lstm2_v2 = true;        // env C3HIP_LSTM2_V2=0 selects the streaming 10-wave kernel
-    int wino_stagger = 0;        // env C3HIP_WINOGRAD_STAGGER (units of 64 clocks)
     unsigned wino_mask = 0x1b6;  // layers run as Winograd (bit l): all six stride-1 convs; env C3HIP_WINOGRAD overrides
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
@@ -577,7 +576,6 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             wp.B = (int)n, wp.H = hh[l], wp.W = ww[l], wp.Cin = cin, wp.Cout = Cout;
             wp.th = (hh[l] + 1) / 2, wp.tw = (ww[l] + 1) / 2, wp.P = (int)n * wp.th * wp.tw;
             wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
-            wp.stagger = m->wino_stagger;
             if ((m->wino_p_mask & (1u << l)) && Cout % 64 == 0) {  // persistent 32 x 64 workgroups
                 wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
                 const int grid = std::min(wp.tiles, m->wg_slots / wp.tiles_n * wp.tiles_n);
@@ -825,7 +823,6 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
             m->wg_slots = 2 * prop.multiProcessorCount;
     }
     if (const char *e = getenv("C3HIP_WINOGRAD_N64MASK")) m->wino_n64_mask = (unsigned)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("C3HIP_WINOGRAD_STAGGER")) m->wino_stagger = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {

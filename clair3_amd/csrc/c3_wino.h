@@ -17,8 +17,9 @@
 //   * output transform in the epilogue: the 16 M_xi of a (tile, cout) live in four different waves, so they
 //     are exchanged once through the same LDS buffer (two passes of 16 couts), then each thread applies
 //     A^T M A, bias, optional residual and ReLU and stores the 2x2 pixels (edge tiles are clipped).
-// K chunk = 16 cin; the single 64 KiB U buffer means two workgroups per CU, which run out of phase: one
-// transforms (VALU + memory) while the other issues MFMAs.
+// K chunk = 16 cin; the single 64 KiB U buffer means two workgroups per CU.  (They do NOT overlap one's transform with
+// the other's MFMAs -- a wave streaming fp32 MFMAs starves its SIMD partner, DESIGN.md 3.7 -- but their non-MFMA phases
+// overlap each other.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,7 +40,6 @@ struct WinoParams {
     int B, H, W, Cin, Cout;
     int th, tw, P;       // tiles per column / row, total tiles
     int tiles_n, tiles;  // Cout/32, ceil(P/64)*tiles_n
-    int stagger;         // s_sleep units (64 clk) the second workgroup of a CU waits at start, 0 = off
 };
 
 constexpr int kWinoPT = 64;  // tiles per workgroup
@@ -83,18 +83,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoParams p) {
     const int tile = xcd_tile_index(blockIdx.x, p.tiles);
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int p0 = tm * kWinoPT, n0 = tn * kWinoNT;
-    // Two workgroups share a CU and each alternates a transform phase (VALU + memory) with an MFMA phase.
-    // Started together they stay in lockstep (both transform, then both fight for the matrix pipe); delaying
-    // every other workgroup of an XCD's dispatch sequence by about one phase lets them settle in anti-phase.
-    if (p.stagger != 0) {
-        // stagger > 0: every other group of 32 workgroups of an XCD; stagger < 0: every other workgroup of an XCD
-        const int slot = blockIdx.x >> 3;
-        const bool late = p.stagger > 0 ? ((slot >> 5) & 1) : (slot & 1);
-        const int n = p.stagger > 0 ? p.stagger : -p.stagger;
-        if (late)
-            for (int i = 0; i < n; i += 64) __builtin_amdgcn_s_sleep(64);
-    }
-
     // ---- transform role: thread (tl, q) = (tile within block, cin quad within the chunk)
     const int tl = tid >> 2, q = tid & 3;
     // The patch is fetched with buffer loads: one 32-bit byte offset per thread + wave-uniform tap offsets, and

@@ -128,12 +128,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
         }
     };
     if (tm0 >= ngm) return;
-    if (p.stagger > 0) {  // experiment: start the CU's second workgroup (LDS base != 0) late so the two run out of phase
-        unsigned la;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
-        if ((la & 0xff) != 0)
-            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     uint32_t base, okmask;
     setup(tm0, 0, base, okmask);
     f32x2 d[4][4];

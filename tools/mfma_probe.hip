@@ -70,7 +70,6 @@ static float run_wino(const float *x, const float *zeros, const float *v, const 
     wp.B = B, wp.H = H, wp.W = W, wp.Cin = Cin, wp.Cout = Cout;
     wp.th = (H + 1) / 2, wp.tw = (W + 1) / 2, wp.P = B * wp.th * wp.tw;
     wp.tiles_n = Cout / kWinoNT, wp.tiles = ((wp.P + kWinoPT - 1) / kWinoPT) * wp.tiles_n;
-    wp.stagger = 0;
     return time_it([&] { hipLaunchKernelGGL((wino_conv_kernel<false, ABL>), dim3(wp.tiles), dim3(256), 0, 0, wp); });
 }
 

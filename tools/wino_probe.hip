@@ -24,7 +24,6 @@ static WinoParams make(const float *x, const float *zeros, const float *v, const
     wp.B = B, wp.H = H, wp.W = W, wp.Cin = C, wp.Cout = C;
     wp.th = (H + 1) / 2, wp.tw = (W + 1) / 2, wp.P = B * wp.th * wp.tw;
     wp.tiles_n = C / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
-    wp.stagger = 0;
     return wp;
 }
 template <int ABL> static float run_n64(const WinoParams &wp) {
