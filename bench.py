@@ -14,7 +14,7 @@ probability rows to rank 0.  One process per GPU, windows sharded
   value        whole-job candidate-windows/s of the headline workload = BASELINE.json configs[2]
                "ONT r10.4.1 full-alignment model, synthetic (B=256, 89, 33, 8)" (the path the north-star target
                is quoted on); the same measurement for configs[1] (pileup, B=1024) is in "pileup".  By default three
-               batches are kept in flight per GPU (--streams 3: three model handles on three HIP streams, every step
+               batches (pileup: two) are kept in flight per GPU (three model handles on three HIP streams, every step
                still a complete forward over one full batch -- the reference runs several workers per GPU too);
                "one_batch_in_flight" is the same K steps issued strictly one after the other;
   roofline     dominant kernel family (implicit-GEMM 3x3 convolutions on v_mfma_f32_32x32x2_f32), HIP-event
@@ -77,7 +77,7 @@ def run_workload(name, args, rank, world, local):
     # workers per device, clair3/CallVariantsFromCffiGPU.py:55-56).  Kernels that cannot fill 256 CUs on their own
     # (the 33-step LSTM recurrences on 128 workgroups, the 12x5 stage, the FC tail) then overlap the next batch's
     # large kernels.  Every step is still one complete forward pass over one full batch.
-    S = max(args.streams, 1)
+    S = args.streams if args.streams > 0 else (2 if kind == syn.PILEUP else 3)  # measured optimum per workload
     models = [model] + [build_model(kind, channels, indel, local)[0] for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in models]
 
@@ -241,7 +241,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="all", choices=["all"] + list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/experiments only)")
-    ap.add_argument("--streams", type=int, default=3, help="batches kept in flight per GPU (model handles x HIP streams)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="batches kept in flight per GPU (model handles x HIP streams); 0 = 3 for full alignment, 2 for pileup")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", nargs=4, metavar=("WORKLOAD", "THREADS", "BUDGET", "BATCH"), help=argparse.SUPPRESS)

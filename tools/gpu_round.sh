@@ -70,7 +70,7 @@ print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), '
     isolate) for cfg in "0 0" "0 1" "0x40 0"; do set -- $cfg; echo "== BN64MASK=$1 CONV1_DIRECT=$2"; C3HIP_CONV_BN64MASK=$1 C3HIP_CONV1_DIRECT=$2 timeout 600 python tools/gpu_diag.py fa > gpurun_out/iso.txt 2>&1; grep -E "act0|act5|act6|act7|^  y" gpurun_out/iso.txt | cut -c1-150; done ;;
     cmpq) timeout 600 python tools/cmp_variants.py "C3HIP_WINOGRAD_PMASK=0" "C3HIP_WINOGRAD_PMASK=0x1b6" 300 > gpurun_out/cmpq.txt 2>&1; echo "cmpq rc=$?"; grep -E "differ|^y" gpurun_out/cmpq.txt ;;
     diagfap) C3HIP_WINOGRAD_PMASK=0x1b6 timeout 600 python tools/gpu_diag.py fa fa9 > gpurun_out/diagp.txt 2>&1; echo "diag(pmask) rc=$?"; grep -E "act|y " gpurun_out/diagp.txt | head -30 ;;
-    streams) for st in 1 2 3; do echo "== --streams $st"; timeout 600 python bench.py --gpus 1 --no-cpu-baseline --streams $st 2> gpurun_out/benchs.err | python -c "
+    streams) for st in 1 2 3 4; do echo "== --streams $st"; timeout 600 python bench.py --gpus 1 --no-cpu-baseline --streams $st 2> gpurun_out/benchs.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  FA %.0f windows/s  %.4f ms/step | pileup %.0f windows/s %.4f ms/step' % (d['value'], d['ms_per_step'], d['pileup']['value'], d['pileup']['ms_per_step']))
