@@ -172,8 +172,9 @@ __global__ __launch_bounds__(H * 4) void lstm_recurrent_kernel(LstmParams p) {
 // resident (H/32 * H/16 * 4 = 200 VGPRs at H = 160: the whole 400 KiB matrix lives in the CU's register file
 // instead of being re-streamed from L2 every step, which was bandwidth-bound at ~15 B/clk/CU).
 // The price is that i/f/g/o of one unit now sit in different waves: the gate pre-activations go through LDS
-// once per step (16 x 4H floats), then thread (window, unit) applies the cell.  The x-projection of step t+1
-// is loaded straight into the accumulators right after they were stored, so it flies during the cell phase.
+// once per step (16 x 4H floats), then thread (window, units) applies the cell.  The x-projection of step t+1 has
+// exactly the accumulators' layout: it is requested between the MFMAs of step t into spare registers and enters step
+// t+1 as the C operand of the first MFMA of each block.
 struct Lstm2Params {
     const float *gx;   // [B*T][ld_gx]; column = dir*4H + gate*H + unit  (PyTorch gate-row order)
     const float *whh;  // [dir][gate block 4H/16][q = H/16][lane][4]
@@ -192,10 +193,10 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
     constexpr int LDG = 4 * H + 4;    // gate tile row stride (floats, 16-byte multiple)
     constexpr int NP = 16 * H / 512;  // (window, unit) pairs per thread in the cell phase
     constexpr int WCOLS = NB * 16;    // gate columns owned by one wave
-    static_assert((WCOLS * 4) % 16 == 0 && WCOLS * 4 <= 1024, "one DMA piece per row");
-    // ONE LDS object (a second one makes the compiler drain the DMA before every ds_read): manual carve-up
+    static_assert(NP * 32 == H, "cell phase: thread (row = tid >> 5) covers units (tid & 31) + 32 r");
+    // ONE LDS object, carved up by hand
     constexpr int OFF_H = 0;                                 // float hbuf[2][16][LDH]
-    constexpr int OFF_G = OFF_H + 2 * 16 * LDH * 4;          // float gbuf[16][LDG]: x-projection, then gate pre-activations
+    constexpr int OFF_G = OFF_H + 2 * 16 * LDH * 4;          // float gbuf[16][LDG]: gate pre-activations
     constexpr int OFF_W = OFF_G + 16 * LDG * 4;              // float wlds[NQL][8][NB][64][4]
     constexpr int LDS_BYTES = OFF_W + NQL * 8 * NB * 64 * 16;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
