@@ -261,3 +261,43 @@ def test_two_handles_share_a_gpu():
     torch.cuda.synchronize()
     for o, r in zip(outs, ref):
         assert np.array_equal(o.cpu().numpy(), r)
+
+
+def test_model_handles_release_their_device_memory():
+    """c3_model_destroy frees everything the handle allocated (weights, fragments, workspace, staging): creating and
+    dropping handles in a loop must not eat HBM"""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=5)
+    x = syn.make_fa_windows(40, seed=6)
+    make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)  # first use pays one-off runtime allocations
+    free0, _ = _lib.mem_info(0)
+    for _ in range(12):
+        m = make_model(syn.FULL_ALIGNMENT, 8, True, sd)
+        m.predict_numpy(x)
+        del m
+    free1, _ = _lib.mem_info(0)
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of HBM lost over 12 create/predict/destroy cycles"
+
+
+def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracle_mod):
+    """the A/B switches of README.md select older kernels for the same layers: each selection stays within the parity
+    gate (they are what a regression is bisected with, so they must keep working)"""
+    sd_f = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=21)
+    x_f = syn.make_fa_windows(37, seed=22)
+    y_f = oracle_mod.fa_forward(sd_f, x_f, True)
+    sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=23)
+    x_p = syn.make_pileup_windows(70, seed=24)
+    y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
+    fa_sets = [{"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
+               {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"}]
+    for env in fa_sets:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f, what=f"FA {env}")
+        for k in env:
+            monkeypatch.delenv(k)
+    for env in [{"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"}]:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        util.assert_rows_match(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p, what=f"pileup {env}")
+        for k in env:
+            monkeypatch.delenv(k)
