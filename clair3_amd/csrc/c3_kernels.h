@@ -57,6 +57,27 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
+// Two cells at a time on the packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 cost the same 8
+// matrix-pipe cycles as their scalar forms); only the transcendentals stay scalar.
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2g pk_sigmoid(f32x2g x) {
+    const f32x2g e = x * -1.4426950408889634f;
+    const f32x2g d = f32x2g{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + 1.f;
+    return f32x2g{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2g pk_tanh(f32x2g x) {
+    const f32x2g e = x * 2.8853900817779268f;
+    const f32x2g d = f32x2g{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + 1.f;
+    const f32x2g r = f32x2g{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return __builtin_elementwise_fma(r, f32x2g{-2.f, -2.f}, f32x2g{1.f, 1.f});
+}
+// c' = s(f) c + s(i) tanh(g), returns h' = s(o) tanh(c')   (torch.nn.LSTM cell, gate order i, f, g, o)
+__device__ __forceinline__ f32x2g pk_lstm_cell(f32x2g gi, f32x2g gf, f32x2g gg, f32x2g go, f32x2g &c) {
+    const f32x2g ig = pk_sigmoid(gi), fg = pk_sigmoid(gf), gt = pk_tanh(gg), og = pk_sigmoid(go);
+    c = __builtin_elementwise_fma(fg, c, ig * gt);
+    return og * pk_tanh(c);
+}
+
 // RESIDENT: keep this wave's W_hh fragments (4 gates x H/16 k-groups = H registers) in VGPRs for all T steps
 // (H = 128: 8 waves x 2 per SIMD fit the 512-entry file).  Otherwise stream them from L2 every step through
 // a 2-deep register ring so the loads of k-group q+1 fly while the MFMAs of group q issue.
@@ -309,7 +330,20 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
         // cell: c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')   (rows i, f, g, o)
         const uint32_t ho = hobase + (uint32_t)(t * 2 * H * 4);
 #pragma unroll
-        for (int r = 0; r < NP; ++r) {
+        for (int r = 0; r + 1 < NP; r += 2) {  // units cu0 + 32 r and cu0 + 32 (r + 1) as one packed pair
+            const float *g0 = gbase + 32 * r, *g1 = g0 + 32;
+            f32x2g cc = {c[r], c[r + 1]};
+            const f32x2g h = pk_lstm_cell(f32x2g{g0[0], g1[0]}, f32x2g{g0[H], g1[H]}, f32x2g{g0[2 * H], g1[2 * H]},
+                                          f32x2g{g0[3 * H], g1[3 * H]}, cc);
+            c[r] = cc[0], c[r + 1] = cc[1];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                *hb(cur ^ 1, crow, cu0 + 32 * (r + e)) = h[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[e]), hrsrc, ho + 128 * (r + e), 0, 0);
+            }
+        }
+        if (NP & 1) {
+            constexpr int r = NP - 1;
             const float *g = gbase + 32 * r;
             const float ig = fast_sigmoid(g[0]);
             const float fg = fast_sigmoid(g[H]);

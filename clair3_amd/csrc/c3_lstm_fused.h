@@ -128,15 +128,16 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
             }
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float ig = fast_sigmoid(acc[0][v]);
-            const float fg = fast_sigmoid(acc[1][v]);
-            const float gg = fast_tanh(acc[2][v]);
-            const float og = fast_sigmoid(acc[3][v]);
-            c[v] = fg * c[v] + ig * gg;
-            const float h = og * fast_tanh(c[v]);
-            hbuf[cur ^ 1][4 * s + v][wave * 16 + col] = h;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrsrc, ho[v] + (uint32_t)(t * 2 * H * 4), 0, 0);
+        for (int v = 0; v < 4; v += 2) {  // two cells per packed instruction
+            f32x2g cc = {c[v], c[v + 1]};
+            const f32x2g h = pk_lstm_cell(f32x2g{acc[0][v], acc[0][v + 1]}, f32x2g{acc[1][v], acc[1][v + 1]},
+                                          f32x2g{acc[2][v], acc[2][v + 1]}, f32x2g{acc[3][v], acc[3][v + 1]}, cc);
+            c[v] = cc[0], c[v + 1] = cc[1];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                hbuf[cur ^ 1][4 * s + v + e][wave * 16 + col] = h[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[e]), hrsrc, ho[v + e] + (uint32_t)(t * 2 * H * 4), 0, 0);
+            }
         }
         lds_barrier();
     }
