@@ -41,7 +41,10 @@ CASES = [
     ("fa_peaked", syn.FULL_ALIGNMENT, 8, True, 2, True, 2, "realistic", 16, "int8"),
     ("fa_dwell", syn.FULL_ALIGNMENT, 9, True, 3, False, 3, "realistic", 16, "int8"),
     ("fa_no_indel_heads", syn.FULL_ALIGNMENT, 8, False, 4, False, 4, "realistic", 8, "int8"),
+    ("fa_hifi_depth55", syn.FULL_ALIGNMENT, 8, True, 5, False, 5, "realistic", 12, "int8"),
 ]
+# matrix depth of the full-alignment cases that are not ONT (shared/param_f.py:11: hifi / ilmn = 55 rows)
+DEPTH = {"fa_hifi_depth55": 55}
 
 
 def digest(a):
@@ -62,7 +65,7 @@ def case_inputs(case):
     if kind == syn.PILEUP:
         x = syn.make_pileup_windows(batch, xseed, recipe, dtype=np.dtype(xdt), channels=ch)
     else:
-        x = syn.make_fa_windows(batch, xseed, recipe, channels=ch)
+        x = syn.make_fa_windows(batch, xseed, recipe, channels=ch, depth=DEPTH.get(name, syn.FA_DEPTH_ONT))
     return sd, x
 
 
@@ -144,6 +147,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
         manifest[name] = dict(kind=kind, channels=ch, add_indel_length=indel, weight_seed=wseed, peaked=peaked,
                               input_seed=xseed, recipe=recipe, batch=batch, x_dtype=xdt, x_sha=digest(x),
+                              depth=(int(x.shape[1]) if kind == syn.FULL_ALIGNMENT else None),
                               sd_sha=sd_digest(sd), y_sha=digest(y), positions=pos, alt_info=alt, vcf_rows=rows,
                               torch=torch.__version__)
         print(f"{name}: x{x.shape} -> y{y.shape}  argmax21={np.bincount(y[:, :21].argmax(1), minlength=21).tolist()}")

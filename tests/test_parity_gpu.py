@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 CASES = sorted(util.manifest().keys())
 
 
-def make_model(kind, channels, add_indel, sd, keep=False):
+def make_model(kind, channels, add_indel, sd, keep=False, depth=None):
     cls = Clair3_P if kind == syn.PILEUP else Clair3_F
     m = cls(add_indel_length=add_indel, predict=True, input_channels=channels)
+    if depth and depth != syn.FA_DEPTH_ONT:
+        m.set_geometry(depth, 33)
     if keep:
         m.keep_activations(True)
     m.to("cuda:0")
@@ -45,7 +47,7 @@ def test_golden_rows(name):
     """HIP rows vs rows of the reference PyTorch modules on identical tensors."""
     meta = util.manifest()[name]
     sd, x = util.case_inputs(meta)
-    m = make_model(meta["kind"], meta["channels"], meta["add_indel_length"], sd)
+    m = make_model(meta["kind"], meta["channels"], meta["add_indel_length"], sd, depth=meta.get("depth"))
     y = _hip_predict(m, "cuda:0", x)
     err = util.assert_rows_match(y, util.golden_y(name), what=name)
     print(f"{name}: max|dY| vs reference = {err:.2e}")

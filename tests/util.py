@@ -28,7 +28,8 @@ def case_inputs(meta):
         x = syn.make_pileup_windows(meta["batch"], meta["input_seed"], meta["recipe"], dtype=np.dtype(meta["x_dtype"]),
                                     channels=meta["channels"])
     else:
-        x = syn.make_fa_windows(meta["batch"], meta["input_seed"], meta["recipe"], channels=meta["channels"])
+        x = syn.make_fa_windows(meta["batch"], meta["input_seed"], meta["recipe"], channels=meta["channels"],
+                                depth=meta.get("depth") or syn.FA_DEPTH_ONT)
     return sd, x
 
 
