@@ -45,8 +45,11 @@ def _check_gpu_memory_or_exit(memory, device_ids=None, print_log=True):
         sys.exit(1)
 
 
-def install(worker=True, gpu_wrapper=True):
-    """Patch the imported (or importable) reference modules in place.  Returns the list of rebound names."""
+def install(worker=True, gpu_wrapper=True, decoder=False):
+    """Patch the imported (or importable) reference modules in place.  Returns the list of rebound names.
+    decoder=True additionally makes the full-alignment rows carry the decoder columns of libc3hip and
+    rebinds clair3.CallVariants.possible_outcome_probabilites_from / batch_output to read them
+    (clair3_amd/decode.py): same VCF text, ~6x the decode rate per host core on rows with the indel-length heads."""
     done = []
     import clair3.model as ref_model
     ref_model.Clair3_P, ref_model.Clair3_F = Clair3_P, Clair3_F
@@ -59,6 +62,13 @@ def install(worker=True, gpu_wrapper=True):
         w._limit_gpu_memory = _limit_gpu_memory
         done += ["clair3.CallVariantsFromCffi." + n for n in
                  ("_torch_predict", "_load_torch_checkpoint", "_select_device", "_limit_gpu_memory")]
+    if decoder:
+        from . import decode
+        if worker:
+            import clair3.CallVariantsFromCffi  # noqa: F401  (so that its imported copy of batch_output is rebound too)
+        decode.install_decoder()
+        predict.DECODER_COLUMNS = True
+        done += ["clair3.CallVariants.possible_outcome_probabilites_from", "clair3.CallVariants.batch_output"]
     if gpu_wrapper:
         import clair3.CallVariantsFromCffiGPU as g
         g.get_gpu_memory = predict.get_gpu_memory

@@ -23,27 +23,38 @@
 namespace c3 {
 
 struct DecodeParams {
-    const float *y;         // [B][24 | 90]
-    const uint8_t *ref21;   // [B] gt21 index of (ref, ref): 0 AA, 4 CC, 7 GG, 9 TT
-    float *maxp;            // [B][10]
-    int32_t *argmax;        // [B][10]
-    uint8_t *early;         // [B] 1 = the reference returns [homo_Ref_probability] without enumerating
+    const float *y;         // [B][ldy]: 24 | 90 probabilities at the start of every row
+    int64_t ldy;            // row stride in floats
+    const uint8_t *ref21;   // [B] gt21 index of (ref, ref): 0 AA, 4 CC, 7 GG, 9 TT          (COLS = false)
+    float *maxp;            // [B][10]                                                        (COLS = false)
+    int32_t *argmax;        // [B][10]                                                        (COLS = false)
+    uint8_t *early;         // [B] 1 = the reference returns [homo_Ref_probability] without enumerating (COLS = false)
+    float *cols;            // [B][ldy] the row's kDecodeCols decoder columns                 (COLS = true)
     int B, indel;
 };
 
 constexpr int kDecodeClasses = 10;
+// Decoder columns (c3_model_set_decode_columns): the same results appended to the probability row itself, for a caller
+// that does not know the reference base when it asks for the prediction (_torch_predict sees only X,
+// clair3/CallVariantsFromCffi.py:48-52).  Only class 0 and the early exit depend on that base, so they are given for
+// all four:
+//   [0..8]   maxima of classes 1..9          [9..12]  homo_Ref probability for reference base A, C, G, T
+//   [13..21] positions of those maxima       [22]     early-exit bits (bit b: base b takes the early exit)
+// positions and bits as float values (all < 2^24: exact).
+constexpr int kDecodeCols = 23;
 
 // one wave per row; candidates of a class are dealt to the lanes in enumeration order, then a 64-lane max with
 // smallest-index tie-break (key = value bits << 32 | ~index: probabilities are >= 0, so float order == bit order)
+template <bool COLS>
 __global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.B) return;
-    const int ncol = p.indel ? 90 : 24;
-    const float *y = p.y + (int64_t)row * ncol;
+    const float *y = p.y + (int64_t)row * p.ldy;
     const float *g = y, *z = y + 21, *p1 = y + 24, *p2 = y + 57;
-    const int ref = p.ref21[row];
+    const int ref = COLS ? 0 : p.ref21[row];
     const float hr = z[0], hv = z[1], ht = z[2];
+    float *cols = COLS ? p.cols + (int64_t)row * p.ldy : nullptr;
 
     auto reduce_store = [&](int cls, unsigned long long key) {
 #pragma unroll
@@ -52,15 +63,28 @@ __global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
             key = o > key ? o : key;
         }
         if (lane == 0) {
-            p.maxp[(int64_t)row * kDecodeClasses + cls] = __uint_as_float((unsigned)(key >> 32));
-            p.argmax[(int64_t)row * kDecodeClasses + cls] = (int32_t)(~(unsigned)key);
+            if constexpr (COLS) {
+                if (cls) cols[cls - 1] = __uint_as_float((unsigned)(key >> 32)), cols[12 + cls] = (float)(int32_t)(~(unsigned)key);
+            } else {
+                p.maxp[(int64_t)row * kDecodeClasses + cls] = __uint_as_float((unsigned)(key >> 32));
+                p.argmax[(int64_t)row * kDecodeClasses + cls] = (int32_t)(~(unsigned)key);
+            }
         }
+    };
+    // class 0 and the early exit for each of the four possible reference bases (lanes 0..3)
+    auto all_bases = [&](float scale, bool lengths_ok) {
+        const int hs[4] = {0, 4, 7, 9};
+        const float gb = g[hs[lane & 3]];
+        const unsigned long long bits = __ballot(lane < 4 && lengths_ok && hr >= 0.5f && gb >= 0.5f);
+        if (lane < 4) cols[9 + lane] = p.indel ? __fmul_rn(scale, gb) : __fmul_rn(hr, gb);
+        if (lane == 0) cols[22] = (float)(unsigned)(bits & 15u);
     };
     auto mk = [](float v, int idx) { return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)~idx; };
     const unsigned long long none = 0ull;  // below every real candidate (idx 0xffffffff never occurs)
 
     if (!p.indel) {
-        if (lane == 0) p.early[row] = hr >= 0.5f && g[ref] >= 0.5f;
+        if constexpr (COLS) all_bases(0.f, true);
+        else if (lane == 0) p.early[row] = hr >= 0.5f && g[ref] >= 0.5f;
         const int hsnp[4] = {0, 4, 7, 9}, tsnp[6] = {1, 2, 3, 5, 6, 8};
         reduce_store(0, lane == 0 ? mk(__fmul_rn(hr, g[ref]), 0) : none);
         reduce_store(1, lane < 4 ? mk(__fmul_rn(hv, g[hsnp[lane & 3]]), lane) : none);
@@ -76,7 +100,8 @@ __global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
     }
 
     const float v0 = __fmul_rn(p1[16], p2[16]);
-    if (lane == 0) p.early[row] = p1[16] >= 0.5f && p2[16] >= 0.5f && hr >= 0.5f && g[ref] >= 0.5f;
+    if constexpr (COLS) all_bases(__fmul_rn(v0, hr), p1[16] >= 0.5f && p2[16] >= 0.5f);
+    else if (lane == 0) p.early[row] = p1[16] >= 0.5f && p2[16] >= 0.5f && hr >= 0.5f && g[ref] >= 0.5f;
     {
         const int hsnp[4] = {0, 4, 7, 9}, tsnp[6] = {1, 2, 3, 5, 6, 8};
         reduce_store(0, lane == 0 ? mk(__fmul_rn(__fmul_rn(v0, hr), g[ref]), 0) : none);

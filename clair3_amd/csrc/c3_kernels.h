@@ -443,9 +443,9 @@ struct TailParams {
     const float *b5;    // [NB*128]
     const float *wh;    // [NB][128][64]  (head columns zero-padded to 64)
     const float *bh;    // [NB][64]
-    float *y;           // [B][nout]
+    float *y;           // [B][ldy]: nout probabilities at the start of every row
     float *l4_dbg;      // optional [B][FC]
-    int B, S, NB, nout;
+    int B, S, NB, nout, ldy;
 };
 constexpr int kTailWindows = 2;  // windows per workgroup: B/2 workgroups keep every CU busy at B >= 512
 
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
         for (int k = 1; k < n; ++k) m = fmaxf(m, l[k]);
         float sum = 0.f;
         for (int k = 0; k < n; ++k) sum += expf(l[k] - m);
-        float *y = p.y + (int64_t)b * p.nout + head_off(br);
+        float *y = p.y + (int64_t)b * p.ldy + head_off(br);
         for (int k = 0; k < n; ++k) y[k] = expf(l[k] - m) / sum;
     }
 }

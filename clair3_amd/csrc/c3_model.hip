@@ -90,6 +90,7 @@ struct c3_model {
     int kind = 0, C = 0, add_indel = 0, device = 0;
     int depth = 89, positions = 33;
     int nb = 2, nout = 24;
+    int row = 24;  // floats per output row: nout, + kDecodeCols when c3_model_set_decode_columns is on
     bool loaded = false;
     hipStream_t stream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;
 
@@ -536,7 +537,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
         hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
         HIP_TRY(hipGetLastError());
-        Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->nout};
+        Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->row};
         const dim3 grid((unsigned)((n + 15) / 16), m->nb);
         if (FC == 256)
             hipLaunchKernelGGL(fc_tail_mfma_kernel<256>, grid, dim3(256), 0, s, tp);
@@ -546,12 +547,18 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
     } else {
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
         TailParams tp{m->part, m->l4_b, m->w5t, m->b5, m->wh, m->bh, y, m->keep ? m->l4dbg : nullptr,
-                      (int)n, S, m->nb, m->nout};
+                      (int)n, S, m->nb, m->nout, m->row};
         const int grid = (int)((n + kTailWindows - 1) / kTailWindows);
         if (FC == 256)
             hipLaunchKernelGGL(fc_tail_kernel<256>, dim3(grid), dim3(256), 0, s, tp);
         else
             hipLaunchKernelGGL(fc_tail_kernel<128>, dim3(grid), dim3(256), 0, s, tp);
+        HIP_TRY(hipGetLastError());
+    }
+    if (m->row > m->nout) {  // decoder columns behind the probabilities of every row (c3_decode.h)
+        ProfScope ps(m, s, m->kind == C3_KIND_PILEUP ? "p.decode" : "fa.decode", 0.0, 4.0 * n * m->row);
+        DecodeParams dp{y, m->row, nullptr, nullptr, nullptr, nullptr, y + m->nout, (int)n, m->nout == 90 ? 1 : 0};
+        hipLaunchKernelGGL(outcome_maxima_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dp);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -730,7 +737,7 @@ static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype
         const int64_t n = std::min<int64_t>(m->cap, batch - off);
         const char *xp = starts ? (const char *)x : (const char *)x + off * wbytes;  // region matrix is shared
         const int32_t *sp = starts ? starts + off : nullptr;
-        float *yp = y + off * m->nout;
+        float *yp = y + off * m->row;
         if (m->kind == C3_KIND_FULL_ALIGNMENT)
             TRY(run_fa(m, s, (const int8_t *)xp, n, yp));
         else if (x_dtype == C3_DTYPE_I8)
@@ -801,6 +808,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     c3_model *m = new c3_model();
     m->kind = kind, m->C = in_channels, m->add_indel = add_indel_length ? 1 : 0, m->device = device;
     m->nb = m->add_indel ? 4 : 2, m->nout = m->add_indel ? 90 : 24;
+    m->row = m->nout;
     m->FC = kind == C3_KIND_PILEUP ? 128 : 256;
     m->K4 = kind == C3_KIND_PILEUP ? m->positions * 320 : 14 * 256;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -846,6 +854,15 @@ int c3_model_set_geometry(c3_model *m, int depth, int positions) {
 }
 
 int c3_model_output_size(const c3_model *m) { return m ? m->nout : -1; }
+int c3_model_row_size(const c3_model *m) { return m ? m->row : -1; }
+
+int c3_model_set_decode_columns(c3_model *m, int enable) {
+    if (!m) return fail("null model");
+    for (const HostSlot &sl : m->slot)
+        if (sl.busy) return fail("a prediction is in flight: call c3_predict_wait first");
+    m->row = m->nout + (enable ? kDecodeCols : 0);
+    return 0;
+}
 
 int64_t c3_model_window_bytes(const c3_model *m, int x_dtype) {
     if (!m) return -1;
@@ -941,7 +958,7 @@ int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batc
     HIP_TRY(hipSetDevice(m->device));
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
-    const size_t yb = (size_t)batch * m->nout * sizeof(float);
+    const size_t yb = (size_t)batch * m->row * sizeof(float);
     sl.y_host = y_host, sl.y_bytes = yb, sl.busy = true;
     if (batch == 0) return 0;
     TRY(ensure_slot(m, sl, xb, yb));
@@ -996,7 +1013,7 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
     const size_t item = x_dtype == C3_DTYPE_I32 ? 4 : 1;
     const size_t rb = ((size_t)n_cols * m->C * item + 255) & ~(size_t)255;
     const size_t sb = (size_t)batch * sizeof(int32_t);
-    const size_t yb = (size_t)batch * m->nout * sizeof(float);
+    const size_t yb = (size_t)batch * m->row * sizeof(float);
     TRY(ensure_slot(m, sl, rb + sb, yb));
     memcpy(sl.pin_x, region_host, (size_t)n_cols * m->C * item);
     memcpy((char *)sl.pin_x + rb, starts_host, sb);
@@ -1035,12 +1052,37 @@ int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uin
     uint8_t *early = (uint8_t *)(base + yb + rb + 2 * mb);
     HIP_TRY(hipMemcpyAsync(y, y_host, yb, hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(ref, ref21_host, (size_t)batch, hipMemcpyHostToDevice, m->stream));
-    DecodeParams dp{y, ref, maxp, arg, early, (int)batch, m->nout == 90 ? 1 : 0};
-    hipLaunchKernelGGL(outcome_maxima_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
+    DecodeParams dp{y, m->nout, ref, maxp, arg, early, nullptr, (int)batch, m->nout == 90 ? 1 : 0};
+    hipLaunchKernelGGL(outcome_maxima_kernel<false>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(maxp_host, maxp, mb, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(argmax_host, arg, mb, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(early_host, early, (size_t)batch, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *rows_host) {
+    if (!m) return fail("null model");
+    if (batch < 0) return fail("negative batch");
+    if (batch == 0) return 0;
+    if (!y_host || !rows_host) return fail("null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const int wide = m->nout + kDecodeCols;
+    const size_t total = (size_t)batch * wide * sizeof(float);
+    if (m->decode_bytes < total) {
+        if (m->decode_dev) (void)hipFree(m->decode_dev);
+        m->decode_dev = nullptr, m->decode_bytes = 0;
+        HIP_TRY(hipMalloc(&m->decode_dev, total));
+        m->decode_bytes = total;
+    }
+    float *rows = (float *)m->decode_dev;
+    HIP_TRY(hipMemcpy2DAsync(rows, (size_t)wide * sizeof(float), y_host, (size_t)m->nout * sizeof(float),
+                             (size_t)m->nout * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->stream));
+    DecodeParams dp{rows, wide, nullptr, nullptr, nullptr, nullptr, rows + m->nout, (int)batch, m->nout == 90 ? 1 : 0};
+    hipLaunchKernelGGL(outcome_maxima_kernel<true>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rows_host, rows, total, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return 0;
 }

@@ -51,8 +51,8 @@ struct Tail2Params {
     const float *b5;   // [NB][128]
     const float *whf;  // [NB][3 cb][8][64 lanes][4]: head_b[out = 16 cb + (lane&15)][k = 16 q + 4 (lane>>4) + e], 0 beyond the head
     const float *bh;   // [NB][48]
-    float *y;          // [B][nout]
-    int B, NB, nout;
+    float *y;          // [B][ldy]: the row's probabilities first (ldy > nout when decoder columns follow, c3_decode.h)
+    int B, NB, ldy;
 };
 
 template <int FC>
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void fc_tail_mfma_kernel(Tail2Params p) {
         sum += __shfl_xor(sum, 2);
         const int b = b0 + t;
         if (b < p.B) {
-            float *y = p.y + (int64_t)b * p.nout + head_off;
+            float *y = p.y + (int64_t)b * p.ldy + head_off;
 #pragma unroll
             for (int i = 0; i < 9; ++i)
                 if (part + 4 * i < head_n) y[part + 4 * i] = l[i] / sum;

@@ -41,6 +41,7 @@ class _HipModel:
         self._pending_sd = None
         self._keep = False
         self._geometry = None
+        self._decode_cols = False
         if device is not None:
             self.to(device)
 
@@ -60,6 +61,8 @@ class _HipModel:
             _lib.check(_lib.lib().c3_model_set_geometry(self._handle, *self._geometry), "c3_model_set_geometry")
         if self._keep:
             _lib.check(_lib.lib().c3_debug_keep_activations(self._handle, 1), "c3_debug_keep_activations")
+        if self._decode_cols:
+            _lib.check(_lib.lib().c3_model_set_decode_columns(self._handle, 1), "c3_model_set_decode_columns")
         if sd is not None:
             self._load(sd)
         return self
@@ -81,6 +84,21 @@ class _HipModel:
             _lib.check(_lib.lib().c3_model_set_geometry(self._handle, *self._geometry), "c3_model_set_geometry")
             if self._pending_sd is not None:
                 self._load(self._pending_sd)
+        return self
+
+    DECODE_COLS = 23  # C3_DECODE_COLS (include/c3hip.h)
+
+    @property
+    def row_size(self):
+        """floats per output row: output_size, + DECODE_COLS decoder columns when decode_columns() is on"""
+        return self.output_size + (self.DECODE_COLS if self._decode_cols else 0)
+
+    def decode_columns(self, enable=True):
+        """Append the decoder columns (clair3_amd/decode.py) to every output row."""
+        self._decode_cols = bool(enable)
+        if self._handle is not None:
+            _lib.check(_lib.lib().c3_model_set_decode_columns(self._handle, int(self._decode_cols)),
+                       "c3_model_set_decode_columns")
         return self
 
     def load_state_dict(self, state_dict, strict=True):
@@ -141,7 +159,7 @@ class _HipModel:
             if dt is None:
                 raise _lib.C3Error(f"unsupported window dtype {x.dtype}")
             self._check_shape(tuple(x.shape), dt)
-            y = torch.empty((x.shape[0], self.output_size), dtype=torch.float32, device=x.device)
+            y = torch.empty((x.shape[0], self.row_size), dtype=torch.float32, device=x.device)
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(_lib.lib().c3_predict_device(self._handle, x.data_ptr(), dt, x.shape[0], y.data_ptr(),
                                                     C.c_void_p(stream)), "c3_predict_device")
@@ -169,7 +187,7 @@ class _HipModel:
         if dt is None:
             raise _lib.C3Error(f"unsupported window dtype {x.dtype} (int8 / int32 expected)")
         self._check_shape(x.shape, dt)
-        y = np.empty((x.shape[0], self.output_size), dtype=np.float32)
+        y = np.empty((x.shape[0], self.row_size), dtype=np.float32)
         _lib.check(_lib.lib().c3_predict(self._handle, x.ctypes.data, dt, x.shape[0], y.ctypes.data), "c3_predict")
         return y
 
@@ -180,7 +198,7 @@ class _HipModel:
         if dt is None:
             raise _lib.C3Error(f"unsupported window dtype {x.dtype} (int8 / int32 expected)")
         self._check_shape(x.shape, dt)
-        y = np.empty((x.shape[0], self.output_size), dtype=np.float32)
+        y = np.empty((x.shape[0], self.row_size), dtype=np.float32)
         _lib.check(_lib.lib().c3_predict_submit(self._handle, x.ctypes.data, dt, x.shape[0], y.ctypes.data, slot),
                    "c3_predict_submit")
         return slot, y
@@ -245,7 +263,7 @@ class Clair3_P(_HipModel):
         if dt is None or region.ndim != 2 or region.shape[1] != self.input_channels:
             raise _lib.C3Error(f"region must be (n_cols, {self.input_channels}) int8/int32, got {region.dtype} {region.shape}")
         starts = np.ascontiguousarray(starts, dtype=np.int32)
-        y = np.empty((len(starts), self.output_size), dtype=np.float32)
+        y = np.empty((len(starts), self.row_size), dtype=np.float32)
         _lib.check(_lib.lib().c3_predict_pileup_region(self._handle, region.ctypes.data, dt, region.shape[0],
                                                        starts.ctypes.data, len(starts), y.ctypes.data),
                    "c3_predict_pileup_region")

@@ -82,10 +82,23 @@ int c3_model_set_geometry(c3_model *m, int depth, int positions);
 int c3_model_load(c3_model *m, const c3_tensor_desc *tensors, int n_tensors);
 /* 24 or 90 */
 int c3_model_output_size(const c3_model *m);
+/* Decoder columns: with enable != 0 every output row of c3_predict / c3_predict_submit /
+ * c3_predict_device / c3_predict_pileup_region grows from c3_model_output_size() to c3_model_row_size() =
+ * output_size + C3_DECODE_COLS floats.  The caller of _torch_predict (clair3/CallVariantsFromCffi.py:48-52, :317)
+ * does not know the reference base of a row, so the columns carry what clair3/CallVariants.py:510-659 + :722-749
+ * derive from the row for EVERY base (same float32 products, same order as c3_outcome_maxima):
+ *   [0..8]   max of the class lists homo_SNP, hetero_SNP, homo_Ins, homo_Del, hetero_ACGT_Ins, hetero_InsIns,
+ *            hetero_ACGT_Del, hetero_DelDel, hetero_InsDel        [9..12] homo_Ref probability if the base is A, C, G, T
+ *   [13..21] position of the first occurrence of each maximum     [22]    bit b set: base b takes the early exit
+ * (positions and bits stored as float values).  Rows stay valid input of the reference's batch_output: it slices
+ * columns [0:21] [21:24] [24:57] [57:90] (CallVariants.py:1072-1080) and never looks further right. */
+#define C3_DECODE_COLS 23
+int c3_model_set_decode_columns(c3_model *m, int enable);
+int c3_model_row_size(const c3_model *m);
 /* bytes of one input window for dtype x_dtype (594 / 2376 / 23496 / 26433 for the ONT shapes) */
 int64_t c3_model_window_bytes(const c3_model *m, int x_dtype);
 
-/* y_host[batch][24|90] = forward(x_host[batch][...]); synchronous */
+/* y_host[batch][24|90 (c3_model_row_size)] = forward(x_host[batch][...]); synchronous */
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host);
 /* asynchronous pair, slot in {0,1}: submit copies x into pinned staging and enqueues H2D + kernels + D2H;
  * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
@@ -116,6 +129,9 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
  * maxp_host: [batch][10] float, argmax_host: [batch][10] int32, early_host: [batch] bytes.  Synchronous. */
 int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uint8_t *ref21_host, float *maxp_host,
                       int32_t *argmax_host, uint8_t *early_host);
+/* The decoder columns for rows that are already on the host: rows_host[batch][output_size + C3_DECODE_COLS] receives
+ * y_host[b] followed by its columns (same kernel as the c3_model_set_decode_columns path).  Synchronous. */
+int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *rows_host);
 /* blocks until everything enqueued on the model's own stream has finished */
 int c3_model_synchronize(c3_model *m);
 int c3_model_destroy(c3_model *m);

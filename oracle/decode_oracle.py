@@ -63,3 +63,18 @@ def outcome_maxima(y, ref21, add_indel_length):
         else:                 # :532-534
             early[r] = row[21] >= 0.5 and row[k] >= 0.5
     return maxp, arg, early
+
+
+def decode_columns(y, add_indel_length):
+    """The 23 decoder columns of include/c3hip.h (C3_DECODE_COLS) for every row: maxima and first positions of classes
+    1..9 (independent of the reference base), homo_Ref probability and early-exit bit for each base A, C, G, T."""
+    y = np.asarray(y, dtype=np.float32)
+    out = np.zeros((len(y), 23), dtype=np.float32)
+    for b, k in enumerate((0, 4, 7, 9)):
+        maxp, arg, early = outcome_maxima(y, np.full(len(y), k), add_indel_length)
+        out[:, 9 + b] = maxp[:, 0]
+        out[:, 22] += early.astype(np.float32) * (1 << b)
+        if b == 0:
+            out[:, 0:9] = maxp[:, 1:]
+            out[:, 13:22] = arg[:, 1:]
+    return out

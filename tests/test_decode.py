@@ -96,3 +96,63 @@ def test_outcome_maxima_rejects_bad_arguments():
         decode.outcome_maxima(m, y[:, :20], "ACG")
     maxp, arg, early = decode.outcome_maxima(m, y[:0], "")
     assert maxp.shape == (0, 10) and early.shape == (0,)
+
+
+def test_oracle_columns_agree_with_the_per_base_maxima():
+    """decode_oracle.decode_columns is outcome_maxima evaluated for the four bases: pinned by the same goldens"""
+    g = golden(True)
+    cols = decode_oracle.decode_columns(g["y"], True)
+    assert cols.shape == (len(g["y"]), 23) and cols.dtype == np.float32
+    base = np.array([{0: 0, 4: 1, 7: 2, 9: 3}[int(k)] for k in g["ref21"]])
+    rows = np.arange(len(base))
+    assert np.array_equal(((cols[:, 22].astype(np.int32) >> base) & 1).astype(bool), g["early"])
+    assert np.array_equal(cols[rows, 9 + base].view(np.uint32), g["maxp"][:, 0].view(np.uint32))
+    live = ~g["early"]
+    assert np.array_equal(cols[live, 0:9].view(np.uint32), g["maxp"][live, 1:].view(np.uint32))
+    assert np.array_equal(cols[live, 13:22].astype(np.int32), g["argmax"][live, 1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("indel", [True, False])
+def test_decode_columns_of_golden_rows(indel):
+    """c3_decode_columns on the hand-made rows (ties, 0.5 boundaries, early exits) == the oracle's columns, bit for bit"""
+    from clair3_amd import decode
+    g = golden(indel)
+    rows = decode.decode_columns(_model(indel), g["y"])
+    assert rows.shape == (len(g["y"]), g["y"].shape[1] + decode.DECODE_COLS)
+    assert np.array_equal(rows[:, :g["y"].shape[1]].view(np.uint32), g["y"].view(np.uint32))
+    want = decode_oracle.decode_columns(g["y"], indel)
+    assert np.array_equal(rows[:, g["y"].shape[1]:].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("indel", [True, False])
+def test_predict_appends_the_decode_columns(indel):
+    """model.decode_columns(): every predict entry point returns [probabilities | columns]; the probabilities are the
+    bits of the plain call, the columns are the oracle's; switching it off restores the plain rows"""
+    from clair3_amd import decode, synthetic as syn
+    m = _model(indel)
+    kind = syn.FULL_ALIGNMENT if indel else syn.PILEUP
+    x = syn.make_windows(kind, 77, seed=9, channels=8 if indel else 18)
+    y = m.predict_numpy(x)
+    m.decode_columns(True)
+    assert m.row_size == m.output_size + decode.DECODE_COLS
+    wide = m.predict_numpy(x)
+    assert wide.shape == (len(x), m.row_size)
+    assert np.array_equal(wide[:, :m.output_size].view(np.uint32), y.view(np.uint32))
+    want = decode_oracle.decode_columns(y, indel)
+    assert np.array_equal(wide[:, m.output_size:].view(np.uint32), want.view(np.uint32))
+    t0, t1 = m.submit(x[:40], 0), m.submit(x[40:], 1)   # the asynchronous pair, both slots
+    both = np.concatenate([m.wait(t0), m.wait(t1)])
+    assert np.array_equal(both.view(np.uint32), wide.view(np.uint32))
+    import torch
+    xd = torch.from_numpy(x).to("cuda:0")
+    yd = m(xd)                                          # device-to-device entry
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy().view(np.uint32), wide.view(np.uint32))
+    if not indel:
+        region = np.ascontiguousarray(np.concatenate([x[0], x[1]]))
+        r = m.predict_region(region, [0, 33])
+        assert np.array_equal(r.view(np.uint32), wide[:2].view(np.uint32))
+    m.decode_columns(False)
+    assert np.array_equal(m.predict_numpy(x).view(np.uint32), y.view(np.uint32))
