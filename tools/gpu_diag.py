@@ -138,6 +138,23 @@ def decode_rate():
         decode_oracle.outcome_maxima(y[:256], ref[:256], indel)
         cpu = 256 / (time.time() - t)
         print(f"  {kind:15s} {n} rows x {y.shape[1]} floats: c3_outcome_maxima {gpu:,.0f} rows/s | python enumeration {cpu:,.0f} rows/s/core", flush=True)
+    # what the decoder columns cost on the prediction path (host windows in, host rows out, one batch at a time)
+    print("== c3_predict with / without the decoder columns (c3_model_set_decode_columns)")
+    for kind, ch, indel, B in ((syn.FULL_ALIGNMENT, 8, True, 256), (syn.FULL_ALIGNMENT, 8, True, 1000), (syn.PILEUP, 18, False, 1024)):
+        cls = Clair3_P if kind == syn.PILEUP else Clair3_F
+        m = cls(add_indel_length=indel, predict=True, input_channels=ch).to("cuda:0")
+        m.load_state_dict(syn.make_state_dict(kind, ch, indel, seed=0))
+        x = syn.make_windows(kind, B, seed=3)
+        rates = []
+        for on in (False, True, False, True):
+            m.decode_columns(on)
+            m.predict_numpy(x)
+            reps = 40
+            t = time.time()
+            for _ in range(reps):
+                m.predict_numpy(x)
+            rates.append(reps * B / (time.time() - t))
+        print(f"  {kind:15s} B={B}: plain {rates[0]:,.0f} / {rates[2]:,.0f}  with columns {rates[1]:,.0f} / {rates[3]:,.0f} windows/s", flush=True)
 
 
 if __name__ == "__main__":
