@@ -71,7 +71,19 @@ def test_install_rebinds_the_reference_call_sites():
         # constructor keywords used at CallVariantsFromCffi.py:232,243
         m = ref_model.Clair3_F(add_indel_length=True, predict=True, input_channels=9)
         assert m.output_size == 90 and m.input_channels == 9
+        # decoder=True: two more names, same parameter lists, and the worker's imported copy follows
+        import clair3.CallVariants as cv
+        sig = {n: list(inspect.signature(getattr(cv, n)).parameters) for n in ("batch_output", "possible_outcome_probabilites_from")}
+        unpatched = cv.batch_output
+        assert not predict.DECODER_COLUMNS
+        names = callvar.install(decoder=True)
+        assert len(names) == 10 and predict.DECODER_COLUMNS
+        assert cv.batch_output is not unpatched and w.batch_output is cv.batch_output
+        for n, params in sig.items():
+            assert list(inspect.signature(getattr(cv, n)).parameters) == params, n
     finally:
+        from clair3_amd import predict as _p
+        _p.DECODER_COLUMNS = False
         sys.path.remove(ref)
         for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")]:
             del sys.modules[k]
