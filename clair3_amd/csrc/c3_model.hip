@@ -697,11 +697,24 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     {
         ProfScope ps(m, s, "p.proj2", 2.0 * M * 1280.0 * 256.0, 4.0 * M * (256.0 + 1280.0));
         if (m->proj2_stream && m->proj2_frag && m->lstm2_v2) {
-            ProjParams pp{m->h1, m->proj2_frag, m->proj_b[1], m->gx2, M, 1280, (M + 31) / 32, 40};
+            ProjParams pp{m->h1, m->proj2_frag, m->proj_b[1], m->gx2, M, 1280, (M + 31) / 32, 40, nullptr};
+            static int trace_left = getenv("C3HIP_PROJ_TRACE") ? 3 : 0;  // debug: the third launch is traced
+            static unsigned long long *trace_dev = nullptr;
+            if (trace_left && !trace_dev) HIP_TRY(hipMalloc((void **)&trace_dev, 24 * 8 * 8));
+            if (trace_left == 1) pp.trace = trace_dev;
             const int64_t units = (int64_t)pp.row_blocks * pp.col_blocks;
             const int grid = (int)std::min<int64_t>(m->wg_slots, (units + 3) / 4);
             hipLaunchKernelGGL(proj_stream_kernel, dim3(grid), dim3(256), 0, s, pp);
             HIP_TRY(hipGetLastError());
+            if (trace_left && trace_left-- == 1) {
+                unsigned long long h[24 * 8];
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost));
+                fprintf(stderr, "proj trace (workgroup 0 wave 0; shader cycles): unit start -> q0 q1 q2 q3 | gap to next unit\n");
+                for (int u = 0; u < 23; ++u)
+                    fprintf(stderr, "  unit %2d: %6llu %6llu %6llu %6llu | %6llu\n", u, h[u * 8 + 1] - h[u * 8], h[u * 8 + 2] - h[u * 8 + 1],
+                            h[u * 8 + 3] - h[u * 8 + 2], h[u * 8 + 4] - h[u * 8 + 3], h[(u + 1) * 8] - h[u * 8 + 4]);
+            }
         } else {
             DenseLoaderParams lp{m->h1, 256};
             EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
