@@ -80,6 +80,13 @@ def run_workload(name, args, rank, world, local):
     S = args.streams if args.streams > 0 else (2 if kind == syn.PILEUP else 3)  # measured optimum per workload
     models = [model] + [build_model(kind, channels, indel, local)[0] for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in models]
+    # part of model set-up, like the weight upload: every handle sizes its device workspace on its first batch
+    # (hipMalloc) and torch's allocator opens a pool per stream -- neither belongs to a step, warm-up or timed
+    model(x)
+    for mi, st in zip(models, streams):
+        with torch.cuda.stream(st):
+            mi(x)
+    torch.cuda.synchronize()
 
     def fence():
         torch.cuda.synchronize()

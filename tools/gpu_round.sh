@@ -24,6 +24,7 @@ for k,v in d['kernels'].items(): print('   %-9s %7.1f us %6.1f TF' % (k, v['avg_
 "; done; unset C3HIP_WINOGRAD_PMASK ;;
     wprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w tools/wino_probe.hip -o /tmp/wino_probe && timeout 300 /tmp/wino_probe > gpurun_out/wino_probe.txt 2>&1; echo "wprobe rc=$?"; cat gpurun_out/wino_probe.txt ;;
     ptrace) for g in 1; do C3HIP_PROJ_TRACE=1 timeout 300 python bench.py --gpus 1 --workload pileup --no-cpu-baseline --streams 1 --steps 3 --warmup 1 2>&1 >/dev/null | grep -A24 'proj trace'; done ;;
+    torchrun1) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/torchrun1.json 2> gpurun_out/torchrun1.err; echo "torchrun1 rc=$?"; cut -c1-400 gpurun_out/torchrun1.json; tail -3 gpurun_out/torchrun1.err ;;
     sprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -w tools/stream_probe.hip -o /tmp/stream_probe && timeout 300 /tmp/stream_probe > gpurun_out/stream_probe.txt 2>&1; echo "sprobe rc=$?"; cat gpurun_out/stream_probe.txt ;;
     coprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -w tools/coissue_probe.hip -o /tmp/coissue_probe && timeout 300 /tmp/coissue_probe > gpurun_out/coissue_probe.txt 2>&1; echo "coprobe rc=$?"; cat gpurun_out/coissue_probe.txt ;;
     tail) for v in 0 1; do echo "== C3HIP_TAIL_MFMA=$v"; C3HIP_TAIL_MFMA=$v timeout 600 python bench.py --gpus 1 --no-cpu-baseline --streams 1 2> gpurun_out/bencht.err | python -c "
