@@ -92,3 +92,29 @@ def test_async_file_pipeline_matches_sync_predict(tmp_path):
     n = worker.predict_file_list(m, lst, lambda p, a, y: rows.append(y), batch_size=64)
     assert n == 208
     assert np.array_equal(np.concatenate(rows), m.predict_numpy(np.concatenate(xs)))
+
+
+def test_batches_equal_the_reference_generator(tmp_path):
+    """the real tensor_generator_for_chunk (clair3/CallVariantsFromCffi.py:106-133) on the same files (build container
+    only): same batches, same strings, same order"""
+    import sys
+    import types
+    ref = os.environ.get("CLAIR3_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "clair3")):
+        pytest.skip("reference checkout not present")
+    lst, _ = write_chunk_files(tmp_path, [7, 12, 1, 1000, 1001], kind=syn.PILEUP)
+    sys.path.insert(0, ref)
+    try:
+        import clair3.CallVariantsFromCffi as w
+        args = types.SimpleNamespace(output_tensor_can_fn_list=lst)
+        for bs in (5, 1000):
+            want = list(w.tensor_generator_for_chunk(None, args, batch_size=bs))
+            got = list(worker.iter_batches(lst, batch_size=bs))
+            assert len(got) == len(want)
+            for (gx, gp, ga), (wx, wp, wa) in zip(got, want):
+                assert np.array_equal(np.asarray(gx), wx) and gx.dtype == wx.dtype
+                assert list(gp) == list(wp) and list(ga) == list(wa)
+    finally:
+        sys.path.remove(ref)
+        for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")]:
+            del sys.modules[k]
