@@ -178,6 +178,10 @@ def run_workload(name, args, rank, world, local):
         "whole_forward_frac": res["value"] / world * flop_w / (FP32_MFMA_PEAK_TFLOPS * 1e12),
         "hbm_algorithmic_gbs": res["value"] / world * bytes_w / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
     }
+    if kind == syn.FULL_ALIGNMENT:
+        res["roofline"]["note"] = ("achieved = ALGORITHMIC FLOP (direct 3x3 convolution, SURVEY 8d) / measured kernel time; the six "
+                                   "stride-1 layers run as Winograd F(2x2,3x3) and execute 2.25x fewer multiplications, so frac can "
+                                   "exceed 1; matrix-pipe busy time per kernel: profiles/*_pmc_sq.md (SQ_VALU_MFMA_BUSY_CYCLES)")
     return res
 
 
