@@ -172,6 +172,13 @@ class _HipModel:
         return y
 
     def _check_shape(self, shape, dt):
+        if self.KIND == _lib.KIND_FULL_ALIGNMENT and len(shape) == 4 and shape[-1] == self.input_channels:
+            # the reference network is convolutional + pyramid pooling: the same module takes the 89-row ONT matrix
+            # and the 55-row hifi / ilmn one (shared/param_f.py:11), and its call sites construct it without naming
+            # the depth (clair3/CallVariantsFromCffi.py:239-243) -- follow the tensor
+            geometry = (int(shape[1]), int(shape[2]))
+            if geometry != (self._geometry or (89, 33)):
+                self.set_geometry(*geometry)
         wbytes = _lib.lib().c3_model_window_bytes(self._handle, dt)
         item = 4 if dt == _lib.DTYPE_I32 else 1
         n = 1

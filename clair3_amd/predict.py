@@ -56,7 +56,7 @@ _torch_predict = _hip_predict  # the name the reference call sites use
 def build_model(pileup, add_indel_length, platform="ont", enable_dwell_time=False, device=0, chkpnt_fn=None):
     """Model factory block of call_variants_from_cffi (clair3/CallVariantsFromCffi.py:223-248)."""
     if platform != "ont":
-        # hifi/ilmn use a 55-row matrix (shared/param_f.py:11); supported by geometry, but only ONT is validated
+        # hifi/ilmn use a 55-row matrix (shared/param_f.py:11); golden case fa_hifi_depth55
         depth = 55
     else:
         depth = 89

@@ -247,6 +247,22 @@ def test_other_window_geometry(oracle_mod):
     util.assert_rows_match(y, y_o, what="depth-55 geometry")
 
 
+def test_geometry_follows_the_tensor():
+    """the reference call sites build Clair3_F without naming the matrix depth (CallVariantsFromCffi.py:239-243): a handle
+    fed 55-row windows, then 89-row windows, then 55-row ones again gives the golden rows each time"""
+    meta55, meta89 = util.manifest()["fa_hifi_depth55"], util.manifest()["fa_realistic"]
+    sd55, x55 = util.case_inputs(meta55)
+    sd89, x89 = util.case_inputs(meta89)
+    m = make_model(syn.FULL_ALIGNMENT, 8, True, sd55)  # default (ONT) geometry
+    assert util.assert_rows_match(_hip_predict(m, "cuda:0", x55), util.golden_y("fa_hifi_depth55"), what="55 rows") < 2e-5
+    m.load_state_dict(sd89)
+    assert util.assert_rows_match(_hip_predict(m, "cuda:0", x89), util.golden_y("fa_realistic"), what="89 rows") < 2e-5
+    m.load_state_dict(sd55)
+    assert util.assert_rows_match(_hip_predict(m, "cuda:0", x55), util.golden_y("fa_hifi_depth55"), what="55 rows again") < 2e-5
+    with pytest.raises(_lib.C3Error):
+        m.predict_numpy(x55[:, :, :, :7])  # a channel count the weights do not have is still an error
+
+
 def test_two_handles_share_a_gpu():
     """two model handles with the same weights (what bench.py --streams 2 and worker.predict_batches use) give the
     same rows as one, whatever the interleaving"""
