@@ -29,6 +29,8 @@ def ref():
     assert decode.install_decoder() is cv._c3hip_decoder  # idempotent
     yield cv, unpatched
     sys.path.remove(REF)
+    for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")]:
+        del sys.modules[k]  # the next test that imports the reference gets unpatched modules
 
 
 def config(cv, pileup, indel):

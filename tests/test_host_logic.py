@@ -50,6 +50,8 @@ def test_install_rebinds_the_reference_call_sites():
     ref = os.environ.get("CLAIR3_REFERENCE", "/root/reference")
     if not os.path.isdir(os.path.join(ref, "clair3")):
         pytest.skip("reference checkout not present")
+    for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")]:
+        del sys.modules[k]  # whatever an earlier test left rebound
     sys.path.insert(0, ref)
     try:
         import clair3.CallVariantsFromCffi as w
