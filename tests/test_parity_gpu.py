@@ -225,6 +225,21 @@ def test_multiple_micro_batches(oracle_mod):
     util.assert_rows_match(y64[:8], oracle_mod.fa_forward(sd, base[:8], False), what="fa 24-col")
 
 
+def test_pileup_beyond_the_largest_micro_batch(oracle_mod):
+    """16384 + 37 pileup windows (the workspace is capped at 16384 per pass; gx2 alone is 2.8 GB there, beyond the
+    2 GiB where 32-bit buffer offsets would need care): every block of 64 equals the same 64 windows predicted alone"""
+    sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=93)
+    m = make_model(syn.PILEUP, 18, False, sd)
+    base = syn.make_pileup_windows(64, seed=94)
+    x = np.concatenate([base] * 257)[: 16384 + 37]
+    y = m.predict_numpy(x)
+    y64 = m.predict_numpy(base)
+    for i in range(0, len(x), 64):
+        n = min(64, len(x) - i)
+        assert np.array_equal(y[i:i + n], y64[:n]), f"block at {i}"
+    util.assert_rows_match(y64[:8], oracle_mod.pileup_forward(sd, base[:8], False), what="pileup 24-col")
+
+
 def test_other_window_geometry(oracle_mod):
     """depth-55 matrices (shared/param_f.py:11 matrix_depth_dict hifi/ilmn): (55,33)->(28,17)->(14,9)->(7,5); exercises
     even-sized stride-2 stages, clipped Winograd edge tiles in both dimensions and the run-time pyramid-bin table
