@@ -5,7 +5,9 @@ probabilities look like if the convolutions ran on bf16 MFMAs with operands spli
 piece-product is an fp32 convolution of bf16-representable operands, i.e. exactly what v_mfma_f32_32x32x16_bf16
 accumulates.  Compares with the committed reference rows (tests/golden/*.npz).
 
-    python tools/bf16x_study.py
+    python tests/diag/bf16x_study.py
+
+TEST INFRASTRUCTURE (lives under tests/ because it calls the oracle as its checker; never imported by the product).
 """
 import os
 import sys
@@ -14,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import torch_port  # noqa: E402
 from tests import util  # noqa: E402

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Layer-by-layer diagnostic of the HIP path against the CPU oracle (run on the GPU box).
-Never asserts: prints one line per tensor so a single gpurun call localises a bug."""
+Never asserts: prints one line per tensor so a single gpurun call localises a bug.
+TEST INFRASTRUCTURE (lives under tests/ because it calls the oracle as its checker; never imported by the product).
+"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from clair3_amd import synthetic as syn  # noqa: E402

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 STAGES="${1:-diag test bench prof}"
 for s in $STAGES; do
   case $s in
-    diag)  timeout 600 python tools/gpu_diag.py > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
+    diag)  timeout 600 python tests/diag/gpu_diag.py > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
     test)  timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu.txt ;;
     testall) timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.txt ;;
     smoke) timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.txt 2>&1; echo "smoke rc=$?"; tail -5 gpurun_out/smoke.txt ;;
@@ -54,7 +54,7 @@ print('  B=%d value %.0f windows/s  %.4f ms/step' % (d['config']['batch_per_gpu'
 "; done; done ;;
     pmcsq2) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_sq_a" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq_a.err"); echo "pmc sq a rc=$?"
            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM -d "$OLDPWD/gpurun_out/pmc_sq_b" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq_b.err"); echo "pmc sq b rc=$?" ;;
-    fa1) timeout 600 python tools/gpu_diag.py fa > gpurun_out/diag.txt 2>&1; grep -E "act2|act5|act8|^  y" gpurun_out/diag.txt | cut -c1-120; for i in 1 2; do timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchc1.err | python -c "
+    fa1) timeout 600 python tests/diag/gpu_diag.py fa > gpurun_out/diag.txt 2>&1; grep -E "act2|act5|act8|^  y" gpurun_out/diag.txt | cut -c1-120; for i in 1 2; do timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --streams 1 2> gpurun_out/benchc1.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
@@ -70,23 +70,23 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
 "; done ;;
-    isolate) for cfg in "0 0" "0 1" "0x40 0"; do set -- $cfg; echo "== BN64MASK=$1 CONV1_DIRECT=$2"; C3HIP_CONV_BN64MASK=$1 C3HIP_CONV1_DIRECT=$2 timeout 600 python tools/gpu_diag.py fa > gpurun_out/iso.txt 2>&1; grep -E "act0|act5|act6|act7|^  y" gpurun_out/iso.txt | cut -c1-150; done ;;
+    isolate) for cfg in "0 0" "0 1" "0x40 0"; do set -- $cfg; echo "== BN64MASK=$1 CONV1_DIRECT=$2"; C3HIP_CONV_BN64MASK=$1 C3HIP_CONV1_DIRECT=$2 timeout 600 python tests/diag/gpu_diag.py fa > gpurun_out/iso.txt 2>&1; grep -E "act0|act5|act6|act7|^  y" gpurun_out/iso.txt | cut -c1-150; done ;;
     cmpq) timeout 600 python tools/cmp_variants.py "C3HIP_WINOGRAD_PMASK=0" "C3HIP_WINOGRAD_PMASK=0x1b6" 300 > gpurun_out/cmpq.txt 2>&1; echo "cmpq rc=$?"; grep -E "differ|^y" gpurun_out/cmpq.txt ;;
-    diagfap) C3HIP_WINOGRAD_PMASK=0x1b6 timeout 600 python tools/gpu_diag.py fa fa9 > gpurun_out/diagp.txt 2>&1; echo "diag(pmask) rc=$?"; grep -E "act|y " gpurun_out/diagp.txt | head -30 ;;
+    diagfap) C3HIP_WINOGRAD_PMASK=0x1b6 timeout 600 python tests/diag/gpu_diag.py fa fa9 > gpurun_out/diagp.txt 2>&1; echo "diag(pmask) rc=$?"; grep -E "act|y " gpurun_out/diagp.txt | head -30 ;;
     streams) for st in 1 2 3 4; do echo "== --streams $st"; timeout 600 python bench.py --gpus 1 --no-cpu-baseline --streams $st 2> gpurun_out/benchs.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  FA %.0f windows/s  %.4f ms/step | pileup %.0f windows/s %.4f ms/step' % (d['value'], d['ms_per_step'], d['pileup']['value'], d['pileup']['ms_per_step']))
 "; done ;;
-    decode) timeout 600 python tools/gpu_diag.py decode > gpurun_out/decode.txt 2>&1; echo "decode rc=$?"; cat gpurun_out/decode.txt ;;
-    host) timeout 600 python tools/gpu_diag.py host > gpurun_out/host.txt 2>&1; echo "host rc=$?"; cat gpurun_out/host.txt ;;
-    diagp) timeout 600 python tools/gpu_diag.py pileup pileup32 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
+    decode) timeout 600 python tests/diag/gpu_diag.py decode > gpurun_out/decode.txt 2>&1; echo "decode rc=$?"; cat gpurun_out/decode.txt ;;
+    host) timeout 600 python tests/diag/gpu_diag.py host > gpurun_out/host.txt 2>&1; echo "host rc=$?"; cat gpurun_out/host.txt ;;
+    diagp) timeout 600 python tests/diag/gpu_diag.py pileup pileup32 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
     benchp) for v in 0 1; do echo "== C3HIP_LSTM1_FUSED=$v"; C3HIP_LSTM1_FUSED=$v timeout 600 python bench.py --gpus 1 --workload pileup --no-cpu-baseline 2> gpurun_out/benchp.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
 "; done ;;
-    diagfa) timeout 600 python tools/gpu_diag.py fa fa9 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
+    diagfa) timeout 600 python tests/diag/gpu_diag.py fa fa9 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
     counters) rocprofv3 -L > gpurun_out/counters.txt 2>&1; echo "counters rc=$?"; wc -l gpurun_out/counters.txt ;;
     pmcsq) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_sq" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq.err"); echo "pmc sq rc=$?" ;;
     info)  (rocminfo | grep -E "Name|Compute Unit|Max Clock|Wavefront" | head -40; lscpu | head -20; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null) > gpurun_out/info.txt 2>&1 ;;
