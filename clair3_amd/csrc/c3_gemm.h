@@ -21,10 +21,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace c3 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// SPLIT mode (bf16x6): an fp32 value is the exact sum of three bf16 pieces x = x0 + x1 + x2 (8 mantissa bits each);
+// x*w is formed from the six piece products x0w0, x0w1, x1w0, x0w2, x1w1, x2w0 on v_mfma_f32_32x32x16_bf16 (products
+// exact, fp32 accumulation), dropping only terms below 2^-24 of the product -- the rounding an fp32 FMA chain makes
+// anyway (tests/diag/bf16x_study.py: rows as close to the reference as the fp32 path's).  Four values -> three 8-byte
+// groups of bf16, round-to-nearest-even at every level.
+__device__ __forceinline__ void split3_bf16(const f32x4 x, u32x2 (&piece)[3]) {
+    float r[4] = {x[0], x[1], x[2], x[3]};
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) {
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r[i], r[i + 1]}, bf16x2));
+            piece[lvl][i >> 1] = u;
+            if (lvl < 2) {
+                r[i] -= __uint_as_float(u << 16);
+                r[i + 1] -= __uint_as_float(u & 0xffff0000u);
+            }
+        }
+    }
+}
 
 constexpr int kBK = 32;        // floats per K chunk
 constexpr int kThreads = 256;  // 4 waves, 2 (M) x 2 (N)
@@ -251,6 +278,7 @@ struct EpilogueParams {
 
 struct GemmParams {
     const float *bt;  // [N][ldb]
+    const uint16_t *bt3;  // SPLIT: the same weights as three bf16 pieces, [3][N][ldb]
     int64_t ldb;
     int M, N;
     int nk;          // K chunks per block (per split)
@@ -260,12 +288,16 @@ struct GemmParams {
 
 // ABL: ablation switches for tools/mfma_probe (0 in the product).  bit0: no global loads in the loop,
 // bit1: no LDS staging writes, bit2: no barrier, bit3: no LDS fragment reads (MFMAs on stale registers).
-template <class Loader, int EPI, int BM, int BN, int ABL = 0>
+template <class Loader, int EPI, int BM, int BN, int ABL = 0, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Params lp, GemmParams gp,
                                                               EpilogueParams ep) {
     constexpr int RA = BM / 32, RBt = BN / 32;  // staged rows per thread
     constexpr int RB = BM / 64, CB = BN / 64;   // 32x32 accumulators per wave (rows x cols)
-    constexpr int kStage = (BM + BN) * 128;     // bytes per LDS stage
+    // fp32: rows of 32 floats (128 B).  SPLIT: per operand three piece planes with rows of 32 bf16 (64 B).
+    constexpr int kRowB = SPLIT ? 64 : 128;
+    constexpr int kPlaneA = BM * 64, kPlaneB = BN * 64;          // SPLIT: bytes of one piece plane
+    constexpr int kStage = SPLIT ? 3 * (kPlaneA + kPlaneB) : (BM + BN) * 128;  // bytes per LDS stage
+    constexpr int kBase_b = SPLIT ? 3 * kPlaneA : BM * 128;
     __shared__ __attribute__((aligned(16))) char smem[2 * kStage];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,23 +314,72 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
     loader.init(lp, m0, lr, lc, gp.M);
     if constexpr (requires { loader.seek(0); }) loader.seek(k0);
 
+    struct BPieces {
+        u32x2 p[3];
+    };
+    using BReg = std::conditional_t<SPLIT, BPieces, f32x4>;  // one thread's 4 k of one weight row: fp32, or 3 x 4 bf16
     const float *bptr[RBt];
+    const uint16_t *bptr3[RBt];
+    const int64_t piece_stride = (int64_t)gp.N * gp.ldb;
 #pragma unroll
-    for (int i = 0; i < RBt; ++i) bptr[i] = gp.bt + (int64_t)(n0 + lr + 32 * i) * gp.ldb + k0 + lc * 4;
+    for (int i = 0; i < RBt; ++i) {
+        bptr[i] = gp.bt + (int64_t)(n0 + lr + 32 * i) * gp.ldb + k0 + lc * 4;
+        bptr3[i] = gp.bt3 + (int64_t)(n0 + lr + 32 * i) * gp.ldb + k0 + lc * 4;
+    }
+    auto load_b = [&](BReg (&dst)[RBt], int kchunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RBt; ++i) {
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    dst[i].p[q] = *reinterpret_cast<const u32x2 *>(bptr3[i] + q * piece_stride + (int64_t)kchunk * kBK);
+            } else {
+                dst[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)kchunk * kBK);
+            }
+        }
+    };
 
+    // staging offsets.  SPLIT: 8-byte slot lc of the 64-byte row = half (lc & 1) of 16-byte chunk lc >> 1, chunks
+    // swizzled by (row >> 2) & 3 so that the ds_read_b128 of 16 consecutive rows covers all 64 banks once
     int st_off_a[RA], st_off_b[RBt];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) st_off_a[i] = lds_chunk_off(lr + 32 * i, lc);
+    for (int i = 0; i < RA; ++i) {
+        const int row = lr + 32 * i;
+        st_off_a[i] = SPLIT ? row * 64 + (((lc >> 1) ^ ((row >> 2) & 3)) << 4) + (lc & 1) * 8 : lds_chunk_off(row, lc);
+    }
 #pragma unroll
-    for (int i = 0; i < RBt; ++i) st_off_b[i] = BM * 128 + lds_chunk_off(lr + 32 * i, lc);
+    for (int i = 0; i < RBt; ++i) {
+        const int row = lr + 32 * i;
+        st_off_b[i] = kBase_b + (SPLIT ? row * 64 + (((lc >> 1) ^ ((row >> 2) & 3)) << 4) + (lc & 1) * 8 : lds_chunk_off(row, lc));
+    }
+    auto stage = [&](char *dst, const f32x4 (&av)[RA], const BReg (&bv)[RBt]) __attribute__((always_inline)) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                u32x2 pc[3];
+                split3_bf16(av[i], pc);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneA + st_off_a[i]) = pc[q];
+            }
+#pragma unroll
+            for (int i = 0; i < RBt; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneB + st_off_b[i]) = bv[i].p[q];
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(dst + st_off_a[i]) = av[i];
+#pragma unroll
+            for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(dst + st_off_b[i]) = bv[i];
+        }
+    };
 
     // fragment read offsets: row (lane&31) of each 32-row block, chunk 2g + (lane>>5)
-    const int frow = lane & 31, fhi = lane >> 5, fsw = (frow >> 1) & 7;
+    const int frow = lane & 31, fhi = lane >> 5, fsw = SPLIT ? (frow >> 2) & 3 : (frow >> 1) & 7;
     int rd_a[RB], rd_b[CB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) rd_a[i] = (wm * (BM / 2) + i * 32 + frow) * 128;
+    for (int i = 0; i < RB; ++i) rd_a[i] = (wm * (BM / 2) + i * 32 + frow) * kRowB;
 #pragma unroll
-    for (int i = 0; i < CB; ++i) rd_b[i] = BM * 128 + (wn * (BN / 2) + i * 32 + frow) * 128;
+    for (int i = 0; i < CB; ++i) rd_b[i] = kBase_b + (wn * (BN / 2) + i * 32 + frow) * kRowB;
 
     f32x16 acc[RB][CB];
 #pragma unroll
@@ -328,45 +409,74 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
     // Chunk indices past the end are clamped to the last chunk (redundant loads / writes nobody reads), so
     // the body has no conditionals and the scheduler can interleave loader VALU with the MFMAs.
     typename Loader::Raw rawA[RA], rawB[RA];
-    f32x4 ra[RA], rbA[RBt], rbB[RBt];
+    f32x4 ra[RA];
+    BReg rbA[RBt], rbB[RBt];
     const int last = gp.nk - 1;
     loader.issue(rawA, 0);
-#pragma unroll
-    for (int i = 0; i < RBt; ++i) rbA[i] = *reinterpret_cast<const f32x4 *>(bptr[i]);
+    load_b(rbA, 0);
     loader.finish(rawA, ra);
-#pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_a[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(smem + st_off_b[i]) = rbA[i];
+    stage(smem, ra, rbA);
     {
         const int k1 = last < 1 ? last : 1;
         loader.issue(rawA, k1);
-#pragma unroll
-        for (int i = 0; i < RBt; ++i) rbA[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)k1 * kBK);
+        load_b(rbA, k1);
     }
     __syncthreads();
 
-    auto body = [&](int kc, typename Loader::Raw (&rCur)[RA], f32x4 (&bCur)[RBt], typename Loader::Raw (&rNext)[RA],
-                    f32x4 (&bNext)[RBt]) __attribute__((always_inline)) {
+    auto body = [&](int kc, typename Loader::Raw (&rCur)[RA], BReg (&bCur)[RBt], typename Loader::Raw (&rNext)[RA],
+                    BReg (&bNext)[RBt]) __attribute__((always_inline)) {
         const char *cur = smem + (kc & 1) * kStage;
         char *nxt = smem + ((kc + 1) & 1) * kStage;
         const int k2 = kc + 2 < last ? kc + 2 : last;
         if constexpr (!(ABL & 1)) {
             loader.issue(rNext, k2);
-#pragma unroll
-            for (int i = 0; i < RBt; ++i) bNext[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)k2 * kBK);
+            load_b(bNext, k2);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the global loads at the top: they must fly during the MFMAs
         trace(1);  // global loads issued
         if constexpr (!(ABL & 2)) {
             loader.finish(rCur, ra);
-#pragma unroll
-            for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_a[i]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < RBt; ++i) *reinterpret_cast<f32x4 *>(nxt + st_off_b[i]) = bCur[i];
+            stage(nxt, ra, bCur);
         }
 
         trace(2);  // previous chunk's registers staged to LDS (issue)
+        if constexpr (SPLIT) {
+            // two k-groups of 16; per group and 32x32 block the six piece products, smallest first.  Weights are the
+            // FIRST operand, as in the fp32 path: the accumulators hold the block transposed (see the epilogue).
+            bf16x8 af[2][RB][3], bf[2][CB][3];
+            auto frags = [&](int g, bf16x8 (&ao)[RB][3], bf16x8 (&bo)[CB][3]) __attribute__((always_inline)) {
+                const int coff = ((2 * g + fhi) ^ fsw) << 4;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) ao[i][q] = *reinterpret_cast<const bf16x8 *>(cur + q * kPlaneA + rd_a[i] + coff);
+#pragma unroll
+                    for (int i = 0; i < CB; ++i) bo[i][q] = *reinterpret_cast<const bf16x8 *>(cur + q * kPlaneB + rd_b[i] + coff);
+                }
+            };
+            frags(0, af[0], bf[0]);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 0) frags(1, af[1], bf[1]);
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) {
+                        f32x16 t = acc[i][c];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][0], af[g][i][2], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][1], af[g][i][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][2], af[g][i][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][0], af[g][i][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][1], af[g][i][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][0], af[g][i][0], t, 0, 0, 0);
+                        acc[i][c] = t;
+                    }
+            }
+            trace(3);
+            if constexpr (!(ABL & 4)) __syncthreads();
+            trace(4);
+            return;
+        }
         // fragments of k-group g+1 are read from LDS while the MFMAs of group g run
         f32x4 a[2][RB], b[2][CB];
         if constexpr (ABL & 8) {  // stale-register operands, kept opaque so nothing is folded away
@@ -375,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
                 for (int i = 0; i < RB; ++i) a[u][i] = ra[i];
 #pragma unroll
-                for (int i = 0; i < CB; ++i) b[u][i] = bCur[i];
+                for (int i = 0; i < CB; ++i) b[u][i] = ra[i];
             }
         } else {
             const int coff = (fhi ^ fsw) << 4;

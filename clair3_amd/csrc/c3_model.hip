@@ -124,6 +124,8 @@ struct c3_model {
     float *conv_w[9] = {};
     float *conv_b[9] = {};
     float *wino_v[9] = {};   // Winograd-domain weights of the stride-1 convs (layers 1,2,4,5,7,8)
+    float *conv_w3[9] = {};  // direct-conv weights as three bf16 pieces [3][Cout][K] (uint16 payload), layers in conv_split_mask
+    unsigned conv_split_mask = 0x48;  // stride-2 convs conv3 / conv5 on the bf16x6 split path (c3_gemm.h SPLIT); env C3HIP_CONV_SPLITMASK
     bool use_wino[9] = {};
     // Measured on MI355X (B=256), direct implicit GEMM -> Winograd v1: res1 134/144 -> 105/112 us, res2 163/172 ->
     // 110/113 us, res3 171/179 -> 162/164 us (res3 gains little: 18 tiles per window quantise badly and its input
@@ -191,17 +193,18 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------ launches
-template <class Loader, int EPI, int BM, int BN>
+template <class Loader, int EPI, int BM, int BN, bool SPLIT = false>
 static int launch_gemm(hipStream_t s, const typename Loader::Params &lp, const float *bt, int64_t ldb, int M, int N,
-                       int nk, int splits, const EpilogueParams &ep) {
+                       int nk, int splits, const EpilogueParams &ep, const float *bt3 = nullptr) {
     if (N % BN) return fail("internal: N=%d not a multiple of BN=%d", N, BN);
     if (M <= 0) return 0;
     GemmParams gp;
     gp.bt = bt, gp.ldb = ldb, gp.M = M, gp.N = N, gp.nk = nk;
+    gp.bt3 = reinterpret_cast<const uint16_t *>(bt3);
     gp.tiles_n = N / BN;
     gp.tiles = ((M + BM - 1) / BM) * gp.tiles_n;
     dim3 grid(gp.tiles, splits);
-    hipLaunchKernelGGL((gemm_mfma_kernel<Loader, EPI, BM, BN>), grid, dim3(kThreads), 0, s, lp, gp, ep);
+    hipLaunchKernelGGL((gemm_mfma_kernel<Loader, EPI, BM, BN, 0, SPLIT>), grid, dim3(kThreads), 0, s, lp, gp, ep);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -235,6 +238,35 @@ static int upload(c3_model *m, float **dst, const std::vector<float> &src) {
     *dst = (float *)p;
     (void)m;
     return 0;
+}
+
+// A weight matrix as three bf16 pieces for the SPLIT path of gemm_mfma_kernel: w = p0 + p1 + p2, every piece rounded
+// to nearest even, the remainders exact in fp32.  Layout [3][n]: uint16 payload carried in a float allocation.
+static int upload_bf16_pieces(c3_model *m, float **dst, const std::vector<float> &w) {
+    auto bf16_rne = [](float f) -> uint16_t {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    auto bf16_f32 = [](uint16_t h) -> float {
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    const size_t n = w.size();
+    std::vector<float> pieces((3 * n + 1) / 2);
+    uint16_t *q = reinterpret_cast<uint16_t *>(pieces.data());
+    for (size_t i = 0; i < n; ++i) {
+        float r = w[i];
+        for (int lvl = 0; lvl < 3; ++lvl) {
+            const uint16_t h = bf16_rne(r);
+            q[lvl * n + i] = h;
+            r -= bf16_f32(h);
+        }
+    }
+    return upload(m, dst, pieces);
 }
 
 static void free_workspace(c3_model *m) {
@@ -495,6 +527,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     }
     TRY(upload(m, &m->conv_w[l], pw));
     TRY(upload(m, &m->conv_b[l], pb));
+    if (l > 0 && (m->conv_split_mask & (1u << l))) TRY(upload_bf16_pieces(m, &m->conv_w3[l], pw));
     if (l == 0 && Cin == 8) {
         // conv1_i8_kernel: k-step s = 4 tap + j of lane (n = lane & 31, kk = lane >> 5) multiplies channel 4 kk + j of tap s / 4
         std::vector<float> pf((size_t)36 * 2 * 64);
@@ -635,7 +668,9 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             const int nk = 9 * cin / kBK;
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
-            if (Cout == 64 || (m->conv_bn64_mask & (1u << l))) {
+            if (!res && m->conv_w3[l] && (m->conv_split_mask & (1u << l))) {
+                TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RELU, 128, 64, true>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep, m->conv_w3[l])));
+            } else if (Cout == 64 || (m->conv_bn64_mask & (1u << l))) {
                 if (res)
                     TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RES_RELU, 128, 64>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep)));
                 else
@@ -851,6 +886,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_BN64MASK")) m->conv_bn64_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_CONV_SPLITMASK")) m->conv_split_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_PROJ2_STREAM")) m->proj2_stream = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_DIRECT")) m->conv1_direct = atoi(e) != 0;
@@ -1137,6 +1173,7 @@ int c3_model_destroy(c3_model *m) {
         if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);
         if (m->wino_v[l]) (void)hipFree(m->wino_v[l]);
+        if (m->conv_w3[l]) (void)hipFree(m->conv_w3[l]);
     }
     for (auto &sl : m->slot) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);

@@ -311,6 +311,31 @@ def test_model_handles_release_their_device_memory():
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of HBM lost over 12 create/predict/destroy cycles"
 
 
+def test_split_bf16_convolutions_are_as_close_to_the_oracle_as_the_fp32_ones(monkeypatch, oracle_mod):
+    """conv3 / conv5 run on v_mfma_f32_32x32x16_bf16 with every operand split into three bf16 pieces (six piece products
+    = the fp32 product up to 2^-24, c3_gemm.h SPLIT).  Their outputs (act3, act6) and the final rows must sit as close to
+    the fp64 oracle as the fp32-MFMA kernels do -- not merely inside the 1e-4 gate."""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=31, peaked=True)
+    x = syn.make_fa_windows(9, seed=32)
+    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+    errs = {}
+    for mask in ("0x48", "0"):
+        monkeypatch.setenv("C3HIP_CONV_SPLITMASK", mask)
+        m = make_model(syn.FULL_ALIGNMENT, 8, True, sd, keep=True)
+        y = m.predict_numpy(x)
+        e = {}
+        for name in ("act3", "act6"):
+            a = m.debug_fetch(name, d[name].shape)
+            e[name] = float(np.abs(a - d[name]).max()) / max(1.0, float(np.abs(d[name]).max()))
+        e["y"] = util.assert_rows_match(y, y_o, what=f"split mask {mask}")
+        errs[mask] = e
+    monkeypatch.delenv("C3HIP_CONV_SPLITMASK")
+    print(errs)
+    for k in ("act3", "act6", "y"):
+        assert errs["0x48"][k] < 2e-5
+        assert errs["0x48"][k] <= 3 * errs["0"][k] + 1e-7, (k, errs)
+
+
 def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracle_mod):
     """the A/B switches of README.md select older kernels for the same layers: each selection stays within the parity
     gate (they are what a regression is bisected with, so they must keep working)"""
@@ -321,7 +346,8 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     x_p = syn.make_pileup_windows(70, seed=24)
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
     fa_sets = [{"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
-               {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"}]
+               {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"},
+               {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0"}]
     for env in fa_sets:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
