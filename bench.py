@@ -160,7 +160,7 @@ def run_workload(name, args, rank, world, local):
                       for r in stats}
     if kind == syn.FULL_ALIGNMENT:
         dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res"))]
-        dom_name = ("3x3 convolution family: conv1_i8_kernel + gemm_mfma_kernel<ConvLoader> (stride-2 implicit GEMM) + "
+        dom_name = ("3x3 convolution family: conv1_i8_kernel + gemm_mfma_kernel<ConvLoader> (stride-2 implicit GEMM, bf16x6 split products) + "
                     "wino_conv_kernel_p (persistent Winograd F(2x2,3x3) on the six stride-1 convs), 9 launches per step, fp32 MFMA")
     else:
         dom = [r for r in stats if r["name"].startswith("p.lstm")]
@@ -188,9 +188,12 @@ def run_workload(name, args, rank, world, local):
         "hbm_algorithmic_gbs": res["value"] / world * bytes_w / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
     }
     if kind == syn.FULL_ALIGNMENT:
-        res["roofline"]["note"] = ("achieved = ALGORITHMIC FLOP (direct 3x3 convolution, SURVEY 8d) / measured kernel time; the six "
-                                   "stride-1 layers run as Winograd F(2x2,3x3) and execute 2.25x fewer multiplications, so frac can "
-                                   "exceed 1; matrix-pipe busy time per kernel: profiles/*_pmc_sq.md (SQ_VALU_MFMA_BUSY_CYCLES)")
+        res["roofline"]["note"] = ("achieved = ALGORITHMIC FLOP (direct 3x3 convolution, SURVEY 8d) / measured kernel time; peak = the "
+                                   "fp32-MFMA roof.  frac can exceed 1: the six stride-1 layers run as Winograd F(2x2,3x3) (2.25x "
+                                   "fewer multiplications), and conv3 / conv5 form their fp32 products from three bf16 pieces per "
+                                   "operand on v_mfma_f32_32x32x16_bf16 (six piece products, exact to 2^-24, fp32 accumulation: "
+                                   "DESIGN.md 3.1 SPLIT; C3HIP_CONV_SPLITMASK=0 C3HIP_L4_SPLIT=0 runs everything on fp32 MFMAs). "
+                                   "Matrix-pipe busy time per kernel: profiles/*_pmc_sq.md (SQ_VALU_MFMA_BUSY_CYCLES)")
     return res
 
 
@@ -288,6 +291,7 @@ def main():
             "metric": "candidate-windows/sec", "value": head["value"], "unit": "candidate-windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 storage, accumulation and results; conv3/conv5/L4 products via bf16x6 split MFMA (DESIGN.md 3.1)",
             "config": {"workload": head["workload"], "batch_per_gpu": head["batch_per_gpu"],
                        "windows_per_step": head["windows_per_step"], "weights": "seeded random (no checkpoints offline)",
                        "sharding": f"windows x{world}, gather of probability rows to rank 0" if world > 1 else "single GPU",

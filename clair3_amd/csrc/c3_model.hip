@@ -143,6 +143,10 @@ struct c3_model {
     unsigned wino_mask = 0x1b6;  // layers run as Winograd (bit l): all six stride-1 convs; env C3HIP_WINOGRAD overrides
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
+    float *l4_w3 = nullptr;                  // the same as three bf16 pieces (SPLIT path); env C3HIP_L4_SPLIT
+    bool l4_split = true;
+    float *proj2_w3 = nullptr;               // LSTM2 projection weights as bf16 pieces for the tiled SPLIT GEMM; env C3HIP_PROJ2_SPLIT
+    bool proj2_split = false;
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
     float *w5f = nullptr, *whf = nullptr, *bh48 = nullptr;  // MFMA fragment packing of the same weights (c3_tail.h)
     bool tail_mfma = true;                                   // env C3HIP_TAIL_MFMA
@@ -339,6 +343,7 @@ static int pack_tail(c3_model *m, const TensorMap &tm) {
     TRY(want(tm, "L4.weight", {FC, K4}, &w));
     TRY(want(tm, "L4.bias", {FC}, &b));
     TRY(upload(m, &m->l4_w, std::vector<float>(w, w + (size_t)FC * K4)));
+    if (m->l4_split) TRY(upload_bf16_pieces(m, &m->l4_w3, std::vector<float>(w, w + (size_t)FC * K4)));
     TRY(upload(m, &m->l4_b, std::vector<float>(b, b + FC)));
     std::vector<float> w5t((size_t)FC * nb * 128), b5((size_t)nb * 128), wh((size_t)nb * 128 * 64, 0.f), bh((size_t)nb * 64, 0.f);
     for (int br = 0; br < nb; ++br) {
@@ -434,6 +439,7 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                             pf[((((size_t)cb * 32 + i) * 64) + lane) * 4 + e] =
                                 pw[(size_t)(32 * cb + (lane & 31)) * Kp + 128 * (lane >> 5) + 4 * i + e];
             TRY(upload(m, &m->proj2_frag, pf));
+            if (m->proj2_split) TRY(upload_bf16_pieces(m, &m->proj2_w3, pw));
         }
         TRY(upload(m, &m->proj_w[layer], pw));
         TRY(upload(m, &m->proj_b[layer], pb));
@@ -579,7 +585,10 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         ProfScope ps(m, s, tag_l4, 2.0 * n * FC * K4, 4.0 * (n * K4 + (double)FC * K4 + (double)S * n * FC));
         DenseLoaderParams lp{a, lda};
         EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
-        TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
+        if (m->l4_split && m->l4_w3)
+            TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64, true>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3)));
+        else
+            TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
     }
     const double fl = 2.0 * n * (FC * 128.0 * m->nb + 128.0 * m->nout);
     if (m->tail_mfma && m->w5f) {
@@ -748,7 +757,12 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.proj2", 2.0 * M * 1280.0 * 256.0, 4.0 * M * (256.0 + 1280.0));
-        if (m->proj2_stream && m->proj2_frag && m->lstm2_v2) {
+        if (m->proj2_split && m->proj2_w3 && m->lstm2_v2) {
+            DenseLoaderParams lp{m->h1, 256};
+            EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
+            // 128x64 tiles (72 KB of LDS, two workgroups per CU); 128x128 (96 KB, one per CU) measured 193 us
+            TRY((launch_gemm<DenseLoader<4>, EPI_BIAS, 128, 64, true>(s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep, m->proj2_w3)));
+        } else if (m->proj2_stream && m->proj2_frag && m->lstm2_v2) {
             ProjParams pp{m->h1, m->proj2_frag, m->proj_b[1], m->gx2, M, 1280, (M + 31) / 32, 40, nullptr};
             static int trace_left = getenv("C3HIP_PROJ_TRACE") ? 3 : 0;  // debug: the third launch is traced
             static unsigned long long *trace_dev = nullptr;
@@ -887,6 +901,8 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_BN64MASK")) m->conv_bn64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_SPLITMASK")) m->conv_split_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("C3HIP_L4_SPLIT")) m->l4_split = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_PROJ2_SPLIT")) m->proj2_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_PROJ2_STREAM")) m->proj2_stream = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_DIRECT")) m->conv1_direct = atoi(e) != 0;
@@ -1165,7 +1181,7 @@ int c3_model_destroy(c3_model *m) {
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
                    m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias,
-                   m->conv1_wfrag, m->w5f, m->whf, m->bh48, m->proj2_frag};
+                   m->conv1_wfrag, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     if (m->decode_dev) (void)hipFree(m->decode_dev);
