@@ -31,6 +31,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // SPLIT mode (bf16x6): an fp32 value is the exact sum of three bf16 pieces x = x0 + x1 + x2 (8 mantissa bits each);
 // x*w is formed from the six piece products x0w0, x0w1, x1w0, x0w2, x1w1, x2w0 on v_mfma_f32_32x32x16_bf16 (products
@@ -50,6 +52,22 @@ __device__ __forceinline__ void split3_bf16(const f32x4 x, u32x2 (&piece)[3]) {
                 r[i + 1] -= __uint_as_float(u & 0xffff0000u);
             }
         }
+    }
+}
+
+// SPLIT mode 2 (fp16x3): x = h0 + h1 with two fp16 pieces (11 mantissa bits each, round to nearest, subnormals kept --
+// v_mfma_f32_32x32x16_f16 honours subnormal inputs, tools/f16_denorm_probe.hip); x*w from x0w0 + x0w1 + x1w0, dropping
+// x1w1 < 2^-22 of the product.  Same operand bytes as fp32 (two 16-bit pieces), half the matrix instructions of bf16x6
+// and 2.5 instead of 4.5 vector instructions per split value; rows as close to the reference as the fp32 path's
+// (tests/diag/bf16x_study.py).  Needs |x| < 65504, which every activation and weight of these networks satisfies by orders of
+// magnitude (int8/100 inputs, BatchNorm-scaled stages).
+__device__ __forceinline__ void split2_f16(const f32x4 x, u32x2 (&piece)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const f16x2 h = __builtin_convertvector(f32x2{x[i], x[i + 1]}, f16x2);
+        const f32x2 r = f32x2{x[i], x[i + 1]} - __builtin_convertvector(h, f32x2);
+        piece[0][i >> 1] = __builtin_bit_cast(uint32_t, h);
+        piece[1][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
     }
 }
 
@@ -288,16 +306,18 @@ struct GemmParams {
 
 // ABL: ablation switches for tools/mfma_probe (0 in the product).  bit0: no global loads in the loop,
 // bit1: no LDS staging writes, bit2: no barrier, bit3: no LDS fragment reads (MFMAs on stale registers).
-template <class Loader, int EPI, int BM, int BN, int ABL = 0, bool SPLIT = false>
+template <class Loader, int EPI, int BM, int BN, int ABL = 0, int SPLIT = 0>
 __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Params lp, GemmParams gp,
                                                               EpilogueParams ep) {
     constexpr int RA = BM / 32, RBt = BN / 32;  // staged rows per thread
     constexpr int RB = BM / 64, CB = BN / 64;   // 32x32 accumulators per wave (rows x cols)
-    // fp32: rows of 32 floats (128 B).  SPLIT: per operand three piece planes with rows of 32 bf16 (64 B).
+    // fp32: rows of 32 floats (128 B).  SPLIT: per operand NP piece planes with rows of 32 16-bit values (64 B);
+    // SPLIT 1 = bf16x6 (three bf16 pieces, six products), SPLIT 2 = fp16x3 (two fp16 pieces, three products).
+    constexpr int NP = SPLIT == 1 ? 3 : 2;
     constexpr int kRowB = SPLIT ? 64 : 128;
     constexpr int kPlaneA = BM * 64, kPlaneB = BN * 64;          // SPLIT: bytes of one piece plane
-    constexpr int kStage = SPLIT ? 3 * (kPlaneA + kPlaneB) : (BM + BN) * 128;  // bytes per LDS stage
-    constexpr int kBase_b = SPLIT ? 3 * kPlaneA : BM * 128;
+    constexpr int kStage = SPLIT ? NP * (kPlaneA + kPlaneB) : (BM + BN) * 128;  // bytes per LDS stage
+    constexpr int kBase_b = SPLIT ? NP * kPlaneA : BM * 128;
     __shared__ __attribute__((aligned(16))) char smem[2 * kStage];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -315,9 +335,9 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
     if constexpr (requires { loader.seek(0); }) loader.seek(k0);
 
     struct BPieces {
-        u32x2 p[3];
+        u32x2 p[NP];
     };
-    using BReg = std::conditional_t<SPLIT, BPieces, f32x4>;  // one thread's 4 k of one weight row: fp32, or 3 x 4 bf16
+    using BReg = std::conditional_t<(SPLIT != 0), BPieces, f32x4>;  // one thread's 4 k of one weight row: fp32, or NP x 4 16-bit pieces
     const float *bptr[RBt];
     const uint16_t *bptr3[RBt];
     const int64_t piece_stride = (int64_t)gp.N * gp.ldb;
@@ -331,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         for (int i = 0; i < RBt; ++i) {
             if constexpr (SPLIT) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < NP; ++q)
                     dst[i].p[q] = *reinterpret_cast<const u32x2 *>(bptr3[i] + q * piece_stride + (int64_t)kchunk * kBK);
             } else {
                 dst[i] = *reinterpret_cast<const f32x4 *>(bptr[i] + (int64_t)kchunk * kBK);
@@ -356,15 +376,16 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         if constexpr (SPLIT) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
-                u32x2 pc[3];
-                split3_bf16(av[i], pc);
+                u32x2 pc[NP];
+                if constexpr (SPLIT == 1) split3_bf16(av[i], pc);
+                else split2_f16(av[i], pc);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneA + st_off_a[i]) = pc[q];
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneA + st_off_a[i]) = pc[q];
             }
 #pragma unroll
             for (int i = 0; i < RBt; ++i)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneB + st_off_b[i]) = bv[i].p[q];
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneB + st_off_b[i]) = bv[i].p[q];
         } else {
 #pragma unroll
             for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(dst + st_off_a[i]) = av[i];
@@ -443,16 +464,23 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         if constexpr (SPLIT) {
             // two k-groups of 16; per group and 32x32 block the six piece products, smallest first.  Weights are the
             // FIRST operand, as in the fp32 path: the accumulators hold the block transposed (see the epilogue).
-            bf16x8 af[2][RB][3], bf[2][CB][3];
-            auto frags = [&](int g, bf16x8 (&ao)[RB][3], bf16x8 (&bo)[CB][3]) __attribute__((always_inline)) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 af[2][RB][NP], bf[2][CB][NP];
+            auto frags = [&](int g, u32x4 (&ao)[RB][NP], u32x4 (&bo)[CB][NP]) __attribute__((always_inline)) {
                 const int coff = ((2 * g + fhi) ^ fsw) << 4;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NP; ++q) {
 #pragma unroll
-                    for (int i = 0; i < RB; ++i) ao[i][q] = *reinterpret_cast<const bf16x8 *>(cur + q * kPlaneA + rd_a[i] + coff);
+                    for (int i = 0; i < RB; ++i) ao[i][q] = *reinterpret_cast<const u32x4 *>(cur + q * kPlaneA + rd_a[i] + coff);
 #pragma unroll
-                    for (int i = 0; i < CB; ++i) bo[i][q] = *reinterpret_cast<const bf16x8 *>(cur + q * kPlaneB + rd_b[i] + coff);
+                    for (int i = 0; i < CB; ++i) bo[i][q] = *reinterpret_cast<const u32x4 *>(cur + q * kPlaneB + rd_b[i] + coff);
                 }
+            };
+            auto mma = [&](f32x16 t, u32x4 w, u32x4 x) __attribute__((always_inline)) {
+                if constexpr (SPLIT == 1)
+                    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), t, 0, 0, 0);
+                else
+                    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), t, 0, 0, 0);
             };
             frags(0, af[0], bf[0]);
 #pragma unroll
@@ -463,12 +491,14 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
                     for (int c = 0; c < CB; ++c) {
                         f32x16 t = acc[i][c];
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][0], af[g][i][2], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][1], af[g][i][1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][2], af[g][i][0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][0], af[g][i][1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][1], af[g][i][0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][c][0], af[g][i][0], t, 0, 0, 0);
+                        if constexpr (SPLIT == 1) {
+                            t = mma(t, bf[g][c][0], af[g][i][2]);
+                            t = mma(t, bf[g][c][1], af[g][i][1]);
+                            t = mma(t, bf[g][c][2], af[g][i][0]);
+                        }
+                        t = mma(t, bf[g][c][0], af[g][i][1]);
+                        t = mma(t, bf[g][c][1], af[g][i][0]);
+                        t = mma(t, bf[g][c][0], af[g][i][0]);
                         acc[i][c] = t;
                     }
             }

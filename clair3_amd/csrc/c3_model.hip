@@ -125,7 +125,8 @@ struct c3_model {
     float *conv_b[9] = {};
     float *wino_v[9] = {};   // Winograd-domain weights of the stride-1 convs (layers 1,2,4,5,7,8)
     float *conv_w3[9] = {};  // direct-conv weights as three bf16 pieces [3][Cout][K] (uint16 payload), layers in conv_split_mask
-    unsigned conv_split_mask = 0x48;  // stride-2 convs conv3 / conv5 on the bf16x6 split path (c3_gemm.h SPLIT); env C3HIP_CONV_SPLITMASK
+    unsigned conv_split_mask = 0x48;  // stride-2 convs conv3 / conv5 on the split-precision path (c3_gemm.h SPLIT); env C3HIP_CONV_SPLITMASK
+    int split_kind = 2;               // 2 = fp16x3 (two fp16 pieces, three products), 1 = bf16x6 (three bf16 pieces, six products); env C3HIP_SPLIT_KIND
     bool use_wino[9] = {};
     // Measured on MI355X (B=256), direct implicit GEMM -> Winograd v1: res1 134/144 -> 105/112 us, res2 163/172 ->
     // 110/113 us, res3 171/179 -> 162/164 us (res3 gains little: 18 tiles per window quantise badly and its input
@@ -197,7 +198,7 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------ launches
-template <class Loader, int EPI, int BM, int BN, bool SPLIT = false>
+template <class Loader, int EPI, int BM, int BN, int SPLIT = 0>
 static int launch_gemm(hipStream_t s, const typename Loader::Params &lp, const float *bt, int64_t ldb, int M, int N,
                        int nk, int splits, const EpilogueParams &ep, const float *bt3 = nullptr) {
     if (N % BN) return fail("internal: N=%d not a multiple of BN=%d", N, BN);
@@ -244,9 +245,10 @@ static int upload(c3_model *m, float **dst, const std::vector<float> &src) {
     return 0;
 }
 
-// A weight matrix as three bf16 pieces for the SPLIT path of gemm_mfma_kernel: w = p0 + p1 + p2, every piece rounded
-// to nearest even, the remainders exact in fp32.  Layout [3][n]: uint16 payload carried in a float allocation.
-static int upload_bf16_pieces(c3_model *m, float **dst, const std::vector<float> &w) {
+// A weight matrix as 16-bit pieces for the SPLIT paths of gemm_mfma_kernel, layout [pieces][n] (uint16 payload carried
+// in a float allocation), every piece rounded to nearest even, the remainders exact in fp32:
+//   kind 1: w = p0 + p1 + p2, bf16;   kind 2: w = h0 + h1, fp16 (subnormals kept).
+static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float> &w) {
     auto bf16_rne = [](float f) -> uint16_t {
         uint32_t u;
         memcpy(&u, &f, 4);
@@ -260,18 +262,29 @@ static int upload_bf16_pieces(c3_model *m, float **dst, const std::vector<float>
         return f;
     };
     const size_t n = w.size();
-    std::vector<float> pieces((3 * n + 1) / 2);
+    const int np = m->split_kind == 1 ? 3 : 2;
+    std::vector<float> pieces((np * n + 1) / 2);
     uint16_t *q = reinterpret_cast<uint16_t *>(pieces.data());
     for (size_t i = 0; i < n; ++i) {
         float r = w[i];
-        for (int lvl = 0; lvl < 3; ++lvl) {
-            const uint16_t h = bf16_rne(r);
-            q[lvl * n + i] = h;
-            r -= bf16_f32(h);
+        for (int lvl = 0; lvl < np; ++lvl) {
+            if (m->split_kind == 1) {
+                const uint16_t h = bf16_rne(r);
+                q[lvl * n + i] = h;
+                r -= bf16_f32(h);
+            } else {
+                const _Float16 h = (_Float16)r;  // round to nearest even, subnormals kept
+                memcpy(&q[lvl * n + i], &h, 2);
+                r -= (float)h;
+            }
         }
     }
     return upload(m, dst, pieces);
 }
+
+// launch the SPLIT instantiation the model was packed for
+#define LAUNCH_SPLIT(m, Loader, EPI, BM, BN, ...) \
+    ((m)->split_kind == 1 ? launch_gemm<Loader, EPI, BM, BN, 1>(__VA_ARGS__) : launch_gemm<Loader, EPI, BM, BN, 2>(__VA_ARGS__))
 
 static void free_workspace(c3_model *m) {
     for (auto &b : m->bufs) (void)hipFree(b.p);
@@ -343,7 +356,7 @@ static int pack_tail(c3_model *m, const TensorMap &tm) {
     TRY(want(tm, "L4.weight", {FC, K4}, &w));
     TRY(want(tm, "L4.bias", {FC}, &b));
     TRY(upload(m, &m->l4_w, std::vector<float>(w, w + (size_t)FC * K4)));
-    if (m->l4_split) TRY(upload_bf16_pieces(m, &m->l4_w3, std::vector<float>(w, w + (size_t)FC * K4)));
+    if (m->l4_split) TRY(upload_split_pieces(m, &m->l4_w3, std::vector<float>(w, w + (size_t)FC * K4)));
     TRY(upload(m, &m->l4_b, std::vector<float>(b, b + FC)));
     std::vector<float> w5t((size_t)FC * nb * 128), b5((size_t)nb * 128), wh((size_t)nb * 128 * 64, 0.f), bh((size_t)nb * 64, 0.f);
     for (int br = 0; br < nb; ++br) {
@@ -439,7 +452,7 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                             pf[((((size_t)cb * 32 + i) * 64) + lane) * 4 + e] =
                                 pw[(size_t)(32 * cb + (lane & 31)) * Kp + 128 * (lane >> 5) + 4 * i + e];
             TRY(upload(m, &m->proj2_frag, pf));
-            if (m->proj2_split) TRY(upload_bf16_pieces(m, &m->proj2_w3, pw));
+            if (m->proj2_split) TRY(upload_split_pieces(m, &m->proj2_w3, pw));
         }
         TRY(upload(m, &m->proj_w[layer], pw));
         TRY(upload(m, &m->proj_b[layer], pb));
@@ -533,7 +546,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     }
     TRY(upload(m, &m->conv_w[l], pw));
     TRY(upload(m, &m->conv_b[l], pb));
-    if (l > 0 && (m->conv_split_mask & (1u << l))) TRY(upload_bf16_pieces(m, &m->conv_w3[l], pw));
+    if (l > 0 && (m->conv_split_mask & (1u << l))) TRY(upload_split_pieces(m, &m->conv_w3[l], pw));
     if (l == 0 && Cin == 8) {
         // conv1_i8_kernel: k-step s = 4 tap + j of lane (n = lane & 31, kk = lane >> 5) multiplies channel 4 kk + j of tap s / 4
         std::vector<float> pf((size_t)36 * 2 * 64);
@@ -586,7 +599,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         DenseLoaderParams lp{a, lda};
         EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
         if (m->l4_split && m->l4_w3)
-            TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64, true>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3)));
+            TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_PARTIAL, 128, 64, s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3));
         else
             TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
     }
@@ -678,7 +691,12 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
             if (!res && m->conv_w3[l] && (m->conv_split_mask & (1u << l))) {
-                TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RELU, 128, 64, true>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep, m->conv_w3[l])));
+                // fp16x3 keeps the fp32 kernel's LDS footprint, so conv3 (N = 128) can use 128x128 tiles at two workgroups
+                // per CU (43 -> 38 us); conv5 stays on 128x64 (480 workgroups), bf16x6 needs 72 KB per 128x64 tile
+                if (m->split_kind == 2 && !(m->conv_bn64_mask & (1u << l)))
+                    TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RELU, 128, 128, 2>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep, m->conv_w3[l])));
+                else
+                    TRY(LAUNCH_SPLIT(m, ConvLoader<4>, EPI_BIAS_RELU, 128, 64, s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep, m->conv_w3[l]));
             } else if (Cout == 64 || (m->conv_bn64_mask & (1u << l))) {
                 if (res)
                     TRY((launch_gemm<ConvLoader<4>, EPI_BIAS_RES_RELU, 128, 64>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep)));
@@ -761,7 +779,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             DenseLoaderParams lp{m->h1, 256};
             EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
             // 128x64 tiles (72 KB of LDS, two workgroups per CU); 128x128 (96 KB, one per CU) measured 193 us
-            TRY((launch_gemm<DenseLoader<4>, EPI_BIAS, 128, 64, true>(s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep, m->proj2_w3)));
+            TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_BIAS, 128, 64, s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep, m->proj2_w3));
         } else if (m->proj2_stream && m->proj2_frag && m->lstm2_v2) {
             ProjParams pp{m->h1, m->proj2_frag, m->proj_b[1], m->gx2, M, 1280, (M + 31) / 32, 40, nullptr};
             static int trace_left = getenv("C3HIP_PROJ_TRACE") ? 3 : 0;  // debug: the third launch is traced
@@ -902,6 +920,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_CONV_BN64MASK")) m->conv_bn64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_SPLITMASK")) m->conv_split_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_L4_SPLIT")) m->l4_split = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_SPLIT_KIND")) m->split_kind = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("C3HIP_PROJ2_SPLIT")) m->proj2_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_PROJ2_STREAM")) m->proj2_stream = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;

@@ -25,10 +25,10 @@ PAIRS = {1: [(0, 0)], 3: [(0, 0), (0, 1), (1, 0)], 6: [(0, 0), (0, 1), (1, 0), (
          9: [(i, j) for i in range(3) for j in range(3)]}
 
 
-def pieces(t, n):
+def pieces(t, n, dtype=torch.bfloat16):
     out, r = [], t
     for _ in range(n):
-        p = r.to(torch.bfloat16).float()
+        p = r.to(dtype).float()
         out.append(p)
         r = r - p
     return out
@@ -37,10 +37,16 @@ def pieces(t, n):
 def split_conv(x, w, b, stride, products):
     if products == 0:
         return F.conv2d(x, w, b, stride=stride, padding=1)
-    n = {1: 1, 3: 2, 6: 3, 9: 3}[products]
-    xs, ws = pieces(x, n), pieces(w, n)
+    if products < 0:  # fp16 pieces: -1 = single fp16, -3 = two pieces each, x0w0 + x0w1 + x1w0, -4 = + x1w1
+        n = 1 if products == -1 else 2
+        xs, ws = pieces(x, n, torch.float16), pieces(w, n, torch.float16)
+        pairs = {-1: [(0, 0)], -3: [(0, 0), (0, 1), (1, 0)], -4: [(0, 0), (0, 1), (1, 0), (1, 1)]}[products]
+    else:
+        n = {1: 1, 3: 2, 6: 3, 9: 3}[products]
+        xs, ws = pieces(x, n), pieces(w, n)
+        pairs = PAIRS[products]
     acc = None
-    for i, j in sorted(PAIRS[products], key=lambda p: -(p[0] + p[1])):  # small terms first
+    for i, j in sorted(pairs, key=lambda p: -(p[0] + p[1])):  # small terms first
         y = F.conv2d(xs[i], ws[j], None, stride=stride, padding=1)
         acc = y if acc is None else acc + y
     return acc + b.view(1, -1, 1, 1)
@@ -72,10 +78,10 @@ def main():
         sd, x = util.case_inputs(meta)
         sd = torch_port.to_torch(sd)
         ref = util.golden_y(name)
-        for products in (0, 9, 6, 3, 1):
+        for products in (0, 9, 6, 3, 1, -4, -3, -1):
             y = fa_forward(sd, x, meta["add_indel_length"], products)
             bad = sum(len(v) for v in util.label_mismatches(y, ref).values()) if isinstance(util.label_mismatches(y, ref), dict) else util.label_mismatches(y, ref)
-            print(f"{name:22s} {('fp32' if products == 0 else 'bf16x%d' % products):>9s} {np.abs(y - ref).max():10.2e} {str(bad):>17s}")
+            print(f"{name:22s} {('fp32' if products == 0 else 'bf16x%d' % products if products > 0 else 'fp16x%d' % -products):>9s} {np.abs(y - ref).max():10.2e} {str(bad):>17s}")
 
 
 if __name__ == "__main__":

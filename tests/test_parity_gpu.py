@@ -312,28 +312,32 @@ def test_model_handles_release_their_device_memory():
 
 
 def test_split_bf16_convolutions_are_as_close_to_the_oracle_as_the_fp32_ones(monkeypatch, oracle_mod):
-    """conv3 / conv5 run on v_mfma_f32_32x32x16_bf16 with every operand split into three bf16 pieces (six piece products
-    = the fp32 product up to 2^-24, c3_gemm.h SPLIT).  Their outputs (act3, act6) and the final rows must sit as close to
-    the fp64 oracle as the fp32-MFMA kernels do -- not merely inside the 1e-4 gate."""
+    """conv3 / conv5 run on 16-bit matrix instructions with every fp32 operand split into pieces (c3_gemm.h SPLIT:
+    fp16x3 = two fp16 pieces, three piece products, the default; bf16x6 = three bf16 pieces, six products).  Their
+    outputs (act3, act6) and the final rows must sit as close to the fp64 oracle as the fp32-MFMA kernels do -- not
+    merely inside the 1e-4 gate."""
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=31, peaked=True)
     x = syn.make_fa_windows(9, seed=32)
     y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
     errs = {}
-    for mask in ("0x48", "0"):
+    for mask, kind in (("0x48", "2"), ("0x48", "1"), ("0", "2")):
         monkeypatch.setenv("C3HIP_CONV_SPLITMASK", mask)
+        monkeypatch.setenv("C3HIP_SPLIT_KIND", kind)
         m = make_model(syn.FULL_ALIGNMENT, 8, True, sd, keep=True)
         y = m.predict_numpy(x)
         e = {}
         for name in ("act3", "act6"):
             a = m.debug_fetch(name, d[name].shape)
             e[name] = float(np.abs(a - d[name]).max()) / max(1.0, float(np.abs(d[name]).max()))
-        e["y"] = util.assert_rows_match(y, y_o, what=f"split mask {mask}")
-        errs[mask] = e
+        e["y"] = util.assert_rows_match(y, y_o, what=f"split mask {mask} kind {kind}")
+        errs["fp32" if mask == "0" else ("fp16x3" if kind == "2" else "bf16x6")] = e
     monkeypatch.delenv("C3HIP_CONV_SPLITMASK")
+    monkeypatch.delenv("C3HIP_SPLIT_KIND")
     print(errs)
-    for k in ("act3", "act6", "y"):
-        assert errs["0x48"][k] < 2e-5
-        assert errs["0x48"][k] <= 3 * errs["0"][k] + 1e-7, (k, errs)
+    for mode in ("fp16x3", "bf16x6"):
+        for k in ("act3", "act6", "y"):
+            assert errs[mode][k] < 2e-5
+            assert errs[mode][k] <= 3 * errs["fp32"][k] + 1e-7, (mode, k, errs)
 
 
 def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracle_mod):
@@ -347,7 +351,8 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
     fa_sets = [{"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
                {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"},
-               {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"}]
+               {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
+               {"C3HIP_SPLIT_KIND": "1"}]
     for env in fa_sets:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -355,7 +360,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
         for k in env:
             monkeypatch.delenv(k)
     for env in [{"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
-                {"C3HIP_PROJ2_SPLIT": "1"}, {"C3HIP_L4_SPLIT": "0"}]:
+                {"C3HIP_PROJ2_SPLIT": "1"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"}]:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         util.assert_rows_match(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p, what=f"pileup {env}")
