@@ -124,6 +124,8 @@ struct c3_model {
     float *conv_w[9] = {};
     float *conv_b[9] = {};
     float *wino_v[9] = {};   // Winograd-domain weights of the stride-1 convs (layers 1,2,4,5,7,8)
+    float *wino_v16[9] = {};  // the same as two fp16 pieces per weight, fragment order of the F16 persistent kernel (c3_wino_p.h)
+    unsigned wino_f16_mask = 0x1b6;  // Winograd layers on the fp16x3 split products; env C3HIP_WINOGRAD_F16MASK
     float *conv_w3[9] = {};  // direct-conv weights as three bf16 pieces [3][Cout][K] (uint16 payload), layers in conv_split_mask
     unsigned conv_split_mask = 0x48;  // stride-2 convs conv3 / conv5 on the split-precision path (c3_gemm.h SPLIT); env C3HIP_CONV_SPLITMASK
     int split_kind = 2;               // 2 = fp16x3 (two fp16 pieces, three products), 1 = bf16x6 (three bf16 pieces, six products); env C3HIP_SPLIT_KIND
@@ -583,6 +585,28 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
             }
         }
         TRY(upload(m, &m->wino_v[l], pv));
+        if ((m->wino_f16_mask & (1u << l)) && Cout % 64 == 0) {
+            // F16 kernel: fragment (nt, xi, chunk c, piece q), lane (n = lane & 31, hi = lane >> 5), 8 fp16:
+            // piece q of V_xi[n][k = 16 c + 8 hi + j] -- the fp32 fragments' bytes and addressing, g replaced by q
+            std::vector<float> pv16(pv.size());  // two 2-byte pieces per weight = the fp32 array's bytes
+            uint16_t *q16 = reinterpret_cast<uint16_t *>(pv16.data());
+            for (int nt = 0; nt < Cout / 32; ++nt)
+                for (int xi = 0; xi < 16; ++xi)
+                    for (int c = 0; c < nch; ++c)
+                        for (int gq = 0; gq < 2; ++gq)
+                            for (int hi = 0; hi < 2; ++hi)
+                                for (int ln = 0; ln < 32; ++ln)
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float v = pv[((((size_t)(nt * 16 + xi) * nch + c) * 2 + gq) * 64 + hi * 32 + ln) * 4 + e];
+                                        const int kk = 8 * gq + 4 * hi + e;  // channel within the chunk (fp32 fragment order)
+                                        const int hi16 = kk / 8, j = kk % 8;
+                                        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                        const size_t base = (((size_t)(nt * 16 + xi) * nch + c) * 2) * 64 * 8;
+                                        memcpy(&q16[base + (size_t)(0 * 64 + hi16 * 32 + ln) * 8 + j], &h0, 2);
+                                        memcpy(&q16[base + (size_t)(1 * 64 + hi16 * 32 + ln) * 8 + j], &h1, 2);
+                                    }
+            TRY(upload(m, &m->wino_v16[l], pv16));
+        }
         m->use_wino[l] = true;
     }
     return 0;
@@ -658,7 +682,13 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             if ((m->wino_p_mask & (1u << l)) && Cout % 64 == 0) {  // persistent 32 x 64 workgroups
                 wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
                 const int grid = std::min(wp.tiles, m->wg_slots / wp.tiles_n * wp.tiles_n);
-                if (wp.res)
+                if (m->wino_v16[l] && (m->wino_f16_mask & (1u << l))) {
+                    wp.v = m->wino_v16[l];
+                    if (wp.res)
+                        hipLaunchKernelGGL((wino_conv_kernel_p<true, 0, 0, true>), dim3(grid), dim3(256), 0, s, wp);
+                    else
+                        hipLaunchKernelGGL((wino_conv_kernel_p<false, 0, 0, true>), dim3(grid), dim3(256), 0, s, wp);
+                } else if (wp.res)
                     hipLaunchKernelGGL(wino_conv_kernel_p<true>, dim3(grid), dim3(256), 0, s, wp);
                 else
                     hipLaunchKernelGGL(wino_conv_kernel_p<false>, dim3(grid), dim3(256), 0, s, wp);
@@ -921,6 +951,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_CONV_SPLITMASK")) m->conv_split_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_L4_SPLIT")) m->l4_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_SPLIT_KIND")) m->split_kind = atoi(e) == 1 ? 1 : 2;
+    if (const char *e = getenv("C3HIP_WINOGRAD_F16MASK")) m->wino_f16_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_PROJ2_SPLIT")) m->proj2_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_PROJ2_STREAM")) m->proj2_stream = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;
@@ -1209,6 +1240,7 @@ int c3_model_destroy(c3_model *m) {
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);
         if (m->wino_v[l]) (void)hipFree(m->wino_v[l]);
         if (m->conv_w3[l]) (void)hipFree(m->conv_w3[l]);
+        if (m->wino_v16[l]) (void)hipFree(m->wino_v16[l]);
     }
     for (auto &sl : m->slot) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);

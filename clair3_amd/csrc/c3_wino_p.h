@@ -22,7 +22,11 @@ namespace c3 {
 // ABL (tools/wino_probe only; 0 in the product): bit0 no patch loads, bit1 no transform+LDS writes, bit2 no V loads,
 // bit3 no epilogue exchange/stores, bit4 no MFMAs.
 // OPT bit1 (tools/wino_probe.hip only): workgroup 0 records the shader clock at its phase boundaries.
-template <bool RES, int ABL = 0, int OPT = 0>
+// F16: the Winograd-domain products on v_mfma_f32_32x32x16_f16 with both operands split into two fp16 pieces
+// (fp16x3, c3_gemm.h SPLIT mode 2): the transform threads write U as two fp16 planes per xi (same 32 KiB), V arrives as
+// two fp16 fragments per (xi, chunk, column block) instead of two k-halves of fp32 (same bytes, same addressing), and a
+// chunk of 16 channels is ONE k-step: three matrix instructions of 32 cycles per xi and column block instead of eight of 64.
+template <bool RES, int ABL = 0, int OPT = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
     constexpr int PT = 32, NT = 64;
     // one LDS object: U [16][32][16] floats (32 KiB) / epilogue exchange [16][32][32] (64 KiB), then tcoord[2][PT]
@@ -66,8 +70,18 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
             tcoord[buf * PT + tl] = make_int2(((b * p.H + 2 * ty) * p.W + 2 * tx) * p.Cout * 4,
                                               (valid ? 1 : 0) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 4 : 0));
     };
-    constexpr int kPlane = PT * 64;  // bytes of one xi plane of U
-    const int u_wr = tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4) + 8 * half;
+    constexpr int kPlane = PT * 64;  // bytes of one xi plane of U (F16: two piece planes of PT * 32 bytes)
+    const int u_wr = F16 ? tl * 32 + q * 8 + half * 4 : tl * 64 + ((q ^ ((tl >> 2) & 3)) << 4) + 8 * half;
+    auto put_u = [&](char *dst, f32x2 v) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            const f16x2 h0 = __builtin_convertvector(v, f16x2);
+            const f32x2 r = v - __builtin_convertvector(h0, f32x2);
+            *reinterpret_cast<uint32_t *>(dst) = __builtin_bit_cast(uint32_t, h0);
+            *reinterpret_cast<uint32_t *>(dst + PT * 32) = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+        } else {
+            *reinterpret_cast<f32x2 *>(dst) = v;
+        }
+    };
 
     // ---- MFMA role: wave owns xi = 4*wave .. 4*wave+3, one row block (32 tiles) x two column blocks (64 couts)
     const int frow = lane & 31, fhi = lane >> 5;
@@ -162,10 +176,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
             for (int i = 0; i < (ABL & 2 ? 0 : 4); ++i) {  // U = t B, xi = 4i + j
                 const f32x2 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
                 char *dst = ubuf + u_wr;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 0) * kPlane) = t0 - t2;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 1) * kPlane) = t1 + t2;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 2) * kPlane) = t2 - t1;
-                *reinterpret_cast<f32x2 *>(dst + (4 * i + 3) * kPlane) = t1 - t3;
+                put_u(dst + (4 * i + 0) * kPlane, t0 - t2);
+                put_u(dst + (4 * i + 1) * kPlane, t1 + t2);
+                put_u(dst + (4 * i + 2) * kPlane, t2 - t1);
+                put_u(dst + (4 * i + 3) * kPlane, t1 - t3);
             }
             trace(3);  // U written (issue)
             __syncthreads();
@@ -189,6 +203,18 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const char *plane = ubuf + (wave * 4 + i) * kPlane;
+                if constexpr (F16) {
+                    // lane (tile, k half) holds channels 8 fhi .. 8 fhi + 7 of its tile: one 16-byte read per piece
+                    const f16x8 a0 = *reinterpret_cast<const f16x8 *>(plane + frow * 32 + fhi * 16);
+                    const f16x8 a1 = *reinterpret_cast<const f16x8 *>(plane + PT * 32 + frow * 32 + fhi * 16);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const f16x8 v0 = __builtin_bit_cast(f16x8, bf[i][cb][0]), v1 = __builtin_bit_cast(f16x8, bf[i][cb][1]);
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, v0, acc[i][cb], 0, 0, 0);
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, v1, acc[i][cb], 0, 0, 0);
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, v0, acc[i][cb], 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const f32x4 a = *reinterpret_cast<const f32x4 *>(plane + a_rd + (((2 * g + fhi) ^ a_sw) << 4));
@@ -197,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[i][0][g][j], acc[i][0], 0, 0, 0);
                         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bf[i][1][g][j], acc[i][1], 0, 0, 0);
                     }
+                }
                 }
                 if constexpr (!LAST) load_v(bf[i], i, c + 1);  // same registers, a whole chunk ahead of their use
                 // The next patch (chunk c+1, or the next group's chunk 0) is requested from INSIDE the MFMA stream, two
