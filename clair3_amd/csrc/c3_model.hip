@@ -149,7 +149,7 @@ struct c3_model {
     float *l4_w3 = nullptr;                  // the same as three bf16 pieces (SPLIT path); env C3HIP_L4_SPLIT
     bool l4_split = true;
     float *proj2_w3 = nullptr;               // LSTM2 projection weights as bf16 pieces for the tiled SPLIT GEMM; env C3HIP_PROJ2_SPLIT
-    bool proj2_split = false;
+    bool proj2_split = true;
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
     float *w5f = nullptr, *whf = nullptr, *bh48 = nullptr;  // MFMA fragment packing of the same weights (c3_tail.h)
     bool tail_mfma = true;                                   // env C3HIP_TAIL_MFMA

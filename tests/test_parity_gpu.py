@@ -340,6 +340,32 @@ def test_split_bf16_convolutions_are_as_close_to_the_oracle_as_the_fp32_ones(mon
             assert errs[mode][k] <= 3 * errs["fp32"][k] + 1e-7, (mode, k, errs)
 
 
+def test_fp16x3_winograd_stays_at_fp32_level(monkeypatch, oracle_mod):
+    """the six stride-1 convolutions form their Winograd-domain products from two fp16 pieces per operand (c3_wino_p.h
+    F16).  Every layer output against the fp64 oracle, next to the same kernels on fp32 MFMAs: the split products may
+    cost a small factor in rounding noise (both are ~1e-6 of the layer's range, 100x inside the 1e-4 gate on the
+    probabilities), never more."""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=41, peaked=True)
+    x = syn.make_fa_windows(7, seed=42)
+    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+    errs = {}
+    for mask in ("0x1b6", "0"):
+        monkeypatch.setenv("C3HIP_WINOGRAD_F16MASK", mask)
+        m = make_model(syn.FULL_ALIGNMENT, 8, True, sd, keep=True)
+        y = m.predict_numpy(x)
+        e = {}
+        for l in range(9):
+            a = m.debug_fetch(f"act{l}", d[f"act{l}"].shape)
+            e[f"act{l}"] = float(np.abs(a - d[f"act{l}"]).max()) / max(1.0, float(np.abs(d[f"act{l}"]).max()))
+        e["y"] = util.assert_rows_match(y, y_o, what=f"winograd f16 mask {mask}")
+        errs[mask] = e
+    monkeypatch.delenv("C3HIP_WINOGRAD_F16MASK")
+    print({k: (round(errs["0x1b6"][k] * 1e6, 2), round(errs["0"][k] * 1e6, 2)) for k in errs["0"]}, "(x1e-6: fp16x3, fp32)")
+    for k, v in errs["0x1b6"].items():
+        assert v < 1e-5, (k, v)
+        assert v <= 5 * errs["0"][k] + 3e-7, (k, errs)
+
+
 def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracle_mod):
     """the A/B switches of README.md select older kernels for the same layers: each selection stays within the parity
     gate (they are what a regression is bisected with, so they must keep working)"""
@@ -352,7 +378,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     fa_sets = [{"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
                {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"},
                {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
-               {"C3HIP_SPLIT_KIND": "1"}]
+               {"C3HIP_SPLIT_KIND": "1"}, {"C3HIP_WINOGRAD_F16MASK": "0"}, {"C3HIP_WINOGRAD_F16MASK": "0x24"}]
     for env in fa_sets:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -360,7 +386,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
         for k in env:
             monkeypatch.delenv(k)
     for env in [{"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
-                {"C3HIP_PROJ2_SPLIT": "1"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"}]:
+                {"C3HIP_PROJ2_SPLIT": "0"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"}]:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         util.assert_rows_match(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p, what=f"pileup {env}")
