@@ -204,7 +204,12 @@ struct Lstm2Params {
     int64_t ld_gx;
 };
 
-template <int H>
+// F16: h_{t-1} W_hh^T on v_mfma_f32_16x16x32_f16 with both operands as two fp16 pieces (fp16x3, c3_gemm.h SPLIT mode 2):
+// W_hh fragment slot q holds piece q & 1 of k-step q >> 1 (32 k per step; same bytes, same addressing as the fp32
+// fragments), the cell phase stores h as two fp16 planes, and a block's 40 fp32 matrix instructions of 32 cycles become
+// 15 of 16.
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+template <int H, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p) {
     constexpr int NB = H / 32;        // gate-column blocks per wave (8 waves)
     constexpr int NQ = H / 16;        // k groups of 16
@@ -217,19 +222,25 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
     static_assert(NP * 32 == H, "cell phase: thread (row = tid >> 5) covers units (tid & 31) + 32 r");
     // ONE LDS object, carved up by hand
     constexpr int OFF_H = 0;                                 // float hbuf[2][16][LDH]
-    constexpr int OFF_G = OFF_H + 2 * 16 * LDH * 4;          // float gbuf[16][LDG]: gate pre-activations
+    constexpr int LDH16 = 2 * H + 16;                        // F16: bytes per row of an fp16 h plane (see hb16)
+    constexpr int H_BYTES = F16 ? 2 * 2 * 16 * LDH16 : 2 * 16 * LDH * 4;
+    constexpr int OFF_G = OFF_H + H_BYTES;                   // float gbuf[16][LDG]: gate pre-activations
     constexpr int OFF_W = OFF_G + 16 * LDG * 4;              // float wlds[NQL][8][NB][64][4]
     constexpr int LDS_BYTES = OFF_W + NQL * 8 * NB * 64 * 16;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     auto hb = [&](int buf, int row, int k) -> float * { return reinterpret_cast<float *>(smem + OFF_H) + (buf * 16 + row) * LDH + k; };
     auto gb = [&](int row, int n) -> float * { return reinterpret_cast<float *>(smem + OFF_G) + row * LDG + n; };
+    // F16: hbuf[2 buffers][2 pieces][16 rows][LDH16 bytes] inside the same region; rows 2 H + 16 bytes apart, so the 16
+    // rows a ds_read_b128 touches fall on 16 different 16-byte slots of the 256-byte bank row
+    static_assert(!F16 || H % 32 == 0, "F16 needs whole 32-wide k-steps");
+    auto hb16 = [&](int buf, int piece, int row, int k) -> char * { return smem + OFF_H + ((buf * 2 + piece) * 16 + row) * LDH16 + 2 * k; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane >> 4, col = lane & 15;
     const int dir = blockIdx.y;
     const int b0 = blockIdx.x * 16;
 
-    for (int i = tid; i < 16 * LDH; i += 512) reinterpret_cast<float *>(smem + OFF_H)[i] = 0.f;
+    for (int i = tid; i < (F16 ? H_BYTES / 4 : 16 * LDH); i += 512) reinterpret_cast<float *>(smem + OFF_H)[i] = 0.f;
 
     // W_hh fragments of this wave's NB blocks: k-groups 0..NQR-1 resident in VGPRs, the last NQL in LDS
     f32x4v wres[NB][NQR];
@@ -288,6 +299,16 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
     load_x(dir ? p.T - 1 : 0);
     __syncthreads();
 
+    auto put_h = [&](int buf, int row, int k, float h) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            const _Float16 h0 = (_Float16)h;
+            const _Float16 h1 = (_Float16)(h - (float)h0);
+            *reinterpret_cast<_Float16 *>(hb16(buf, 0, row, k)) = h0;
+            *reinterpret_cast<_Float16 *>(hb16(buf, 1, row, k)) = h1;
+        } else {
+            *hb(buf, row, k) = h;
+        }
+    };
     for (int step = 0; step < p.T; ++step) {
         const int t = dir ? p.T - 1 - step : step;
         const int cur = step & 1;
@@ -295,6 +316,37 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[b] = xn[b];
             if (p.T > 1) load_x(dir ? t - 1 : t + 1);
+        } else if constexpr (F16) {
+            // k-step ks covers h units 32 ks .. 32 ks + 31; lane (window = col, group s) holds units 32 ks + 8 s .. + 7 of
+            // both pieces; products h1 w0 + h0 w1 + h0 w0 per gate block (fragment slot 2 ks + piece)
+            constexpr int NKS = H / 32;
+            f16x8v a0[2], a1[2];
+            a0[0] = *reinterpret_cast<const f16x8v *>(hb16(cur, 0, col, 8 * s));
+            a1[0] = *reinterpret_cast<const f16x8v *>(hb16(cur, 1, col, 8 * s));
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + 1 < NKS) {
+                    a0[(ks + 1) & 1] = *reinterpret_cast<const f16x8v *>(hb16(cur, 0, col, 32 * (ks + 1) + 8 * s));
+                    a1[(ks + 1) & 1] = *reinterpret_cast<const f16x8v *>(hb16(cur, 1, col, 32 * (ks + 1) + 8 * s));
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    f32x4v w0, w1;
+                    if (2 * ks < NQR) {
+                        w0 = wres[b][2 * ks < NQR ? 2 * ks : 0], w1 = wres[b][2 * ks + 1 < NQR ? 2 * ks + 1 : 0];
+                    } else {
+                        w0 = *reinterpret_cast<const f32x4v *>(wl + ((2 * ks - NQR) * 8 * NB + b) * 256);
+                        w1 = *reinterpret_cast<const f32x4v *>(wl + ((2 * ks + 1 - NQR) * 8 * NB + b) * 256);
+                    }
+                    const f16x8v v0 = __builtin_bit_cast(f16x8v, w0), v1 = __builtin_bit_cast(f16x8v, w1);
+                    f32x4v t = ks == 0 ? xn[b] : acc[b];
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks & 1], v0, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks & 1], v1, t, 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks & 1], v0, t, 0, 0, 0);
+                }
+                if (ks == 0 && step + 1 < p.T) load_x(dir ? t - 1 : t + 1);  // xn was consumed by the MFMAs just issued
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             f32x4v a[2];
             a[0] = *reinterpret_cast<const f32x4v *>(hb(cur, col, 4 * s));
@@ -338,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
             c[r] = cc[0], c[r + 1] = cc[1];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                *hb(cur ^ 1, crow, cu0 + 32 * (r + e)) = h[e];
+                put_h(cur ^ 1, crow, cu0 + 32 * (r + e), h[e]);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[e]), hrsrc, ho + 128 * (r + e), 0, 0);
             }
         }
@@ -351,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
             const float og = fast_sigmoid(g[3 * H]);
             c[r] = fg * c[r] + ig * gg;
             const float h = og * fast_tanh(c[r]);
-            *hb(cur ^ 1, crow, cu0 + 32 * r) = h;
+            put_h(cur ^ 1, crow, cu0 + 32 * r, h);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrsrc, ho + 128 * r, 0, 0);
         }
         lds_barrier();

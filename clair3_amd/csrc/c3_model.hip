@@ -118,6 +118,8 @@ struct c3_model {
     bool proj2_stream = true;               // env C3HIP_PROJ2_STREAM
     float *proj_b[2] = {nullptr, nullptr};  // [2*4H]
     float *whh[2] = {nullptr, nullptr};     // fragment-packed W_hh
+    float *whh16[2] = {nullptr, nullptr};   // W_hh as two fp16 pieces in the F16 kernels' fragment order (c3_kernels.h)
+    bool lstm2_f16 = true;                  // LSTM2 recurrence on fp16x3 split products; env C3HIP_LSTM2_F16
     float *l1_wih = nullptr, *l1_bias = nullptr;  // LSTM1 input projection as MFMA fragments (fused kernel)
     bool lstm1_fused = true;                // env C3HIP_LSTM1_FUSED=0 selects GEMM + recurrence
     // full alignment
@@ -442,6 +444,27 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                             const int k = 16 * q + 4 * (lane >> 4) + e;
                             wf[((((size_t)dir * (4 * H / 16) + blk) * NQ + q) * 64 + lane) * 4 + e] = whh[(size_t)r * H + k];
                         }
+        }
+        if (layer == 1 && m->lstm2_f16 && H % 32 == 0) {
+            // lstm_recurrent_kernel_v2<H, true>: slot q = 2 ks + piece of [dir][block][q][lane][8 fp16]:
+            // piece of W_hh[block*16 + (lane&15)][32 ks + 8 (lane>>4) + j]   (the fp32 fragments' bytes and addressing)
+            std::vector<float> wf16(wf.size());
+            uint16_t *q16 = reinterpret_cast<uint16_t *>(wf16.data());
+            for (int dir = 0; dir < 2; ++dir) {
+                const float *whh;
+                TRY(want(tm, base + ".weight_hh_l0" + (dir ? "_reverse" : ""), {4 * H, H}, &whh));
+                for (int blk = 0; blk < 4 * H / 16; ++blk)
+                    for (int ks = 0; ks < H / 32; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = whh[(size_t)(blk * 16 + (lane & 15)) * H + 32 * ks + 8 * (lane >> 4) + j];
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const size_t slot = (((size_t)dir * (4 * H / 16) + blk) * NQ + 2 * ks) * 64 * 8;
+                                memcpy(&q16[slot + (size_t)lane * 8 + j], &h0, 2);
+                                memcpy(&q16[slot + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                            }
+            }
+            TRY(upload(m, &m->whh16[layer], wf16));
         }
         if (layer == 1 && Kp == 256 && (2 * 4 * H) % 32 == 0) {
             // proj_stream_kernel: [cb][i][lane][e] = W[n = 32 cb + (lane&31)][k = 128 (lane>>5) + 4 i + e]
@@ -839,7 +862,12 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
         if (m->lstm2_v2) {
             Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
-            hipLaunchKernelGGL(lstm_recurrent_kernel_v2<160>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+            if (m->lstm2_f16 && m->whh16[1]) {
+                lp.whh = m->whh16[1];
+                hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+            } else {
+                hipLaunchKernelGGL(lstm_recurrent_kernel_v2<160>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+            }
         } else {
             LstmParams lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
             hipLaunchKernelGGL((lstm_recurrent_kernel<160, false>), dim3((unsigned)((n + 15) / 16), 2), dim3(640), 0, s, lp);
@@ -964,6 +992,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     }
     if (const char *e = getenv("C3HIP_WINOGRAD_N64MASK")) m->wino_n64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_LSTM2_F16")) m->lstm2_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
@@ -1229,7 +1258,7 @@ int c3_model_destroy(c3_model *m) {
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
     free_workspace(m);
-    float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1],
+    float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
                    m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias,
                    m->conv1_wfrag, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3};
     for (float *p : ws)
