@@ -30,10 +30,17 @@ struct LstmFusedParams {
 
 constexpr int kFusedKS = 5;  // k-steps of 4 covering C <= 20 input channels
 
-template <typename TX>
+// F16: the recurrent product h_{t-1} W_hh^T on v_mfma_f32_16x16x32_f16, both operands as two fp16 pieces (fp16x3, see
+// lstm_recurrent_kernel_v2): fragment slot q of a gate holds piece q & 1 of k-step q >> 1, h lives in two fp16 planes.
+// The 18-channel input projection stays on its 20 fp32 matrix instructions.
+template <typename TX, bool F16 = false>
 __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p) {
     constexpr int H = 128, NW = 8, NQ = 8, LDH = H + 4;
+    constexpr int LDH16 = 2 * H + 16;  // bytes per row of an fp16 h plane: 16 rows fall on 16 different 16-byte bank slots
     __shared__ __attribute__((aligned(16))) float hbuf[2][16][LDH];
+    static_assert(2 * 2 * 16 * LDH16 <= (int)sizeof(float) * 2 * 16 * (H + 4) + 2048 || !F16, "");
+    __shared__ __attribute__((aligned(16))) char hbuf16[F16 ? 2 * 2 * 16 * LDH16 : 16];
+    auto hb16 = [&](int buf, int piece, int row, int k) -> char * { return hbuf16 + ((buf * 2 + piece) * 16 + row) * LDH16 + 2 * k; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane >> 4, col = lane & 15;
@@ -41,6 +48,8 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
     const int b0 = blockIdx.x * 16;
 
     for (int i = tid; i < 16 * LDH; i += NW * 64) (&hbuf[0][0][0])[i] = 0.f;
+    if constexpr (F16)
+        for (int i = tid; i < 2 * 2 * 16 * LDH16 / 4; i += NW * 64) reinterpret_cast<uint32_t *>(hbuf16)[i] = 0u;
 
     // resident weights: W_hh fragments (128 VGPRs), W_ih fragments (20), bias (4)
     const float *wbase = p.whh + ((int64_t)(dir * NW + wave) * 4 * NQ * 64 + lane) * 4;
@@ -116,7 +125,22 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         // next step's counts: requested from inside the MFMA stream (a load costs ~60 cycles of issue outside it)
         if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1, xn);
         __builtin_amdgcn_sched_barrier(0);
-        if (step > 0) {  // gates += h_{t-1} W_hh^T, h_{-1} = 0
+        if constexpr (F16) {
+            if (step > 0) {
+#pragma unroll
+                for (int ks = 0; ks < H / 32; ++ks) {
+                    const f16x8v a0 = *reinterpret_cast<const f16x8v *>(hb16(cur, 0, col, 32 * ks + 8 * s));
+                    const f16x8v a1 = *reinterpret_cast<const f16x8v *>(hb16(cur, 1, col, 32 * ks + 8 * s));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f16x8v v0 = __builtin_bit_cast(f16x8v, wres[g * NQ + 2 * ks]), v1 = __builtin_bit_cast(f16x8v, wres[g * NQ + 2 * ks + 1]);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, v0, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, v1, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, v0, acc[g], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (step > 0) {  // gates += h_{t-1} W_hh^T, h_{-1} = 0
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
@@ -135,7 +159,13 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
             c[v] = cc[0], c[v + 1] = cc[1];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                hbuf[cur ^ 1][4 * s + v + e][wave * 16 + col] = h[e];
+                if constexpr (F16) {
+                    const _Float16 h0 = (_Float16)h[e];
+                    *reinterpret_cast<_Float16 *>(hb16(cur ^ 1, 0, 4 * s + v + e, wave * 16 + col)) = h0;
+                    *reinterpret_cast<_Float16 *>(hb16(cur ^ 1, 1, 4 * s + v + e, wave * 16 + col)) = (_Float16)(h[e] - (float)h0);
+                } else {
+                    hbuf[cur ^ 1][4 * s + v + e][wave * 16 + col] = h[e];
+                }
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[e]), hrsrc, ho[v + e] + (uint32_t)(t * 2 * H * 4), 0, 0);
             }
         }

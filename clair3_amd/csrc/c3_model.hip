@@ -120,6 +120,7 @@ struct c3_model {
     float *whh[2] = {nullptr, nullptr};     // fragment-packed W_hh
     float *whh16[2] = {nullptr, nullptr};   // W_hh as two fp16 pieces in the F16 kernels' fragment order (c3_kernels.h)
     bool lstm2_f16 = true;                  // LSTM2 recurrence on fp16x3 split products; env C3HIP_LSTM2_F16
+    bool lstm1_f16 = true;                  // LSTM1 recurrence likewise; env C3HIP_LSTM1_F16
     float *l1_wih = nullptr, *l1_bias = nullptr;  // LSTM1 input projection as MFMA fragments (fused kernel)
     bool lstm1_fused = true;                // env C3HIP_LSTM1_FUSED=0 selects GEMM + recurrence
     // full alignment
@@ -513,6 +514,28 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
     TRY(upload(m, &m->proj_w[layer], pw));
     TRY(upload(m, &m->proj_b[layer], pb));
     TRY(upload(m, &m->whh[layer], wf));
+    if (layer == 0 && m->lstm1_f16 && H % 32 == 0) {
+        // lstm1_fused_kernel<TX, true>: slot q = 2 ks + piece of [dir][wave][gate][q][lane][8 fp16]:
+        // piece of W_hh[gate*H + wave*16 + (lane&15)][32 ks + 8 (lane>>4) + j]
+        std::vector<float> wf16(wf.size());
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(wf16.data());
+        for (int dir = 0; dir < 2; ++dir) {
+            const float *whh;
+            TRY(want(tm, base + ".weight_hh_l0" + (dir ? "_reverse" : ""), {4 * H, H}, &whh));
+            for (int w = 0; w < NW; ++w)
+                for (int g = 0; g < 4; ++g)
+                    for (int ks = 0; ks < H / 32; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = whh[(size_t)(g * H + w * 16 + (lane & 15)) * H + 32 * ks + 8 * (lane >> 4) + j];
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const size_t slot = ((((size_t)dir * NW + w) * 4 + g) * NQ + 2 * ks) * 64 * 8;
+                                memcpy(&q16[slot + (size_t)lane * 8 + j], &h0, 2);
+                                memcpy(&q16[slot + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                            }
+        }
+        TRY(upload(m, &m->whh16[layer], wf16));
+    }
     if (layer == 0 && in <= 4 * kFusedKS) {
         // fused kernel: W_ih as 16x16x4 B fragments [dir][wave][gate][ks][lane] = W_ih[g*H + w*16 + (lane&15)][4ks + (lane>>4)]
         std::vector<float> fw((size_t)2 * NW * 4 * kFusedKS * 64, 0.f), fb((size_t)2 * NW * 4 * 16);
@@ -811,7 +834,12 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     if (fused1) {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
         LstmFusedParams<T> lp{x, starts, m->l1_wih, m->l1_bias, m->whh[0], m->h1, (int)n, Tn, m->C};
-        hipLaunchKernelGGL(lstm1_fused_kernel<T>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+        if (m->lstm1_f16 && m->whh16[0]) {
+            lp.whh = m->whh16[0];
+            hipLaunchKernelGGL((lstm1_fused_kernel<T, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+        } else {
+            hipLaunchKernelGGL(lstm1_fused_kernel<T>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (!fused1) {
@@ -993,6 +1021,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_WINOGRAD_N64MASK")) m->wino_n64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM2_F16")) m->lstm2_f16 = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_LSTM1_F16")) m->lstm1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
