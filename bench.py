@@ -160,11 +160,11 @@ def run_workload(name, args, rank, world, local):
                       for r in stats}
     if kind == syn.FULL_ALIGNMENT:
         dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res"))]
-        dom_name = ("3x3 convolution family: conv1_i8_kernel + gemm_mfma_kernel<ConvLoader> (stride-2 implicit GEMM, bf16x6 split products) + "
-                    "wino_conv_kernel_p (persistent Winograd F(2x2,3x3) on the six stride-1 convs), 9 launches per step, fp32 MFMA")
+        dom_name = ("3x3 convolution family: conv1_i8_kernel + gemm_mfma_kernel<ConvLoader> (stride-2 implicit GEMM) + "
+                    "wino_conv_kernel_p (persistent Winograd F(2x2,3x3) on the six stride-1 convs), 9 launches per step; fp16x3 split products except conv1")
     else:
         dom = [r for r in stats if r["name"].startswith("p.lstm")]
-        dom_name = "lstm1_fused_kernel + lstm_recurrent_kernel_v2<160> (the two BiLSTM recurrences, 2 launches per step, fp32 MFMA 16x16x4)"
+        dom_name = "lstm1_fused_kernel + lstm_recurrent_kernel_v2<160> (the two BiLSTM recurrences, 2 launches per step, fp16x3 split products on v_mfma_f32_16x16x32_f16)"
     ms = sum(r["total_ms"] for r in dom)
     fl = sum(r["flops"] for r in dom)
     launches = sum(r["launches"] for r in dom)
@@ -189,11 +189,14 @@ def run_workload(name, args, rank, world, local):
     }
     if kind == syn.FULL_ALIGNMENT:
         res["roofline"]["note"] = ("achieved = ALGORITHMIC FLOP (direct 3x3 convolution, SURVEY 8d) / measured kernel time; peak = the "
-                                   "fp32-MFMA roof.  frac can exceed 1: the six stride-1 layers run as Winograd F(2x2,3x3) (2.25x "
-                                   "fewer multiplications), and conv3 / conv5 form their fp32 products from three bf16 pieces per "
-                                   "operand on v_mfma_f32_32x32x16_bf16 (six piece products, exact to 2^-24, fp32 accumulation: "
-                                   "DESIGN.md 3.1 SPLIT; C3HIP_CONV_SPLITMASK=0 C3HIP_L4_SPLIT=0 runs everything on fp32 MFMAs). "
+                                   "fp32-MFMA roof BASELINE.md prices this path against.  frac exceeds 1 because (a) the six stride-1 "
+                                   "layers run as Winograd F(2x2,3x3) (2.25x fewer multiplications) and (b) every contraction except "
+                                   "conv1 forms its fp32 products from two fp16 pieces per operand on v_mfma_f32_32x32x16_f16 (fp16x3: "
+                                   "h0w0 + h0w1 + h1w0, fp32 accumulation, fp32-level parity -- DESIGN.md 1; the 16-bit matrix roof is "
+                                   "2500 TFLOP/s, i.e. 833 per fp32-equivalent product).  C3HIP_* switches restore fp32 MFMAs per layer. "
                                    "Matrix-pipe busy time per kernel: profiles/*_pmc_sq.md (SQ_VALU_MFMA_BUSY_CYCLES)")
+    res["roofline"]["fp16x3_roof_tflops"] = 2500.0 / 3.0
+    res["roofline"]["frac_of_fp16x3_roof"] = achieved / (2500.0 / 3.0)
     return res
 
 
@@ -291,7 +294,7 @@ def main():
             "metric": "candidate-windows/sec", "value": head["value"], "unit": "candidate-windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 storage, accumulation and results; conv3/conv5/L4 products via bf16x6 split MFMA (DESIGN.md 3.1)",
+            "dtype_note": "fp32 storage, accumulation and results; products formed from two fp16 pieces per operand (fp16x3 split MFMA, DESIGN.md 1)",
             "config": {"workload": head["workload"], "batch_per_gpu": head["batch_per_gpu"],
                        "windows_per_step": head["windows_per_step"], "weights": "seeded random (no checkpoints offline)",
                        "sharding": f"windows x{world}, gather of probability rows to rank 0" if world > 1 else "single GPU",
