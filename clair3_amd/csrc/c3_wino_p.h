@@ -22,6 +22,18 @@ namespace c3 {
 // ABL (tools/wino_probe only; 0 in the product): bit0 no patch loads, bit1 no transform+LDS writes, bit2 no V loads,
 // bit3 no epilogue exchange/stores, bit4 no MFMAs.
 // OPT bit1 (tools/wino_probe.hip only): workgroup 0 records the shader clock at its phase boundaries.
+// a - b on both halves in one v_pk_add_f32 (hipcc emits two v_sub_f32 for the vector expression)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_sub(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // F16: the Winograd-domain products on v_mfma_f32_32x32x16_f16 with both operands split into two fp16 pieces
 // (fp16x3, c3_gemm.h SPLIT mode 2): the transform threads write U as two fp16 planes per xi (same 32 KiB), V arrives as
 // two fp16 fragments per (xi, chunk, column block) instead of two k-halves of fp32 (same bytes, same addressing), and a
@@ -75,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
     auto put_u = [&](char *dst, f32x2 v) __attribute__((always_inline)) {
         if constexpr (F16) {
             const f16x2 h0 = __builtin_convertvector(v, f16x2);
-            const f32x2 r = v - __builtin_convertvector(h0, f32x2);
+            const f32x2 hf = __builtin_convertvector(h0, f32x2);
+            const f32x2 r = pk_sub(v, hf);
             *reinterpret_cast<uint32_t *>(dst) = __builtin_bit_cast(uint32_t, h0);
             *reinterpret_cast<uint32_t *>(dst + PT * 32) = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
         } else {
@@ -158,15 +171,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[i][cb][v] = 0.f;
+                for (int v = 0; v < 16; ++v)
+                    if (!F16) acc[i][cb][v] = 0.f;
 
         // one K chunk; LAST: the prefetches target the next group (patch here, V fragments from inside the epilogue)
-        auto chunk = [&](int c, auto last_tag) __attribute__((always_inline)) {
+        auto chunk = [&](int c, auto last_tag, auto first_tag) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(last_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;  // F16: the group's first products take C = 0 (no 128 v_mov)
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {  // t = B^T d
                 const f32x2 d0 = d[0][dx], d1 = d[1][dx], d2 = d[2][dx], d3 = d[3][dx];
-                d[0][dx] = d0 - d2, d[1][dx] = d1 + d2, d[2][dx] = d2 - d1, d[3][dx] = d1 - d3;
+                d[0][dx] = pk_sub(d0, d2), d[1][dx] = d1 + d2, d[2][dx] = pk_sub(d2, d1), d[3][dx] = pk_sub(d1, d3);
             }
             trace(1);  // patch arrived, column transform done
             __syncthreads();  // every wave finished reading the previous chunk's U (or the previous group's exchange)
@@ -176,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
             for (int i = 0; i < (ABL & 2 ? 0 : 4); ++i) {  // U = t B, xi = 4i + j
                 const f32x2 t0 = d[i][0], t1 = d[i][1], t2 = d[i][2], t3 = d[i][3];
                 char *dst = ubuf + u_wr;
-                put_u(dst + (4 * i + 0) * kPlane, t0 - t2);
+                put_u(dst + (4 * i + 0) * kPlane, pk_sub(t0, t2));
                 put_u(dst + (4 * i + 1) * kPlane, t1 + t2);
-                put_u(dst + (4 * i + 2) * kPlane, t2 - t1);
-                put_u(dst + (4 * i + 3) * kPlane, t1 - t3);
+                put_u(dst + (4 * i + 2) * kPlane, pk_sub(t2, t1));
+                put_u(dst + (4 * i + 3) * kPlane, pk_sub(t1, t3));
             }
             trace(3);  // U written (issue)
             __syncthreads();
@@ -210,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
                         const f16x8 v0 = __builtin_bit_cast(f16x8, bf[i][cb][0]), v1 = __builtin_bit_cast(f16x8, bf[i][cb][1]);
-                        acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, v0, acc[i][cb], 0, 0, 0);
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, v0, FIRST ? zero : acc[i][cb], 0, 0, 0);
                         acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, v1, acc[i][cb], 0, 0, 0);
                         acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, v0, acc[i][cb], 0, 0, 0);
                     }
@@ -234,8 +250,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::false_type{});
-        chunk(nchunks - 1, std::true_type{});
+        if constexpr (F16) {  // nchunks >= 2 (Cin >= 64 on every Winograd layer; checked on the host)
+            chunk(0, std::false_type{}, std::true_type{});
+            for (int c = 1; c + 1 < nchunks; ++c) chunk(c, std::false_type{}, std::false_type{});
+        } else {
+            for (int c = 0; c + 1 < nchunks; ++c) chunk(c, std::false_type{}, std::false_type{});
+        }
+        chunk(nchunks - 1, std::true_type{}, std::false_type{});
         trace(6);  // all MFMAs of the group issued
 
         // ---- epilogue: one pass per column block (32 couts): exchange M_xi through LDS, A^T M A, bias (+res), ReLU, store
@@ -294,11 +315,11 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                 f32x4 m[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m[i] = *reinterpret_cast<const f32x4 *>(&mbuf[((4 * i + j) * PT + t) * 32 + 4 * cq]);
-                const f32x4 s0 = m[0] + m[1] + m[2], s1 = m[1] - m[2] - m[3];
+                const f32x4 s0 = m[0] + m[1] + m[2], s1 = pk_sub4(pk_sub4(m[1], m[2]), m[3]);
                 if (j == 0) y[0][0] = s0, y[1][0] = s1;
                 if (j == 1) y[0][0] += s0, y[1][0] += s1, y[0][1] = s0, y[1][1] = s1;
-                if (j == 2) y[0][0] += s0, y[1][0] += s1, y[0][1] -= s0, y[1][1] -= s1;
-                if (j == 3) y[0][1] -= s0, y[1][1] -= s1;
+                if (j == 2) y[0][0] += s0, y[1][0] += s1, y[0][1] = pk_sub4(y[0][1], s0), y[1][1] = pk_sub4(y[1][1], s1);
+                if (j == 3) y[0][1] = pk_sub4(y[0][1], s0), y[1][1] = pk_sub4(y[1][1], s1);
             }
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
