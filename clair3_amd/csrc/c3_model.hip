@@ -142,6 +142,8 @@ struct c3_model {
     size_t decode_bytes = 0;
     bool conv1_direct = true;       // 8-channel conv1 through conv1_i8_kernel (c3_conv1.h); env C3HIP_CONV1_DIRECT
     float *conv1_wfrag = nullptr;   // its resident B fragments [36][2][64]
+    float *conv1_wfrag16 = nullptr; // conv1_i8_f16_kernel: [5][2][2 pieces][64][8 fp16]
+    bool conv1_f16 = true;          // conv1 on fp16 matrix instructions (int8 inputs exact, weights as two pieces); env C3HIP_CONV1_F16
     unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
     int wg_slots = 512;             // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
     unsigned wino_n64_mask = 0x1b6; // layers using the 32-tile x 64-cout workgroup shape; env C3HIP_WINOGRAD_N64MASK
@@ -606,6 +608,26 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                     pf[((size_t)s * 2 + cb) * 64 + lane] = (float)((double)w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] * scale / 100.0);
                 }
         TRY(upload(m, &m->conv1_wfrag, pf));
+        if (m->conv1_f16) {
+            // conv1_i8_f16_kernel: lane (n = lane & 31, kh = lane >> 5) of k-step t holds channel j of tap 2 t + kh
+            std::vector<float> pf16((size_t)5 * 2 * 2 * 64 * 4, 0.f);
+            uint16_t *q16 = reinterpret_cast<uint16_t *>(pf16.data());
+            for (int t = 0; t < 5; ++t)
+                for (int cb = 0; cb < 2; ++cb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 32 * cb + (lane & 31), tap = 2 * t + (lane >> 5);
+                            float v = 0.f;
+                            if (tap < 9) {
+                                const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+                                v = (float)((double)w[(((size_t)co * Cin + j) * 3 + tap / 3) * 3 + tap % 3] * scale * (128.0 / 100.0));  // the kernel feeds x / 128
+                            }
+                            const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                            memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 0) * 64 + lane) * 8 + j], &h0, 2);
+                            memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 1) * 64 + lane) * 8 + j], &h1, 2);
+                        }
+            TRY(upload(m, &m->conv1_wfrag16, pf16));
+        }
     }
     if (kConvStride[l] == 1 && Cin % kWinoBK == 0 && Cout % kWinoNT == 0) {
         // Winograd F(2x2,3x3) weights V = G g' G^T (g' = BN-folded), in MFMA B-fragment order
@@ -750,6 +772,13 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
                 else
                     hipLaunchKernelGGL(wino_conv_kernel<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
             }
+            HIP_TRY(hipGetLastError());
+        } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_f16 && m->conv1_wfrag16) {
+            Conv1F16Params cp;
+            cp.x = x, cp.wfrag = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.bias = m->conv_b[0], cp.out = m->act[0];
+            cp.B = (int)n, cp.H = hh[0], cp.W = ww[0], cp.OH = hh[1], cp.OW = ww[1], cp.M = M, cp.groups = (M + 31) / 32;
+            const int grid = std::min((cp.groups + 3) / 4, m->wg_slots);
+            hipLaunchKernelGGL(conv1_i8_f16_kernel, dim3(grid), dim3(256), 0, s, cp);
             HIP_TRY(hipGetLastError());
         } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_wfrag) {
             Conv1Params cp;
@@ -1022,6 +1051,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_LSTM2_V2")) m->lstm2_v2 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM2_F16")) m->lstm2_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_F16")) m->lstm1_f16 = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_CONV1_F16")) m->conv1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
@@ -1289,7 +1319,7 @@ int c3_model_destroy(c3_model *m) {
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
                    m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias,
-                   m->conv1_wfrag, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3};
+                   m->conv1_wfrag, m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     if (m->decode_dev) (void)hipFree(m->decode_dev);
