@@ -292,6 +292,8 @@ struct EpilogueParams {
     const float *res;    // residual, same layout as c (EPI_BIAS_RES_RELU)
     int64_t ldc;
     int64_t split_stride;  // M*ldc for EPI_PARTIAL
+    float post_scale = 1.f;  // SPLIT: the weights are packed times a power of two (so that their low fp16 piece stays a
+                             // normal number) and the sum is scaled back here, exactly, inside the bias FMA
 };
 
 struct GemmParams {
@@ -574,7 +576,11 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
             for (int q = 0; q < 4; ++q) {  // columns nb + 8q .. nb + 8q + 3
                 f32x4 val = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
-                if (EPI != EPI_PARTIAL) val += *reinterpret_cast<const f32x4 *>(ep.bias + nb + 8 * q);
+                if (EPI != EPI_PARTIAL) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(ep.bias + nb + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], ep.post_scale, bv[e]);  // post_scale = 1: the plain add
+                }
                 if (EPI == EPI_BIAS_RES_RELU) val += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off + 32 * q, 0, 0));
                 if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) {
 #pragma unroll

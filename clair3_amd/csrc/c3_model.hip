@@ -131,6 +131,7 @@ struct c3_model {
     unsigned wino_f16_mask = 0x1b6;  // Winograd layers on the fp16x3 split products; env C3HIP_WINOGRAD_F16MASK
     float *conv_w3[9] = {};  // direct-conv weights as three bf16 pieces [3][Cout][K] (uint16 payload), layers in conv_split_mask
     unsigned conv_split_mask = 0x48;  // stride-2 convs conv3 / conv5 on the split-precision path (c3_gemm.h SPLIT); env C3HIP_CONV_SPLITMASK
+    float split_wscale = 256.f;       // fp16x3: weights are packed times this power of two so that their low piece is a normal fp16 number
     int split_kind = 2;               // 2 = fp16x3 (two fp16 pieces, three products), 1 = bf16x6 (three bf16 pieces, six products); env C3HIP_SPLIT_KIND
     bool use_wino[9] = {};
     // Measured on MI355X (B=256), direct implicit GEMM -> Winograd v1: res1 134/144 -> 105/112 us, res2 163/172 ->
@@ -280,6 +281,7 @@ static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float
                 q[lvl * n + i] = h;
                 r -= bf16_f32(h);
             } else {
+                if (lvl == 0) r *= m->split_wscale;  // exact; undone by post_scale in the kernels' epilogues
                 const _Float16 h = (_Float16)r;  // round to nearest even, subnormals kept
                 memcpy(&q[lvl * n + i], &h, 2);
                 r -= (float)h;
@@ -668,7 +670,8 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                                         const float v = pv[((((size_t)(nt * 16 + xi) * nch + c) * 2 + gq) * 64 + hi * 32 + ln) * 4 + e];
                                         const int kk = 8 * gq + 4 * hi + e;  // channel within the chunk (fp32 fragment order)
                                         const int hi16 = kk / 8, j = kk % 8;
-                                        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                        const float vs = v * m->split_wscale;  // exact; wp.post_scale undoes it
+                                        const _Float16 h0 = (_Float16)vs, h1 = (_Float16)(vs - (float)h0);
                                         const size_t base = (((size_t)(nt * 16 + xi) * nch + c) * 2) * 64 * 8;
                                         memcpy(&q16[base + (size_t)(0 * 64 + hi16 * 32 + ln) * 8 + j], &h0, 2);
                                         memcpy(&q16[base + (size_t)(1 * 64 + hi16 * 32 + ln) * 8 + j], &h1, 2);
@@ -690,8 +693,8 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         ProfScope ps(m, s, tag_l4, 2.0 * n * FC * K4, 4.0 * (n * K4 + (double)FC * K4 + (double)S * n * FC));
         DenseLoaderParams lp{a, lda};
         EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
-        if (m->l4_split && m->l4_w3)
-            TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_PARTIAL, 128, 64, s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3));
+        if (m->l4_split && m->l4_w3 && m->tail_mfma && m->w5f)  // (the scalar tail sums the partials itself and knows no scale)
+            TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_PARTIAL, 128, 64, s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3));  // partials carry split_wscale
         else
             TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
     }
@@ -699,6 +702,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
     if (m->tail_mfma && m->w5f) {
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
         ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
+        if (m->l4_split && m->l4_w3 && m->split_kind == 2) rp.pre = m->split_wscale, rp.post = 1.f / m->split_wscale;  // same condition as the launch above (tail_mfma holds here)
         hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
         HIP_TRY(hipGetLastError());
         Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->row};
@@ -751,7 +755,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
                 wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
                 const int grid = std::min(wp.tiles, m->wg_slots / wp.tiles_n * wp.tiles_n);
                 if (m->wino_v16[l] && (m->wino_f16_mask & (1u << l))) {
-                    wp.v = m->wino_v16[l];
+                    wp.v = m->wino_v16[l], wp.post_scale = 1.f / m->split_wscale;
                     if (wp.res)
                         hipLaunchKernelGGL((wino_conv_kernel_p<true, 0, 0, true>), dim3(grid), dim3(256), 0, s, wp);
                     else
@@ -796,6 +800,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
             if (!res && m->conv_w3[l] && (m->conv_split_mask & (1u << l))) {
+                ep.post_scale = (m->split_kind == 2 ? 1.f / m->split_wscale : 1.f);
                 // fp16x3 keeps the fp32 kernel's LDS footprint, so conv3 (N = 128) can use 128x128 tiles at two workgroups
                 // per CU (43 -> 38 us); conv5 stays on 128x64 (480 workgroups), bf16x6 needs 72 KB per 128x64 tile
                 if (m->split_kind == 2 && !(m->conv_bn64_mask & (1u << l)))
@@ -888,6 +893,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         if (m->proj2_split && m->proj2_w3 && m->lstm2_v2) {
             DenseLoaderParams lp{m->h1, 256};
             EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
+            ep.post_scale = (m->split_kind == 2 ? 1.f / m->split_wscale : 1.f);
             // 128x64 tiles (72 KB of LDS, two workgroups per CU); 128x128 (96 KB, one per CU) measured 193 us
             TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_BIAS, 128, 64, s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep, m->proj2_w3));
         } else if (m->proj2_stream && m->proj2_frag && m->lstm2_v2) {

@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    f32x4 o = y[i][j] + bias;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(y[i][j][e], p.post_scale, bias[e]);  // post_scale = 1: the plain add
                     if constexpr (RES) o += r[i][j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
