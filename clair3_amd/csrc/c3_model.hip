@@ -970,7 +970,7 @@ static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
-const char *c3_version(void) { return "c3hip 0.1.0 (gfx950, fp32 MFMA)"; }
+const char *c3_version(void) { return "c3hip 0.2.0 (gfx950, fp32 data, fp16x3 split matrix products)"; }
 const char *c3_last_error(void) { return g_err.c_str(); }
 
 int c3_device_count(void) {
