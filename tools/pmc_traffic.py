@@ -21,7 +21,7 @@ def agg(path):
 def main(tag):
     f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch/c3_counter_collection.csv"))
     w = agg(os.path.join(ROOT, "gpurun_out/pmc_write/c3_counter_collection.csv"))
-    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("wino_conv_kernel" in k) or ("conv1_i8_kernel" in k)
+    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("wino_conv_kernel" in k) or ("conv1_i8" in k)
     tot_f = tot_w = n = 0
     per = {}
     for k in f:
