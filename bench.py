@@ -77,7 +77,7 @@ def run_workload(name, args, rank, world, local):
     # workers per device, clair3/CallVariantsFromCffiGPU.py:55-56).  Kernels that cannot fill 256 CUs on their own
     # (the 33-step LSTM recurrences on 128 workgroups, the 12x5 stage, the FC tail) then overlap the next batch's
     # large kernels.  Every step is still one complete forward pass over one full batch.
-    S = args.streams if args.streams > 0 else (2 if kind == syn.PILEUP else 3)  # measured optimum per workload
+    S = args.streams if args.streams > 0 else 3  # measured optimum for both workloads (2 / 3 / 4: FA 664 / 681 / 660 k, pileup 4.17 / 4.24 / 4.21 M)
     models = [model] + [build_model(kind, channels, indel, local)[0] for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in models]
     # part of model set-up, like the weight upload: every handle sizes its device workspace on its first batch
@@ -268,7 +268,7 @@ def main():
     ap.add_argument("--workload", default="all", choices=["all"] + list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/experiments only)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="batches kept in flight per GPU (model handles x HIP streams); 0 = 3 for full alignment, 2 for pileup")
+                    help="batches kept in flight per GPU (model handles x HIP streams); 0 = 3")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", nargs=4, metavar=("WORKLOAD", "THREADS", "BUDGET", "BATCH"), help=argparse.SUPPRESS)
