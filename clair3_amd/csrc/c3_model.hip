@@ -131,7 +131,9 @@ struct c3_model {
     unsigned wino_f16_mask = 0x1b6;  // Winograd layers on the fp16x3 split products; env C3HIP_WINOGRAD_F16MASK
     float *conv_w3[9] = {};  // direct-conv weights as three bf16 pieces [3][Cout][K] (uint16 payload), layers in conv_split_mask
     unsigned conv_split_mask = 0x48;  // stride-2 convs conv3 / conv5 on the split-precision path (c3_gemm.h SPLIT); env C3HIP_CONV_SPLITMASK
-    float split_wscale = 256.f;       // fp16x3: weights are packed times this power of two so that their low piece is a normal fp16 number
+    // fp16x3: a weight tensor is packed times a power of two chosen per tensor (pick_wscale: as close to 256 as keeps
+    // max |w| * scale below 16384, so the low piece is a normal fp16 number and the high piece cannot overflow)
+    float conv_wscale[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, wino_wscale[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, l4_wscale = 1.f, proj2_wscale = 1.f;
     int split_kind = 2;               // 2 = fp16x3 (two fp16 pieces, three products), 1 = bf16x6 (three bf16 pieces, six products); env C3HIP_SPLIT_KIND
     bool use_wino[9] = {};
     // Measured on MI355X (B=256), direct implicit GEMM -> Winograd v1: res1 134/144 -> 105/112 us, res2 163/172 ->
@@ -256,7 +258,17 @@ static int upload(c3_model *m, float **dst, const std::vector<float> &src) {
 // A weight matrix as 16-bit pieces for the SPLIT paths of gemm_mfma_kernel, layout [pieces][n] (uint16 payload carried
 // in a float allocation), every piece rounded to nearest even, the remainders exact in fp32:
 //   kind 1: w = p0 + p1 + p2, bf16;   kind 2: w = h0 + h1, fp16 (subnormals kept).
-static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float> &w) {
+static float pick_wscale(const float *w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    float s = 256.f;
+    while (s > 1.f / 65536.f && mx * s >= 16384.f) s *= 0.5f;
+    return s;
+}
+
+static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float> &w, float *scale_out) {
+    const float wscale = m->split_kind == 2 ? pick_wscale(w.data(), w.size()) : 1.f;
+    *scale_out = wscale;
     auto bf16_rne = [](float f) -> uint16_t {
         uint32_t u;
         memcpy(&u, &f, 4);
@@ -281,7 +293,7 @@ static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float
                 q[lvl * n + i] = h;
                 r -= bf16_f32(h);
             } else {
-                if (lvl == 0) r *= m->split_wscale;  // exact; undone by post_scale in the kernels' epilogues
+                if (lvl == 0) r *= wscale;  // exact; undone by post_scale in the kernels' epilogues
                 const _Float16 h = (_Float16)r;  // round to nearest even, subnormals kept
                 memcpy(&q[lvl * n + i], &h, 2);
                 r -= (float)h;
@@ -365,7 +377,7 @@ static int pack_tail(c3_model *m, const TensorMap &tm) {
     TRY(want(tm, "L4.weight", {FC, K4}, &w));
     TRY(want(tm, "L4.bias", {FC}, &b));
     TRY(upload(m, &m->l4_w, std::vector<float>(w, w + (size_t)FC * K4)));
-    if (m->l4_split) TRY(upload_split_pieces(m, &m->l4_w3, std::vector<float>(w, w + (size_t)FC * K4)));
+    if (m->l4_split) TRY(upload_split_pieces(m, &m->l4_w3, std::vector<float>(w, w + (size_t)FC * K4), &m->l4_wscale));
     TRY(upload(m, &m->l4_b, std::vector<float>(b, b + FC)));
     std::vector<float> w5t((size_t)FC * nb * 128), b5((size_t)nb * 128), wh((size_t)nb * 128 * 64, 0.f), bh((size_t)nb * 64, 0.f);
     for (int br = 0; br < nb; ++br) {
@@ -482,7 +494,7 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                             pf[((((size_t)cb * 32 + i) * 64) + lane) * 4 + e] =
                                 pw[(size_t)(32 * cb + (lane & 31)) * Kp + 128 * (lane >> 5) + 4 * i + e];
             TRY(upload(m, &m->proj2_frag, pf));
-            if (m->proj2_split) TRY(upload_split_pieces(m, &m->proj2_w3, pw));
+            if (m->proj2_split) TRY(upload_split_pieces(m, &m->proj2_w3, pw, &m->proj2_wscale));
         }
         TRY(upload(m, &m->proj_w[layer], pw));
         TRY(upload(m, &m->proj_b[layer], pb));
@@ -598,7 +610,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     }
     TRY(upload(m, &m->conv_w[l], pw));
     TRY(upload(m, &m->conv_b[l], pb));
-    if (l > 0 && (m->conv_split_mask & (1u << l))) TRY(upload_split_pieces(m, &m->conv_w3[l], pw));
+    if (l > 0 && (m->conv_split_mask & (1u << l))) TRY(upload_split_pieces(m, &m->conv_w3[l], pw, &m->conv_wscale[l]));
     if (l == 0 && Cin == 8) {
         // conv1_i8_kernel: k-step s = 4 tap + j of lane (n = lane & 31, kk = lane >> 5) multiplies channel 4 kk + j of tap s / 4
         std::vector<float> pf((size_t)36 * 2 * 64);
@@ -628,7 +640,13 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                             memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 0) * 64 + lane) * 8 + j], &h0, 2);
                             memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 1) * 64 + lane) * 8 + j], &h1, 2);
                         }
-            TRY(upload(m, &m->conv1_wfrag16, pf16));
+            float mx = 0.f;  // the fp16 form needs its weights inside the fp16 range; a checkpoint with a degenerate BatchNorm stays on fp32
+            for (size_t i = 0; i < pf16.size() * 2; ++i) {
+                _Float16 h;
+                memcpy(&h, &q16[i], 2);
+                mx = std::max(mx, std::fabs((float)h));
+            }
+            if (mx < 16384.f) TRY(upload(m, &m->conv1_wfrag16, pf16));
         }
     }
     if (kConvStride[l] == 1 && Cin % kWinoBK == 0 && Cout % kWinoNT == 0) {
@@ -659,6 +677,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
             // F16 kernel: fragment (nt, xi, chunk c, piece q), lane (n = lane & 31, hi = lane >> 5), 8 fp16:
             // piece q of V_xi[n][k = 16 c + 8 hi + j] -- the fp32 fragments' bytes and addressing, g replaced by q
             std::vector<float> pv16(pv.size());  // two 2-byte pieces per weight = the fp32 array's bytes
+            m->wino_wscale[l] = pick_wscale(pv.data(), pv.size());
             uint16_t *q16 = reinterpret_cast<uint16_t *>(pv16.data());
             for (int nt = 0; nt < Cout / 32; ++nt)
                 for (int xi = 0; xi < 16; ++xi)
@@ -670,7 +689,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                                         const float v = pv[((((size_t)(nt * 16 + xi) * nch + c) * 2 + gq) * 64 + hi * 32 + ln) * 4 + e];
                                         const int kk = 8 * gq + 4 * hi + e;  // channel within the chunk (fp32 fragment order)
                                         const int hi16 = kk / 8, j = kk % 8;
-                                        const float vs = v * m->split_wscale;  // exact; wp.post_scale undoes it
+                                        const float vs = v * m->wino_wscale[l];  // exact; wp.post_scale undoes it
                                         const _Float16 h0 = (_Float16)vs, h1 = (_Float16)(vs - (float)h0);
                                         const size_t base = (((size_t)(nt * 16 + xi) * nch + c) * 2) * 64 * 8;
                                         memcpy(&q16[base + (size_t)(0 * 64 + hi16 * 32 + ln) * 8 + j], &h0, 2);
@@ -694,7 +713,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         DenseLoaderParams lp{a, lda};
         EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
         if (m->l4_split && m->l4_w3 && m->tail_mfma && m->w5f)  // (the scalar tail sums the partials itself and knows no scale)
-            TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_PARTIAL, 128, 64, s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3));  // partials carry split_wscale
+            TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_PARTIAL, 128, 64, s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3));  // partials carry l4_wscale
         else
             TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
     }
@@ -702,7 +721,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
     if (m->tail_mfma && m->w5f) {
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
         ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
-        if (m->l4_split && m->l4_w3 && m->split_kind == 2) rp.pre = m->split_wscale, rp.post = 1.f / m->split_wscale;  // same condition as the launch above (tail_mfma holds here)
+        if (m->l4_split && m->l4_w3) rp.pre = m->l4_wscale, rp.post = 1.f / m->l4_wscale;  // same condition as the launch above (tail_mfma holds here)
         hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
         HIP_TRY(hipGetLastError());
         Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->row};
@@ -755,7 +774,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
                 wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
                 const int grid = std::min(wp.tiles, m->wg_slots / wp.tiles_n * wp.tiles_n);
                 if (m->wino_v16[l] && (m->wino_f16_mask & (1u << l))) {
-                    wp.v = m->wino_v16[l], wp.post_scale = 1.f / m->split_wscale;
+                    wp.v = m->wino_v16[l], wp.post_scale = 1.f / m->wino_wscale[l];
                     if (wp.res)
                         hipLaunchKernelGGL((wino_conv_kernel_p<true, 0, 0, true>), dim3(grid), dim3(256), 0, s, wp);
                     else
@@ -800,7 +819,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
             if (!res && m->conv_w3[l] && (m->conv_split_mask & (1u << l))) {
-                ep.post_scale = (m->split_kind == 2 ? 1.f / m->split_wscale : 1.f);
+                ep.post_scale = 1.f / m->conv_wscale[l];
                 // fp16x3 keeps the fp32 kernel's LDS footprint, so conv3 (N = 128) can use 128x128 tiles at two workgroups
                 // per CU (43 -> 38 us); conv5 stays on 128x64 (480 workgroups), bf16x6 needs 72 KB per 128x64 tile
                 if (m->split_kind == 2 && !(m->conv_bn64_mask & (1u << l)))
@@ -893,7 +912,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         if (m->proj2_split && m->proj2_w3 && m->lstm2_v2) {
             DenseLoaderParams lp{m->h1, 256};
             EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
-            ep.post_scale = (m->split_kind == 2 ? 1.f / m->split_wscale : 1.f);
+            ep.post_scale = 1.f / m->proj2_wscale;
             // 128x64 tiles (72 KB of LDS, two workgroups per CU); 128x128 (96 KB, one per CU) measured 193 us
             TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_BIAS, 128, 64, s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep, m->proj2_w3));
         } else if (m->proj2_stream && m->proj2_frag && m->lstm2_v2) {

@@ -366,6 +366,30 @@ def test_fp16x3_winograd_stays_at_fp32_level(monkeypatch, oracle_mod):
         assert v <= 5 * errs["0"][k] + 3e-7, (k, errs)
 
 
+def test_large_folded_weights_keep_their_fp16_pieces_in_range(oracle_mod):
+    """fp16x3 packs a weight tensor times a power of two picked per tensor (c3_model.hip pick_wscale).  A BatchNorm with a
+    large gamma / sigma (folded conv3 weights up to ~600 here, activations of that stage ~1000) must shrink that factor
+    instead of overflowing the high fp16 piece; the next stage's BatchNorm brings the range back."""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=51)
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    sd["conv3.bn.weight"] *= 400.0
+    sd["conv3.bn.bias"] *= 400.0
+    for k in ("res_block2.0.conv1.weight", "res_block2.0.conv2.weight"):
+        sd[k] /= 20.0
+    sd["conv5.conv.weight"] /= 400.0
+    x = syn.make_fa_windows(5, seed=52)
+    m = make_model(syn.FULL_ALIGNMENT, 8, True, sd, keep=True)
+    y = m.predict_numpy(x)
+    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+    assert float(np.abs(d["act3"]).max()) > 200.0  # the stage really is large
+    for l in range(9):
+        a = m.debug_fetch(f"act{l}", d[f"act{l}"].shape)
+        scale = max(1.0, float(np.abs(d[f"act{l}"]).max()))
+        assert np.isfinite(a).all(), f"layer {l} overflowed"
+        assert float(np.abs(a - d[f"act{l}"]).max()) / scale < 2e-5, f"layer {l}"
+    util.assert_rows_match(y, y_o, what="large folded weights")
+
+
 def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracle_mod):
     """the A/B switches of README.md select older kernels for the same layers: each selection stays within the parity
     gate (they are what a regression is bisected with, so they must keep working)"""
