@@ -155,6 +155,7 @@ struct Conv1F16Params {
                             // 1.28 W'[cout = 32 cb + (lane & 31)][tap = 2 t + (lane >> 5)][channel j]  (W' has BN and /100 folded)
     const float *bias;      // [64]
     float *out;             // [B][OH][OW][64]
+    uint32_t *range_flag;   // set to 1 when an output reaches kF16Range (c3_gemm.h)
     int B, H, W, OH, OW, M, groups;
 };
 
@@ -221,11 +222,13 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
         }
         return o;
     };
+    int omax_i = 0;
     auto store_one = [&](const f32x16 (&r)[2], uint32_t o0, int idx) __attribute__((always_inline)) {
         const int cb = idx >> 4, v = idx & 15;
         const uint32_t off = o0 + (uint32_t)(((v & 3) + 8 * (v >> 2)) * 256 + cb * 128);
         const float val = r[cb][v];
         const int relu = max(__float_as_int(val), 0);
+        omax_i = max(omax_i, relu);  // non-negative floats order like their bit patterns
         __builtin_amdgcn_raw_buffer_store_b32((uint32_t)relu, orsrc, off, 0, 0);
     };
     c1_u32x2 d[5];
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
         }
     };
     auto out_base = [&](int g) { return (uint32_t)((g * 32 + 4 * kh) * 256 + m * 4); };
-    f32x16 accA[2], accB[2];
+    f32x16 accA[2], accB[2] = {};  // accB is the first group's (dropped) "previous" result: defined, so that the range check sees zeros
     uint32_t prev_o0 = 0x80000000u;
     int g = gw;
     for (; g + nw < p.groups; g += 2 * nw) {
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
 #pragma unroll
         for (int i = 0; i < 32; ++i) store_one(accB, prev_o0, i);
     }
+    if (p.range_flag && omax_i >= __float_as_int(kF16Range)) atomicOr(p.range_flag, 1u);  // +NaN patterns are larger still
 }
 
 }  // namespace c3

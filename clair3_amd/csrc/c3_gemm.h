@@ -71,6 +71,10 @@ __device__ __forceinline__ void split2_f16(const f32x4 x, u32x2 (&piece)[2]) {
     }
 }
 
+// Outputs at or above this magnitude make the host re-run the batch on fp32 matrix instructions: a consumer may add up
+// to four of them (Winograd input transform) before splitting the sum into fp16 pieces (max 65504).
+constexpr float kF16Range = 16000.f;
+
 constexpr int kBK = 32;        // floats per K chunk
 constexpr int kThreads = 256;  // 4 waves, 2 (M) x 2 (N)
 
@@ -292,6 +296,7 @@ struct EpilogueParams {
     const float *res;    // residual, same layout as c (EPI_BIAS_RES_RELU)
     int64_t ldc;
     int64_t split_stride;  // M*ldc for EPI_PARTIAL
+    uint32_t *range_flag = nullptr;  // SPLIT: set to 1 when an output reaches kF16Range (the consumers split it into fp16 pieces)
     float post_scale = 1.f;  // SPLIT: the weights are packed times a power of two (so that their low fp16 piece stays a
                              // normal number) and the sum is scaled back here, exactly, inside the bias FMA
 };
@@ -566,6 +571,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(EPI == EPI_BIAS_RES_RELU ? ep.res : ep.c), 0, (uint32_t)((int64_t)gp.M * ep.ldc * 4), 0x00020000);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    float omax = 0.f;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
@@ -586,10 +592,13 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = __int_as_float(max(__float_as_int(val[e]), 0));
                 }
+                if constexpr (SPLIT != 0 && EPI != EPI_PARTIAL) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3]))));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), crsrc, off + 32 * q, 0, 0);
             }
         }
     }
+    if constexpr (SPLIT != 0 && EPI != EPI_PARTIAL)
+        if (ep.range_flag && !(omax < kF16Range)) atomicOr(ep.range_flag, 1u);  // also taken for NaN
     trace(12);  // epilogue stores issued
 }
 

@@ -100,6 +100,9 @@ struct HostSlot {
     hipEvent_t ev_h2d = nullptr, ev_compute = nullptr, ev_out = nullptr;
     float *y_host = nullptr;
     size_t y_bytes = 0;
+    int64_t batch = 0;  // what is in flight (for the fp32 re-run of c3_predict_wait)
+    uint32_t *pin_flag = nullptr;  // pinned copy of the model's range_flag after this batch
+    int x_dtype = 0;
     bool busy = false;
 };
 
@@ -145,6 +148,8 @@ struct c3_model {
     size_t decode_bytes = 0;
     bool conv1_direct = true;       // 8-channel conv1 through conv1_i8_kernel (c3_conv1.h); env C3HIP_CONV1_DIRECT
     float *conv1_wfrag = nullptr;   // its resident B fragments [36][2][64]
+    uint32_t *range_flag = nullptr; // device word set by the fp16x3 kernels when an activation nears the fp16 range (c3_gemm.h kF16Range)
+    bool f16_ok = true;             // cleared by c3_predict_wait when a batch came back non-finite: every layer then runs its fp32-MFMA form
     float *conv1_wfrag16 = nullptr; // conv1_i8_f16_kernel: [5][2][2 pieces][64][8 fp16]
     bool conv1_f16 = true;          // conv1 on fp16 matrix instructions (int8 inputs exact, weights as two pieces); env C3HIP_CONV1_F16
     unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
@@ -712,7 +717,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         ProfScope ps(m, s, tag_l4, 2.0 * n * FC * K4, 4.0 * (n * K4 + (double)FC * K4 + (double)S * n * FC));
         DenseLoaderParams lp{a, lda};
         EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
-        if (m->l4_split && m->l4_w3 && m->tail_mfma && m->w5f)  // (the scalar tail sums the partials itself and knows no scale)
+        if (m->f16_ok && m->l4_split && m->l4_w3 && m->tail_mfma && m->w5f)  // (the scalar tail sums the partials itself and knows no scale)
             TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_PARTIAL, 128, 64, s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3));  // partials carry l4_wscale
         else
             TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
@@ -721,7 +726,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
     if (m->tail_mfma && m->w5f) {
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
         ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
-        if (m->l4_split && m->l4_w3) rp.pre = m->l4_wscale, rp.post = 1.f / m->l4_wscale;  // same condition as the launch above (tail_mfma holds here)
+        if (m->f16_ok && m->l4_split && m->l4_w3) rp.pre = m->l4_wscale, rp.post = 1.f / m->l4_wscale;  // same condition as the launch above (tail_mfma holds here)
         hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
         HIP_TRY(hipGetLastError());
         Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->row};
@@ -773,8 +778,8 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             if ((m->wino_p_mask & (1u << l)) && Cout % 64 == 0) {  // persistent 32 x 64 workgroups
                 wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
                 const int grid = std::min(wp.tiles, m->wg_slots / wp.tiles_n * wp.tiles_n);
-                if (m->wino_v16[l] && (m->wino_f16_mask & (1u << l))) {
-                    wp.v = m->wino_v16[l], wp.post_scale = 1.f / m->wino_wscale[l];
+                if (m->f16_ok && m->wino_v16[l] && (m->wino_f16_mask & (1u << l))) {
+                    wp.v = m->wino_v16[l], wp.post_scale = 1.f / m->wino_wscale[l], wp.range_flag = m->range_flag;
                     if (wp.res)
                         hipLaunchKernelGGL((wino_conv_kernel_p<true, 0, 0, true>), dim3(grid), dim3(256), 0, s, wp);
                     else
@@ -796,9 +801,10 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
                     hipLaunchKernelGGL(wino_conv_kernel<false>, dim3(wp.tiles), dim3(256), 0, s, wp);
             }
             HIP_TRY(hipGetLastError());
-        } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_f16 && m->conv1_wfrag16) {
+        } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_f16 && m->conv1_wfrag16 && m->f16_ok) {
             Conv1F16Params cp;
             cp.x = x, cp.wfrag = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.bias = m->conv_b[0], cp.out = m->act[0];
+            cp.range_flag = m->range_flag;
             cp.B = (int)n, cp.H = hh[0], cp.W = ww[0], cp.OH = hh[1], cp.OW = ww[1], cp.M = M, cp.groups = (M + 31) / 32;
             const int grid = std::min((cp.groups + 3) / 4, m->wg_slots);
             hipLaunchKernelGGL(conv1_i8_f16_kernel, dim3(grid), dim3(256), 0, s, cp);
@@ -818,8 +824,8 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             const int nk = 9 * cin / kBK;
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
-            if (!res && m->conv_w3[l] && (m->conv_split_mask & (1u << l))) {
-                ep.post_scale = 1.f / m->conv_wscale[l];
+            if (m->f16_ok && !res && m->conv_w3[l] && (m->conv_split_mask & (1u << l))) {
+                ep.post_scale = 1.f / m->conv_wscale[l], ep.range_flag = m->range_flag;
                 // fp16x3 keeps the fp32 kernel's LDS footprint, so conv3 (N = 128) can use 128x128 tiles at two workgroups
                 // per CU (43 -> 38 us); conv5 stays on 128x64 (480 workgroups), bf16x6 needs 72 KB per 128x64 tile
                 if (m->split_kind == 2 && !(m->conv_bn64_mask & (1u << l)))
@@ -887,7 +893,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     if (fused1) {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
         LstmFusedParams<T> lp{x, starts, m->l1_wih, m->l1_bias, m->whh[0], m->h1, (int)n, Tn, m->C};
-        if (m->lstm1_f16 && m->whh16[0]) {
+        if (m->f16_ok && m->lstm1_f16 && m->whh16[0]) {
             lp.whh = m->whh16[0];
             hipLaunchKernelGGL((lstm1_fused_kernel<T, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
         } else {
@@ -909,7 +915,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.proj2", 2.0 * M * 1280.0 * 256.0, 4.0 * M * (256.0 + 1280.0));
-        if (m->proj2_split && m->proj2_w3 && m->lstm2_v2) {
+        if (m->f16_ok && m->proj2_split && m->proj2_w3 && m->lstm2_v2) {
             DenseLoaderParams lp{m->h1, 256};
             EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
             ep.post_scale = 1.f / m->proj2_wscale;
@@ -944,7 +950,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
         if (m->lstm2_v2) {
             Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
-            if (m->lstm2_f16 && m->whh16[1]) {
+            if (m->f16_ok && m->lstm2_f16 && m->whh16[1]) {
                 lp.whh = m->whh16[1];
                 hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
             } else {
@@ -1044,6 +1050,11 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     }
     c3_model *m = new c3_model();
     m->kind = kind, m->C = in_channels, m->add_indel = add_indel_length ? 1 : 0, m->device = device;
+    if (hipMalloc((void **)&m->range_flag, 256) != hipSuccess || hipMemset(m->range_flag, 0, 256) != hipSuccess) {
+        fail("c3_model_create: cannot allocate the range flag");
+        delete m;
+        return nullptr;
+    }
     m->nb = m->add_indel ? 4 : 2, m->nout = m->add_indel ? 90 : 24;
     m->row = m->nout;
     m->FC = kind == C3_KIND_PILEUP ? 128 : 256;
@@ -1173,6 +1184,7 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_compute, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
     }
+    if (!sl.pin_flag) HIP_TRY(hipHostMalloc((void **)&sl.pin_flag, 64, hipHostMallocDefault));
     if (xb > sl.cap_x) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);
         if (sl.dev_x) (void)hipFree(sl.dev_x);
@@ -1204,7 +1216,7 @@ int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batc
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
     const size_t yb = (size_t)batch * m->row * sizeof(float);
-    sl.y_host = y_host, sl.y_bytes = yb, sl.busy = true;
+    sl.y_host = y_host, sl.y_bytes = yb, sl.busy = true, sl.batch = batch, sl.x_dtype = x_dtype;
     if (batch == 0) return 0;
     TRY(ensure_slot(m, sl, xb, yb));
     TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream));
@@ -1218,6 +1230,7 @@ int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batc
     HIP_TRY(hipEventRecord(sl.ev_compute, m->stream));
     HIP_TRY(hipStreamWaitEvent(m->d2h_stream, sl.ev_compute, 0));
     HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->d2h_stream));
+    HIP_TRY(hipMemcpyAsync(sl.pin_flag, m->range_flag, 4, hipMemcpyDeviceToHost, m->d2h_stream));
     HIP_TRY(hipEventRecord(sl.ev_out, m->d2h_stream));
     return 0;
 }
@@ -1230,6 +1243,21 @@ int c3_predict_wait(c3_model *m, int slot) {
     sl.busy = false;
     if (sl.y_bytes == 0) return 0;
     HIP_TRY(hipEventSynchronize(sl.ev_out));
+    if (m->f16_ok) {
+        // Safety net of the fp16x3 products: an activation beyond the fp16 range (|x| >= 65504; never seen)
+        // would surface as inf / NaN rows.  Rows are probabilities, so any non-finite value means exactly that: switch
+        // every layer to its fp32-MFMA form for the rest of this handle's life and run the batch again.
+        const uint32_t *u = reinterpret_cast<const uint32_t *>(sl.pin_y);
+        bool bad = *sl.pin_flag != 0;  // a conv stage produced a value near the fp16 range (kF16Range): its consumers may have overflowed
+        for (size_t i = 0, n = sl.y_bytes / 4; i < n; ++i) bad |= (u[i] & 0x7f800000u) == 0x7f800000u;
+        if (bad) {
+            m->f16_ok = false;
+            fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
+            TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.dev_y));
+            HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, sl.y_bytes, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+    }
     memcpy(sl.y_host, sl.pin_y, sl.y_bytes);
     return 0;
 }
@@ -1284,6 +1312,7 @@ int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uin
     const size_t total = yb + rb + 2 * mb + rb;
     if (m->decode_bytes < total) {
         if (m->decode_dev) (void)hipFree(m->decode_dev);
+    if (m->range_flag) (void)hipFree(m->range_flag);
         m->decode_dev = nullptr, m->decode_bytes = 0;
         HIP_TRY(hipMalloc(&m->decode_dev, total));
         m->decode_bytes = total;
@@ -1358,6 +1387,7 @@ int c3_model_destroy(c3_model *m) {
     for (auto &sl : m->slot) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);
         if (sl.pin_y) (void)hipHostFree(sl.pin_y);
+        if (sl.pin_flag) (void)hipHostFree(sl.pin_flag);
         if (sl.dev_x) (void)hipFree(sl.dev_x);
         if (sl.dev_y) (void)hipFree(sl.dev_y);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);

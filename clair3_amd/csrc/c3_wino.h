@@ -40,6 +40,7 @@ struct WinoParams {
     int B, H, W, Cin, Cout;
     int th, tw, P;       // tiles per column / row, total tiles
     int tiles_n, tiles;  // Cout/32, ceil(P/64)*tiles_n
+    uint32_t *range_flag = nullptr;  // F16 kernel: set to 1 when an output reaches kF16Range
     float post_scale = 1.f;  // F16 kernel: V is packed times a power of two (low fp16 pieces stay normal), undone in the bias FMA
 };
 

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
     int buf = 0;
     for (int tm = tm0; tm < ngm; tm += tstride, buf ^= 1) {
         f32x16 acc[4][2];
+        float omax = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -332,9 +333,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel_p(WinoParams p) {
                     if constexpr (RES) o += r[i][j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                    if constexpr (F16) omax = fmaxf(omax, fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])));
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, off[i][j], 0, 0);
                 }
         }
+        if constexpr (F16)
+            if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);
     }
 }
 

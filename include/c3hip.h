@@ -100,6 +100,10 @@ int64_t c3_model_window_bytes(const c3_model *m, int x_dtype);
 
 /* y_host[batch][24|90 (c3_model_row_size)] = forward(x_host[batch][...]); synchronous */
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host);
+/* Note on the arithmetic: the contractions form their fp32 products from two fp16 pieces per operand (fp16x3, DESIGN.md 1:
+ * fp32-level parity).  Should a checkpoint ever drive an activation towards the fp16 range (|x| >= 16000), c3_predict /
+ * c3_predict_wait notice (a flag raised by the kernels, or a non-finite row), print one line to stderr, switch the handle
+ * to the fp32 matrix instructions for the rest of its life and run the batch again; c3_predict_device does not check. */
 /* asynchronous pair, slot in {0,1}: submit copies x into pinned staging and enqueues H2D + kernels + D2H;
  * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);

@@ -390,6 +390,38 @@ def test_large_folded_weights_keep_their_fp16_pieces_in_range(oracle_mod):
     util.assert_rows_match(y, y_o, what="large folded weights")
 
 
+def test_activations_beyond_the_fp16_range_fall_back_to_fp32(oracle_mod, capfd):
+    """a stage whose activations reach ~1e7 overflows the fp16 pieces of the layers that read it: the rows come back
+    non-finite, c3_predict_wait notices (rows are probabilities), switches the handle to the fp32-MFMA kernels and runs
+    the batch again -- the caller still gets the reference's rows"""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=61)
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    sd["conv3.bn.weight"] *= 4.0e6
+    sd["conv3.bn.bias"] *= 4.0e6
+    for k in ("res_block2.0.conv1.weight", "res_block2.0.conv2.weight"):
+        sd[k] /= 2.0e3
+    sd["conv5.conv.weight"] /= 4.0e6
+    x = syn.make_fa_windows(5, seed=62)
+    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+    assert float(np.abs(d["act3"]).max()) > 1.0e6
+    m = make_model(syn.FULL_ALIGNMENT, 8, True, sd)
+    y = m.predict_numpy(x)
+    assert np.isfinite(y).all()
+    util.assert_rows_match(y, y_o, tol=1e-4, what="fp32 re-run")
+    assert "continues on fp32" in capfd.readouterr().err
+    util.assert_rows_match(m.predict_numpy(x), y_o, tol=1e-4, what="handle stays on fp32")
+
+
+def test_range_guard_is_silent_on_ordinary_models(capfd):
+    """the seeded models (activations up to ~15) never trip the range flag: no fallback, no message, for either network"""
+    for kind, ch, indel in ((syn.FULL_ALIGNMENT, 8, True), (syn.FULL_ALIGNMENT, 9, True), (syn.PILEUP, 18, False)):
+        m = make_model(kind, ch, indel, syn.make_state_dict(kind, ch, indel, seed=7))
+        x = syn.make_windows(kind, 300, seed=8, channels=ch)
+        for _ in range(2):
+            assert np.isfinite(m.predict_numpy(x)).all()
+    assert "continues on fp32" not in capfd.readouterr().err
+
+
 def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracle_mod):
     """the A/B switches of README.md select older kernels for the same layers: each selection stays within the parity
     gate (they are what a regression is bisected with, so they must keep working)"""
