@@ -67,6 +67,30 @@ def gather_rows(y_local, n_total, dst=0):
     return None
 
 
+class RowGatherer:
+    """Collect the per-step rows of this rank and send them to ``dst`` ``every`` steps at a time -- one collective per
+    super-batch instead of one per step.  ``add(y)`` returns what ``gather_rows`` returns when a group is
+    complete (the rows of the group's steps, rank-major: all steps of rank 0, then all steps of rank 1, ...; None on the
+    other ranks) and None otherwise; ``flush()`` sends an incomplete group.  Every step must bring the same number of
+    rows per rank (``rows_per_step_total`` = that number x world size)."""
+
+    def __init__(self, rows_per_step_total, every=8, dst=0):
+        self.n_total, self.every, self.dst, self.pending = int(rows_per_step_total), int(every), dst, []
+
+    def add(self, y):
+        self.pending.append(y)
+        return self.flush() if len(self.pending) >= self.every else None
+
+    def flush(self):
+        if not self.pending:
+            return None
+        import torch
+        rows = torch.cat(self.pending) if len(self.pending) > 1 else self.pending[0]
+        k = len(self.pending)
+        self.pending = []
+        return gather_rows(rows, self.n_total * k, dst=self.dst)
+
+
 def predict_sharded(model, x_all, dst=0):
     """Whole-job helper: every rank passes the same host window array (or its own memmap of it), computes its
     contiguous shard on its GPU and rank ``dst`` receives all rows in window order (numpy), others None."""

@@ -59,3 +59,53 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     y_single = oracle.pileup_forward(sd, x, n_threads=1)
     assert y.shape == (n, 24)
     assert np.array_equal(y, y_single)  # sharding must not change a single bit, nor the row order
+
+
+GATHERER = textwrap.dedent("""
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, {root!r})
+    from clair3_amd import dist as c3dist
+    rank, world, _ = c3dist.init_from_env(backend="gloo")
+    B, W, steps, every = 5, 7, 11, 4
+    g = c3dist.RowGatherer(B * world, every=every, dst=0)
+    got = []
+    for step in range(steps):  # row value encodes (step, rank, row)
+        y = torch.tensor([[1000.0 * step + 100.0 * rank + r] * W for r in range(B)])
+        out = g.add(y)
+        if out is not None:
+            got.append(out)
+    out = g.flush()
+    if out is not None:
+        got.append(out)
+    assert g.flush() is None
+    if rank == 0:
+        np.save({out!r}, torch.cat(got).numpy())
+    else:
+        assert not got
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+""")
+
+
+def test_row_gatherer_groups_steps_and_loses_nothing(tmp_path):
+    """bench.py --gpus N sends the rows of 8 steps per collective: groups of `every` steps plus the flushed remainder,
+    rank-major inside a group, every (step, rank, row) exactly once"""
+    out = str(tmp_path / "g.npy")
+    script = tmp_path / "gatherer.py"
+    script.write_text(GATHERER.format(root=ROOT, out=out))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    y = np.load(out)
+    B, W, steps, every, world = 5, 7, 11, 4, 2
+    assert y.shape == (steps * world * B, W)
+    want = []
+    for g0 in range(0, steps, every):
+        group = range(g0, min(g0 + every, steps))
+        for rank in range(world):
+            for step in group:
+                want += [1000.0 * step + 100.0 * rank + r for r in range(B)]
+    assert np.array_equal(y[:, 0], np.array(want, dtype=np.float32))
