@@ -615,7 +615,8 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     }
     TRY(upload(m, &m->conv_w[l], pw));
     TRY(upload(m, &m->conv_b[l], pb));
-    if (l > 0 && (m->conv_split_mask & (1u << l))) TRY(upload_split_pieces(m, &m->conv_w3[l], pw, &m->conv_wscale[l]));
+    if ((l > 0 && (m->conv_split_mask & (1u << l))) || (l == 0 && Cin != 8 && m->conv1_f16))  // (the 9-channel conv1 runs on the tiled GEMM)
+        TRY(upload_split_pieces(m, &m->conv_w3[l], pw, &m->conv_wscale[l]));
     if (l == 0 && Cin == 8) {
         // conv1_i8_kernel: k-step s = 4 tap + j of lane (n = lane & 31, kk = lane >> 5) multiplies channel 4 kk + j of tap s / 4
         std::vector<float> pf((size_t)36 * 2 * 64);
@@ -818,7 +819,12 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             HIP_TRY(hipGetLastError());
         } else if (l == 0) {
             Conv1LoaderParams lp{x, (const int8_t *)m->zeros, hh[0], ww[0], cin, hh[1], ww[1]};
-            TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU, 128, 64>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep)));
+            if (m->f16_ok && m->conv1_f16 && m->conv_w3[0]) {
+                ep.post_scale = 1.f / m->conv_wscale[0], ep.range_flag = m->range_flag;
+                TRY(LAUNCH_SPLIT(m, Conv1Loader<4>, EPI_BIAS_RELU, 128, 64, s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep, m->conv_w3[0]));
+            } else {
+                TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU, 128, 64>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep)));
+            }
         } else {
             ConvLoaderParams lp{m->act[l - 1], m->zeros, hh[l], ww[l], cin, hh[l + 1], ww[l + 1], kConvStride[l], cin / kBK};
             const int nk = 9 * cin / kBK;
