@@ -33,6 +33,10 @@ template <int ABL> static float run_p(const WinoParams &wp, int slots) {
     const int grid = std::min(wp.tiles, slots / wp.tiles_n * wp.tiles_n);
     return time_it([&] { hipLaunchKernelGGL((wino_conv_kernel_p<true, ABL>), dim3(grid), dim3(256), 0, 0, wp); });
 }
+template <int ABL> static float run_p16(const WinoParams &wp, int slots) {
+    const int grid = std::min(wp.tiles, slots / wp.tiles_n * wp.tiles_n);
+    return time_it([&] { hipLaunchKernelGGL((wino_conv_kernel_p<true, ABL, 0, true>), dim3(grid), dim3(256), 0, 0, wp); });
+}
 int main() {
     const int B = 256;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
@@ -62,6 +66,25 @@ int main() {
         printf("== %s: %d workgroups of 32 tiles x 64 couts, %d slots; pure MFMA time at 157.3 TF = %.1f us\n", sh.name, wp.tiles, slots, mf / 157.3e6);
         for (int i = 0; i < 8; ++i)
             printf("  %-26s n64 %6.1f us (%5.1f TF-eq)   persistent %6.1f us (%5.1f TF-eq)\n", wn[i], t[0][i], fl / t[0][i] / 1e6, t[1][i], fl / t[1][i] / 1e6);
+        {   // the F16 form (fp16x3 products): same ablations, then its phase trace
+            float tf[8] = {run_p16<0>(wp, slots), run_p16<1>(wp, slots), run_p16<3>(wp, slots), run_p16<4>(wp, slots),
+                           run_p16<8>(wp, slots), run_p16<16>(wp, slots), run_p16<15>(wp, slots), run_p16<28>(wp, slots)};
+            for (int i = 0; i < 8; ++i) printf("  F16 %-26s persistent %6.1f us\n", wn[i], tf[i]);
+            long long *tb; CK(hipMalloc(&tb, 4 * 256 * 16)); CK(hipMemset(tb, 0, 4 * 256 * 16));
+            WinoParams wt = wp; wt.zeros = reinterpret_cast<const float *>(tb);
+            const int grid = std::min(wt.tiles, slots / wt.tiles_n * wt.tiles_n);
+            hipLaunchKernelGGL((wino_conv_kernel_p<true, 0, 2, true>), dim3(grid), dim3(256), 0, 0, wt);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> ht(4 * 256 * 2);
+            CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+            for (int w = 0; w < 1; ++w) {
+                printf("  F16 trace wave %d (tag:+cycles):", w);
+                for (int i = 1; i < 120 && ht[(w * 256 + i) * 2] != 0; ++i)
+                    printf(" %lld:+%lld", ht[(w * 256 + i) * 2], ht[(w * 256 + i) * 2 + 1] - ht[(w * 256 + i - 1) * 2 + 1]);
+                printf("\n");
+            }
+            hipFree(tb);
+        }
         {   // phase trace of workgroup 0 (OPT bit1): shader-clock deltas between phase boundaries, wave 0
             long long *tb; CK(hipMalloc(&tb, 4 * 256 * 16)); CK(hipMemset(tb, 0, 4 * 256 * 16));
             WinoParams wt = wp; wt.zeros = reinterpret_cast<const float *>(tb);
