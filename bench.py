@@ -187,8 +187,8 @@ def run_workload(name, args, rank, world, local):
     launches = sum(r["launches"] for r in dom)
     achieved = fl / ms / 1e9 if ms > 0 else 0.0
     traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if kind == syn.FULL_ALIGNMENT and os.path.exists(tpath):
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if kind == syn.FULL_ALIGNMENT else "pmc_traffic_pileup.json")
+    if os.path.exists(tpath) and channels != 9:
         # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2
         # + WRITE_SIZE, collected in their own runs by tools/gpu_round.sh `pmc`; bench.py cannot run rocprof on itself)
         with open(tpath) as fh:

@@ -54,5 +54,43 @@ def main(tag):
     print({k: v for k, v in out.items() if k != "per_kernel"})
 
 
+def main_pileup(tag):
+    """the two BiLSTM recurrences of one pileup step (B = 1024): gpurun_out/pmcp_fetch, pmcp_write (stage `pmcp`)"""
+    f = agg(os.path.join(ROOT, "gpurun_out/pmcp_fetch/c3_counter_collection.csv"))
+    w = agg(os.path.join(ROOT, "gpurun_out/pmcp_write/c3_counter_collection.csv"))
+    lstm = lambda k: ("lstm1_fused_kernel" in k) or ("lstm_recurrent_kernel" in k)
+    tot_f = tot_w = n = 0
+    per = {}
+    for k in f:
+        fs, ws = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
+        per[k[:90]] = {"launches": len(fs), "fetch_kb_avg_reported": sum(fs) / len(fs), "write_kb_avg": sum(ws) / len(ws)}
+        if lstm(k):
+            tot_f += sum(fs)
+            tot_w += sum(ws)
+            n += len(fs)
+    B, T = 1024, 33
+    # LSTM1: int8 windows in, h1 (256 fp32) out; LSTM2: gx2 (1280 fp32) in, h2 (320 fp32) out -- per (window, position)
+    algorithmic = B * T * ((18 + 256 * 4) + (1280 * 4 + 320 * 4)) / 2
+    out = {
+        "tag": tag,
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around "
+                  "`bench.py --gpus 1 --steps 5 --warmup 2 --workload pileup` (B=1024)",
+        "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B",
+        "kernel_family": "the two BiLSTM recurrence launches of one pileup step (lstm1_fused_kernel + lstm_recurrent_kernel_v2<160>)",
+        "launches": n,
+        "hbm_bytes_per_launch": (2 * tot_f + tot_w) * 1024 / n,
+        "fetch_bytes_per_launch_corrected": 2 * tot_f * 1024 / n,
+        "write_bytes_per_launch": tot_w * 1024 / n,
+        "algorithmic_bytes_per_launch": algorithmic,
+        "per_kernel": per,
+    }
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic_pileup.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print({k: v for k, v in out.items() if k != "per_kernel"})
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "round1")
+    if len(sys.argv) > 2 and sys.argv[1] == "pileup":
+        main_pileup(sys.argv[2])
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else "round1")
