@@ -24,6 +24,8 @@ struct LstmFusedParams {
     const float *wih;   // [dir][wave][gate][ks = 5][lane]: W_ih[gate*H + wave*16 + (lane&15)][4*ks + (lane>>4)], 0 beyond C
     const float *bias;  // [dir][wave][gate][16]: b_ih + b_hh of row gate*H + wave*16 + u
     const float *whh;   // [dir][wave][gate][q = H/16][lane][4]   (same packing as lstm_recurrent_kernel)
+    const uint32_t *wih16;  // F16 + int8 input: [dir][wave][gate][piece][lane][4 dwords = 8 fp16]: piece of
+                            // 128 W_ih[gate*H + wave*16 + (lane&15)][8 (lane>>4) + j] (0 beyond C); the kernel feeds x / 128
     float *hout;        // [B][T][2H]; column = dir*H + unit
     int B, T, C;
 };
@@ -94,6 +96,37 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
     f32x4v biasv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) biasv[g] = f32x4v{bias[g], bias[g], bias[g], bias[g]};
+    // F16 + int8 windows: the projection too runs on v_mfma_f32_16x16x32_f16.  The counts are exact in fp16 (one piece);
+    // lane (window, s) supplies channels 8 s .. 8 s + 7 of x[window][t] as b / 128 -- four 2-byte loads, each widened by
+    // one v_perm_b32 + one v_pk_add_f16 (byte ^ 0x80 into the mantissa of 8.0, minus 9) -- against two fp16 pieces of
+    // 128 W_ih: 8 matrix instructions of 16 cycles instead of 20 of 32.
+    constexpr bool F16P = F16 && sizeof(TX) == 1;
+    typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
+    u32x4p wp16[4][2];
+    uint32_t xo2[4];
+    if constexpr (F16P) {
+        const u32x4p *wi = reinterpret_cast<const u32x4p *>(p.wih16) + ((int64_t)(dir * NW + wave) * 4 * 2) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wp16[g][q] = wi[(g * 2 + q) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 8 * s + 2 * j;  // channels k, k + 1 (C is even: 18)
+            xo2[j] = k < p.C ? (uint32_t)(xrow + k) : 0x80000000u;
+        }
+    }
+    auto load_x16 = [&](int t, u32x4p &xa) __attribute__((always_inline)) {
+        const int so = t * p.C;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t u = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, xo2[j], so, 0) ^ 0x8080u;
+            const uint32_t w = __builtin_amdgcn_perm(0x48484848u, u, 0x04010400u);
+            xa[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, w) + h2{(_Float16)-9.0f, (_Float16)-9.0f});
+        }
+    };
+    u32x4p xn16 = {0u, 0u, 0u, 0u};
     const int h_col = dir * H + wave * 16 + col;
     float c[4] = {0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t hrsrc =
@@ -105,7 +138,8 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         ho[v] = b < p.B ? (uint32_t)((((int64_t)b * p.T) * (2 * H) + h_col) * 4) : 0x80000000u;
     }
     float xn[kFusedKS];
-    load_x(dir ? p.T - 1 : 0, xn);
+    if constexpr (F16P) load_x16(dir ? p.T - 1 : 0, xn16);
+    else load_x(dir ? p.T - 1 : 0, xn);
     __syncthreads();
 
     for (int step = 0; step < p.T; ++step) {
@@ -117,6 +151,15 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         f32x4v acc[4];
         // gates = bias + x_t W_ih^T   (clair3/model.py:131-132: x.float() then LSTM1); the bias is the C operand of the
         // first MFMA (a resident 4-register vector per gate) instead of 16 register moves per step
+        if constexpr (F16P) {
+            const f16x8v xh = __builtin_bit_cast(f16x8v, xn16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wp16[g][1]), biasv[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wp16[g][0]), acc[g], 0, 0, 0);
+            }
+            if (step + 1 < p.T) load_x16(dir ? t - 1 : t + 1, xn16);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < kFusedKS; ++ks)
 #pragma unroll
@@ -124,6 +167,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wih[g][ks], ks == 0 ? biasv[g] : acc[g], 0, 0, 0);
         // next step's counts: requested from inside the MFMA stream (a load costs ~60 cycles of issue outside it)
         if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1, xn);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (F16) {
             if (step > 0) {

@@ -125,6 +125,7 @@ struct c3_model {
     bool lstm2_f16 = true;                  // LSTM2 recurrence on fp16x3 split products; env C3HIP_LSTM2_F16
     bool lstm1_f16 = true;                  // LSTM1 recurrence likewise; env C3HIP_LSTM1_F16
     float *l1_wih = nullptr, *l1_bias = nullptr;  // LSTM1 input projection as MFMA fragments (fused kernel)
+    float *l1_wih16 = nullptr;                    // the same as two fp16 pieces of 128 W_ih for the F16 kernel (int8 windows)
     bool lstm1_fused = true;                // env C3HIP_LSTM1_FUSED=0 selects GEMM + recurrence
     // full alignment
     float *conv_w[9] = {};
@@ -581,6 +582,27 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
         }
         TRY(upload(m, &m->l1_wih, fw));
         TRY(upload(m, &m->l1_bias, fb));
+        if (m->lstm1_f16 && in <= 32 && in % 2 == 0) {
+            // [dir][wave][gate][piece][lane][8 fp16]: piece of 128 W_ih[g*H + w*16 + (lane&15)][8 (lane>>4) + j]
+            std::vector<float> fw16((size_t)2 * NW * 4 * 2 * 64 * 4, 0.f);
+            uint16_t *q16 = reinterpret_cast<uint16_t *>(fw16.data());
+            for (int dir = 0; dir < 2; ++dir) {
+                const float *wih;
+                TRY(want(tm, base + ".weight_ih_l0" + (dir ? "_reverse" : ""), {4 * H, in}, &wih));
+                for (int w = 0; w < NW; ++w)
+                    for (int g = 0; g < 4; ++g)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int r = g * H + w * 16 + (lane & 15), k = 8 * (lane >> 4) + j;
+                                const float v = k < in ? 128.f * wih[(size_t)r * in + k] : 0.f;
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const size_t slot = ((((size_t)dir * NW + w) * 4 + g) * 2) * 64 * 8;
+                                memcpy(&q16[slot + (size_t)lane * 8 + j], &h0, 2);
+                                memcpy(&q16[slot + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                            }
+            }
+            TRY(upload(m, &m->l1_wih16, fw16));
+        }
     }
     return 0;
 }
@@ -898,8 +920,8 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     if (starts && !fused1) return fail("region gathering needs the fused LSTM1 kernel (input_channels <= 20, C3HIP_LSTM1_FUSED != 0)");
     if (fused1) {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
-        LstmFusedParams<T> lp{x, starts, m->l1_wih, m->l1_bias, m->whh[0], m->h1, (int)n, Tn, m->C};
-        if (m->f16_ok && m->lstm1_f16 && m->whh16[0]) {
+        LstmFusedParams<T> lp{x, starts, m->l1_wih, m->l1_bias, m->whh[0], reinterpret_cast<const uint32_t *>(m->l1_wih16), m->h1, (int)n, Tn, m->C};
+        if (m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16)) {
             lp.whh = m->whh16[0];
             hipLaunchKernelGGL((lstm1_fused_kernel<T, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
         } else {
@@ -1378,7 +1400,7 @@ int c3_model_destroy(c3_model *m) {
     (void)hipDeviceSynchronize();
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
-                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_bias,
+                   m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias,
                    m->conv1_wfrag, m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3};
     for (float *p : ws)
         if (p) (void)hipFree(p);

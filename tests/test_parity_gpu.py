@@ -134,7 +134,11 @@ def test_int32_and_int8_pileup_inputs_agree():
     sd = syn.make_state_dict(syn.PILEUP, seed=41)
     m = make_model(syn.PILEUP, 18, False, sd)
     x8 = syn.make_pileup_windows(64, seed=42)
-    assert np.array_equal(m.predict_numpy(x8), m.predict_numpy(x8.astype(np.int32)))
+    y8, y32 = m.predict_numpy(x8), m.predict_numpy(x8.astype(np.int32))
+    # same counts, two input projections: int8 windows are exact in fp16 and take the fp16 matrix instructions, int32
+    # windows (no bound on the counts) stay on the fp32 ones -- equal up to the rounding of either
+    assert float(np.abs(y8 - y32).max()) < 2e-6
+    assert np.array_equal(y8.argmax(1), y32.argmax(1))
 
 
 def test_async_submit_wait_and_device_paths_agree():
