@@ -23,19 +23,36 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def stale():
+def source_hash():
+    """sha256 over every source and header the library is compiled from (+ the flags): c3_version() carries its first
+    12 hex digits, so a binary that does not correspond to the tree is detectable on any box (tests/test_abi.py)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
+def built_hash():
+    """the source hash embedded in the existing binary (None if there is none), read without loading the library"""
     if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+        return None
+    with open(LIB, "rb") as fh:
+        blob = fh.read()
+    i = blob.find(b"srchash:")
+    return blob[i + 8:i + 20].decode("ascii", "replace") if i >= 0 else None
+
+
+def stale():
+    return built_hash() != source_hash()
 
 
 def build(force=False, verbose=False, extra=()):
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    cmd = [hipcc()] + FLAGS + [f'-DC3HIP_SRC_HASH="{source_hash()}"'] + list(extra) + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

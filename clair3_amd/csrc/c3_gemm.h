@@ -578,7 +578,9 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             const int nb = n0 + wn * (BN / 2) + c * 32 + 4 * (lane >> 5);
-            const uint32_t off = m < gp.M ? (uint32_t)(((int64_t)m * ep.ldc + nb) * 4) : 0x80000000u;
+            // padding rows: an offset beyond every buffer this kernel writes (the LSTM2 projection's gx2 passes 2 GiB at 12710
+            // windows, so 0x80000000 would be IN range there), with room for the + 32 q below
+            const uint32_t off = m < gp.M ? (uint32_t)(((int64_t)m * ep.ldc + nb) * 4) : 0xffffff00u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {  // columns nb + 8q .. nb + 8q + 3
                 f32x4 val = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};

@@ -104,7 +104,10 @@ struct HostSlot {
     uint32_t *pin_flag = nullptr;  // pinned copy of the model's range_flag after this batch
     int x_dtype = 0;
     bool busy = false;
+    bool used_f16 = false;  // the batch in flight was computed by the fp16x3 kernels (c3_predict_wait then checks its range)
 };
+
+constexpr int kHostSlots = 4;  // batches in flight per handle through c3_predict_submit / _wait (C3_HOST_SLOTS)
 
 struct c3_model {
     int kind = 0, C = 0, add_indel = 0, device = 0;
@@ -150,6 +153,7 @@ struct c3_model {
     bool conv1_direct = true;       // 8-channel conv1 through conv1_i8_kernel (c3_conv1.h); env C3HIP_CONV1_DIRECT
     float *conv1_wfrag = nullptr;   // its resident B fragments [36][2][64]
     uint32_t *range_flag = nullptr; // device word set by the fp16x3 kernels when an activation nears the fp16 range (c3_gemm.h kF16Range)
+    uint32_t *pin_flag = nullptr;   // pinned copy of range_flag for c3_predict_device_checked
     bool f16_ok = true;             // cleared by c3_predict_wait when a batch came back non-finite: every layer then runs its fp32-MFMA form
     float *conv1_wfrag16 = nullptr; // conv1_i8_f16_kernel: [5][2][2 pieces][64][8 fp16]
     bool conv1_f16 = true;          // conv1 on fp16 matrix instructions (int8 inputs exact, weights as two pieces); env C3HIP_CONV1_F16
@@ -180,7 +184,7 @@ struct c3_model {
     int splits = 1;
     int64_t last_n = 0;  // windows of the last micro-batch (for debug fetch)
 
-    HostSlot slot[2];
+    HostSlot slot[kHostSlots];
 
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -317,6 +321,7 @@ static void free_workspace(c3_model *m) {
     for (auto &b : m->bufs) (void)hipFree(b.p);
     m->bufs.clear();
     m->cap = 0;
+    m->gx1 = nullptr;
 }
 
 static int64_t max_microbatch(const c3_model *m) { return m->kind == C3_KIND_PILEUP ? 16384 : 2048; }
@@ -345,7 +350,8 @@ static int ensure_workspace(c3_model *m, int64_t n) {
         TRY(dev_alloc(m, (void **)&m->spp, (size_t)n * m->K4 * sizeof(float)));
     } else {
         const int T = m->positions;
-        TRY(dev_alloc(m, (void **)&m->gx1, (size_t)n * T * 1024 * sizeof(float)));
+        if (!(m->lstm1_fused && m->l1_wih))  // the fused LSTM1 kernel never touches gx1 (2.2 GB at the 16384-window cap)
+            TRY(dev_alloc(m, (void **)&m->gx1, (size_t)n * T * 1024 * sizeof(float)));
         TRY(dev_alloc(m, (void **)&m->h1, (size_t)n * T * 256 * sizeof(float)));
         TRY(dev_alloc(m, (void **)&m->gx2, (size_t)n * T * 1280 * sizeof(float)));
         TRY(dev_alloc(m, (void **)&m->h2, (size_t)n * T * 320 * sizeof(float)));
@@ -1023,7 +1029,10 @@ static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
-const char *c3_version(void) { return "c3hip 0.2.0 (gfx950, fp32 data, fp16x3 split matrix products)"; }
+#ifndef C3HIP_SRC_HASH
+#define C3HIP_SRC_HASH "unknown"
+#endif
+const char *c3_version(void) { return "c3hip 0.3.0 (gfx950, fp32 data, fp16x3 split matrix products) srchash:" C3HIP_SRC_HASH; }
 const char *c3_last_error(void) { return g_err.c_str(); }
 
 int c3_device_count(void) {
@@ -1206,6 +1215,46 @@ int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch
     return forward_device(m, (hipStream_t)stream, x_dev, x_dtype, batch, y_dev);
 }
 
+// one thread per output float: raises the handle's range flag when a probability is not finite
+__global__ void rows_finite_kernel(const float *y, int64_t n, uint32_t *flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && (__float_as_uint(y[i]) & 0x7f800000u) == 0x7f800000u) atomicOr(flag, 2u);
+}
+
+int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, void *stream) {
+    if (!m) return fail("null model");
+    if (batch > 0 && (!x_dev || !y_dev)) return fail("null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const bool f16 = m->f16_ok;
+    TRY(forward_device(m, s, x_dev, x_dtype, batch, y_dev));
+    if (!f16 || batch == 0) return 0;
+    if (!m->pin_flag) HIP_TRY(hipHostMalloc((void **)&m->pin_flag, 64, hipHostMallocDefault));
+    const int64_t nf = batch * m->row;
+    hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, y_dev, nf, m->range_flag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(m->pin_flag, m->range_flag, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*m->pin_flag) {
+        fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
+        m->f16_ok = false;
+        TRY(forward_device(m, s, x_dev, x_dtype, batch, y_dev));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int c3_model_range_status(c3_model *m, int *flag_out, int *on_fp32_out) {
+    if (!m) return fail("null model");
+    HIP_TRY(hipSetDevice(m->device));
+    uint32_t f = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&f, m->range_flag, 4, hipMemcpyDeviceToHost));
+    if (flag_out) *flag_out = (int)f;
+    if (on_fp32_out) *on_fp32_out = m->f16_ok ? 0 : 1;
+    return 0;
+}
+
 static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     if (!sl.ev_h2d) {
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
@@ -1235,7 +1284,7 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
 
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
     if (!m) return fail("null model");
-    if (slot < 0 || slot > 1) return fail("slot must be 0 or 1");
+    if (slot < 0 || slot >= kHostSlots) return fail("slot must be in [0, %d)", kHostSlots);
     if (batch < 0) return fail("negative batch");
     if (batch > 0 && (!x_host || !y_host)) return fail("null buffer");
     HostSlot &sl = m->slot[slot];
@@ -1244,43 +1293,45 @@ int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batc
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
     const size_t yb = (size_t)batch * m->row * sizeof(float);
-    sl.y_host = y_host, sl.y_bytes = yb, sl.busy = true, sl.batch = batch, sl.x_dtype = x_dtype;
-    if (batch == 0) return 0;
-    TRY(ensure_slot(m, sl, xb, yb));
-    TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream));
-    HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
-    HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
-    int rc = forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y);
-    if (rc) {
-        sl.busy = false;
-        return rc;
+    if (batch > 0) {
+        // the slot becomes busy only once everything has been queued: a failure on the way leaves it free
+        TRY(ensure_slot(m, sl, xb, yb));
+        TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream));
+        HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
+        HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
+        const bool f16 = m->f16_ok;
+        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
+        HIP_TRY(hipEventRecord(sl.ev_compute, m->stream));
+        HIP_TRY(hipStreamWaitEvent(m->d2h_stream, sl.ev_compute, 0));
+        HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->d2h_stream));
+        HIP_TRY(hipMemcpyAsync(sl.pin_flag, m->range_flag, 4, hipMemcpyDeviceToHost, m->d2h_stream));
+        HIP_TRY(hipEventRecord(sl.ev_out, m->d2h_stream));
+        sl.used_f16 = f16;
     }
-    HIP_TRY(hipEventRecord(sl.ev_compute, m->stream));
-    HIP_TRY(hipStreamWaitEvent(m->d2h_stream, sl.ev_compute, 0));
-    HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->d2h_stream));
-    HIP_TRY(hipMemcpyAsync(sl.pin_flag, m->range_flag, 4, hipMemcpyDeviceToHost, m->d2h_stream));
-    HIP_TRY(hipEventRecord(sl.ev_out, m->d2h_stream));
+    sl.y_host = y_host, sl.y_bytes = yb, sl.batch = batch, sl.x_dtype = x_dtype, sl.busy = true;
     return 0;
 }
 
 int c3_predict_wait(c3_model *m, int slot) {
     if (!m) return fail("null model");
-    if (slot < 0 || slot > 1) return fail("slot must be 0 or 1");
+    if (slot < 0 || slot >= kHostSlots) return fail("slot must be in [0, %d)", kHostSlots);
     HostSlot &sl = m->slot[slot];
     if (!sl.busy) return fail("slot %d has nothing in flight", slot);
     sl.busy = false;
     if (sl.y_bytes == 0) return 0;
     HIP_TRY(hipEventSynchronize(sl.ev_out));
-    if (m->f16_ok) {
-        // Safety net of the fp16x3 products: an activation beyond the fp16 range (|x| >= 65504; never seen)
-        // would surface as inf / NaN rows.  Rows are probabilities, so any non-finite value means exactly that: switch
-        // every layer to its fp32-MFMA form for the rest of this handle's life and run the batch again.
+    if (sl.used_f16) {
+        // Safety net of the fp16x3 products, per batch: what matters is how THIS slot's rows were computed, not what the
+        // handle does now (another slot's wait may have switched it to fp32 while this batch was in flight).  An
+        // activation beyond the fp16 range (|x| >= 65504; never seen) surfaces as inf / NaN rows or as the
+        // range flag (sticky: an overflow in any earlier fp16x3 batch also lands here, which only costs a re-run).
         const uint32_t *u = reinterpret_cast<const uint32_t *>(sl.pin_y);
         bool bad = *sl.pin_flag != 0;  // a conv stage produced a value near the fp16 range (kF16Range): its consumers may have overflowed
         for (size_t i = 0, n = sl.y_bytes / 4; i < n; ++i) bad |= (u[i] & 0x7f800000u) == 0x7f800000u;
         if (bad) {
+            if (m->f16_ok)
+                fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
             m->f16_ok = false;
-            fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
             TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.dev_y));
             HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, sl.y_bytes, hipMemcpyDeviceToHost, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1340,7 +1391,6 @@ int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uin
     const size_t total = yb + rb + 2 * mb + rb;
     if (m->decode_bytes < total) {
         if (m->decode_dev) (void)hipFree(m->decode_dev);
-    if (m->range_flag) (void)hipFree(m->range_flag);
         m->decode_dev = nullptr, m->decode_bytes = 0;
         HIP_TRY(hipMalloc(&m->decode_dev, total));
         m->decode_bytes = total;
@@ -1405,6 +1455,8 @@ int c3_model_destroy(c3_model *m) {
     for (float *p : ws)
         if (p) (void)hipFree(p);
     if (m->decode_dev) (void)hipFree(m->decode_dev);
+    if (m->range_flag) (void)hipFree(m->range_flag);
+    if (m->pin_flag) (void)hipHostFree(m->pin_flag);
     for (int l = 0; l < 9; ++l) {
         if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);

@@ -105,6 +105,6 @@ def predict_sharded(model, x_all, dst=0):
     if world == 1:
         return model.predict_numpy(x)
     xd = torch.from_numpy(x).cuda()
-    yd = model(xd)
+    yd = model.forward(xd, checked=True)  # the range guard of the host path, on the device-resident entry
     out = gather_rows(yd, n, dst)
     return out.cpu().numpy() if out is not None else None

@@ -141,9 +141,12 @@ class _HipModel:
     def __call__(self, x):
         return self.forward(x)
 
-    def forward(self, x):
+    def forward(self, x, checked=False):
         """x: numpy (host) or torch tensor (host or cuda).  Returns the same container kind holding the
-        (B, 24|90) float32 probabilities (``predict=True`` layout of the reference, model.py:152-159)."""
+        (B, 24|90) float32 probabilities (``predict=True`` layout of the reference, model.py:152-159).
+        Host inputs always carry the fp16-range guard (c3_predict_wait); for a cuda tensor ``checked=True`` selects
+        c3_predict_device_checked (synchronises the stream), the default stays asynchronous and unchecked --
+        ``range_status()`` tells afterwards whether any batch raised the flag."""
         if self._handle is None:
             raise _lib.C3Error("model has no device/weights yet: call .to(device) and .load_state_dict() first")
         if not self.predict:
@@ -161,8 +164,9 @@ class _HipModel:
             self._check_shape(tuple(x.shape), dt)
             y = torch.empty((x.shape[0], self.row_size), dtype=torch.float32, device=x.device)
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            _lib.check(_lib.lib().c3_predict_device(self._handle, x.data_ptr(), dt, x.shape[0], y.data_ptr(),
-                                                    C.c_void_p(stream)), "c3_predict_device")
+            fn = _lib.lib().c3_predict_device_checked if checked else _lib.lib().c3_predict_device
+            _lib.check(fn(self._handle, x.data_ptr(), dt, x.shape[0], y.data_ptr(), C.c_void_p(stream)),
+                       "c3_predict_device_checked" if checked else "c3_predict_device")
             return y
         xn = x.numpy() if is_torch else np.asarray(x)
         y = self.predict_numpy(xn)
@@ -214,6 +218,14 @@ class _HipModel:
         slot, y = ticket
         _lib.check(_lib.lib().c3_predict_wait(self._handle, slot), "c3_predict_wait")
         return y
+
+    def range_status(self):
+        """(flag, on_fp32): flag != 0 when an fp16x3 batch of this handle produced an activation near the fp16 range
+        (or a non-finite row under the checked entry); on_fp32 when the handle has switched to fp32 matrix
+        instructions.  Synchronises the device."""
+        f, o = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().c3_model_range_status(self._handle, C.byref(f), C.byref(o)), "c3_model_range_status")
+        return f.value, bool(o.value)
 
     def synchronize(self):
         _lib.check(_lib.lib().c3_model_synchronize(self._handle), "c3_model_synchronize")

@@ -103,8 +103,10 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
 /* Note on the arithmetic: the contractions form their fp32 products from two fp16 pieces per operand (fp16x3, DESIGN.md 1:
  * fp32-level parity).  Should a checkpoint ever drive an activation towards the fp16 range (|x| >= 16000), c3_predict /
  * c3_predict_wait notice (a flag raised by the kernels, or a non-finite row), print one line to stderr, switch the handle
- * to the fp32 matrix instructions for the rest of its life and run the batch again; c3_predict_device does not check. */
-/* asynchronous pair, slot in {0,1}: submit copies x into pinned staging and enqueues H2D + kernels + D2H;
+ * to the fp32 matrix instructions for the rest of its life and run the batch again; c3_predict_device does not check
+ * (c3_predict_device_checked does; c3_model_range_status reports). */
+#define C3_HOST_SLOTS 4
+/* asynchronous pair, slot in [0, C3_HOST_SLOTS): submit copies x into pinned staging and enqueues H2D + kernels + D2H;
  * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);
 int c3_predict_wait(c3_model *m, int slot);
@@ -113,6 +115,15 @@ int c3_predict_wait(c3_model *m, int slot);
  * host; ordered like any other work on that stream.  Calls on one handle must not overlap each other (one
  * workspace per handle): keep several batches in flight with several handles. */
 int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, void *stream);
+/* The same forward with the range guard of c3_predict_wait (the device-resident entry a sharded job uses,
+ * clair3_amd/dist.py): after the kernels it scans the rows for non-finite values on the device, reads the range flag,
+ * and -- should either be raised -- switches the handle to the fp32 matrix instructions and runs the batch again.
+ * Synchronises `stream` before returning (that is the price of the check; c3_predict_device stays asynchronous). */
+int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, void *stream);
+/* For callers of the unchecked entry: *flag_out != 0 when any fp16x3 batch of this handle raised the range flag
+ * (bit 0: a convolution output reached 16000, bit 1: a non-finite row seen by the checked entry), *on_fp32_out != 0 when
+ * the handle has been switched to the fp32 matrix instructions.  Synchronises the device. */
+int c3_model_range_status(c3_model *m, int *flag_out, int *on_fp32_out);
 /* Pileup only: windows gathered on the device out of ONE region matrix instead of `batch` pre-sliced
  * copies.  region_host: (n_cols, C) int8|int32 counts exactly as calculate_clair3_pileup returns them for a region
  * (src/clair3_pileup.h:113; preprocess/CreateTensorPileupFromCffi.py:143-146); starts_host[b] = first column of window

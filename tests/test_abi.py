@@ -30,6 +30,14 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib_version()
 
 
+def test_binary_corresponds_to_the_tree():
+    """c3_version() embeds a hash of the sources it was compiled from: a stale libc3hip.so (they are git-ignored but
+    travel to the GPU box) cannot be tested against newer source unnoticed"""
+    from clair3_amd import build
+    assert build.built_hash() == build.source_hash(), "libc3hip.so is stale: python -m clair3_amd.build"
+    assert ("srchash:" + build.source_hash()).encode() in lib_version()
+
+
 def lib_version():
     return _lib.lib().c3_version()
 

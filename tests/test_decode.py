@@ -83,6 +83,12 @@ def test_kernel_matches_oracle_on_model_rows(indel):
     # the overall maximum sits in at least one class, and the kernel agrees with the oracle on which
     best = maxp.max(axis=1, keepdims=True)
     assert np.array_equal(maxp == best, o_maxp == o_maxp.max(axis=1, keepdims=True))
+    # the same handle keeps predicting after the decoder has grown its scratch buffer, twice (the growth
+    # path used to free the handle's range flag, which every fp16x3 epilogue writes)
+    assert np.array_equal(m.predict_numpy(x), y)
+    decode.outcome_maxima(m, np.concatenate([y, y]), ref + ref)
+    assert np.array_equal(m.predict_numpy(x), y)
+    assert m.range_status() == (0, False)
 
 
 @pytest.mark.gpu

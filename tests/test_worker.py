@@ -91,7 +91,13 @@ def test_async_file_pipeline_matches_sync_predict(tmp_path):
     rows = []
     n = worker.predict_file_list(m, lst, lambda p, a, y: rows.append(y), batch_size=64)
     assert n == 208
-    assert np.array_equal(np.concatenate(rows), m.predict_numpy(np.concatenate(xs)))
+    y = np.concatenate(rows)
+    # parity: the pipeline's rows against the CPU oracle on the same windows (not against the HIP path itself)
+    from oracle import oracle
+    from tests import util
+    err = util.assert_rows_match(y, oracle.fa_forward(sd, np.concatenate(xs), True), what="file pipeline vs oracle")
+    assert err < 2e-5
+    assert np.array_equal(y, m.predict_numpy(np.concatenate(xs)))  # and double buffering changes no bit
 
 
 def test_batches_equal_the_reference_generator(tmp_path):
