@@ -1,32 +1,40 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the MI355X-native Clair3 inference path (BASELINE.json metric:
-candidate-windows/sec, pileup + full-alignment).
+candidate-windows/sec, pileup + full-alignment; GT-call concordance vs the reference arithmetic).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (c3_predict_device: every kernel of the forward pass) over one batch of
-synthetic candidate windows already resident in HBM, plus -- for N > 1 -- the RCCL gather of the (B, 24|90)
-probability rows to rank 0.  One process per GPU, windows sharded with no data-path collective
-(weak scaling: every GPU gets the configured batch).  Rank 0 prints ONE JSON line:
+A "step" is one pass of the hot path over one batch of synthetic candidate windows.  One process per GPU, windows
+sharded with no data-path collective (weak scaling: every GPU gets the configured batch); for N > 1 the (B, 24|90)
+probability rows travel to rank 0 in one RCCL gather per GATHER_EVERY steps.  Rank 0 prints ONE JSON line:
 
-  value        whole-job candidate-windows/s of the headline workload = BASELINE.json configs[2]
-               "ONT r10.4.1 full-alignment model, synthetic (B=256, 89, 33, 8)" (the path the north-star target
-               is quoted on); the same measurement for configs[1] (pileup, B=1024) is in "pileup".  By default three
-               batches (pileup: two) are kept in flight per GPU (three model handles on three HIP streams, every step
-               still a complete forward over one full batch -- the reference runs several workers per GPU too);
-               "one_batch_in_flight" is the same K steps issued strictly one after the other;
-  roofline     dominant kernel family (implicit-GEMM 3x3 convolutions on v_mfma_f32_32x32x2_f32), HIP-event
-               timed per launch on the launch stream in a second, profiled pass over the same steps;
-               achieved = algorithmic FLOP (2*MACs of the reference layer shapes) / kernel time;
-  cpu_baseline the reference CPU path's arithmetic (oracle/torch_port.py: the same ATen operators the
-               reference modules call) timed on this node's host cores, rank 0, N=1 only, bounded sample.
+  value           whole-job candidate-windows/s of the headline workload = BASELINE.json configs[2] "ONT r10.4.1
+                  full-alignment model, synthetic (B=256, 89, 33, 8)", windows RESIDENT IN HBM when the timed region
+                  starts (the bench contract: c3_predict_device, every kernel of the forward pass).  The better of
+                  "one_batch_in_flight" (K steps strictly one after the other on one handle) and three handles on three
+                  HIP streams; both are reported;
+  host_inclusive  the SURVEY 8d metric: the same K steps through c3_predict_submit / c3_predict_wait from PAGEABLE numpy
+                  windows to probability rows landed in host memory (staging copy + H2D + kernels + D2H, one handle, a
+                  ring of three slots), at the configured batch and at the reference's GPU batch of 1000
+                  (clair3/CallVariantsFromCffi.py:265-269).  N = 1 only;
+  roofline        dominant kernel family, HIP-event timed per launch on the launch stream in a profiled pass over the
+                  same steps: achieved = ALGORITHMIC FLOP (2*MACs of the reference layer shapes) / kernel
+                  time; peak = the dense peak of the matrix instruction the family issues (2500 TFLOP/s for the 16-bit
+                  forms every contraction uses, 157.3 for the fp32 fallbacks); frac = achieved / peak; mfma_util = FLOP
+                  the matrix instructions EXECUTE (three fp16 piece products per fp32 product, tile padding) / time /
+                  peak; traffic / hbm_frac from the committed rocprofv3 PMC passes (profiles/pmc_traffic*.json);
+  cpu_baseline    the reference CPU path's arithmetic (oracle/torch_port.py: the ATen operators the reference modules
+                  call) on this node's host cores, rank 0, N = 1, bounded sample: (i) in-process at its best thread
+                  count, (ii) one thread (how the reference pipeline runs its workers) x visible cores;
+  gt_concordance  arg-max of the gt21 and zygosity heads of the GPU rows vs the CPU baseline's rows on the same batch.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,11 +42,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 WORKLOADS = {
-    # name: (kind, batch, channels, add_indel_length, FLOP/window, algorithmic bytes/window, BASELINE.json config)
+    # name: (kind, batch, channels, add_indel_length, FLOP/window, algorithmic bytes/window (SURVEY 8d), BASELINE.json config)
     "full_alignment": ("full_alignment", 256, 8, True, 451538432, 23856,
                        "configs[2]: ONT r10.4.1 full-alignment model, synthetic (B=256, 89, 33, 8) int8, 1xMI355X"),
     "pileup": ("pileup", 1024, 18, False, 47785984, 690,
@@ -46,6 +53,9 @@ WORKLOADS = {
     "full_alignment_dwell": ("full_alignment", 256, 9, True, 452419712, 26793,
                              "configs[4]: ONT --enable_dwell_time full-alignment, synthetic (B=256, 89, 33, 9) int8"),
 }
+TRAFFIC_FILE = {"full_alignment": "pmc_traffic.json", "pileup": "pmc_traffic_pileup.json"}
+HOST_SLOTS = 3
+GATHER_EVERY = 8  # steps per gather of probability rows to rank 0 (N > 1)
 
 
 def build_model(kind, channels, indel, device):
@@ -59,7 +69,25 @@ def build_model(kind, channels, indel, device):
     return m, sd
 
 
-GATHER_EVERY = 8  # steps per gather of probability rows to rank 0 (N > 1)
+def host_leg(model, x_host, steps, warmup):
+    """K steps host to host: pageable numpy windows -> rows in host memory, ring of HOST_SLOTS submits in flight on ONE
+    handle (c3_predict_submit / c3_predict_wait).  Returns (seconds, last rows)."""
+    tickets = []
+    y = None
+
+    def run(k):
+        nonlocal y
+        for i in range(k):
+            if len(tickets) == HOST_SLOTS:
+                y = model.wait(tickets.pop(0))
+            tickets.append(model.submit(x_host, slot=i % HOST_SLOTS))
+        while tickets:
+            y = model.wait(tickets.pop(0))
+
+    run(warmup)
+    t0 = time.perf_counter()
+    run(steps)
+    return time.perf_counter() - t0, y
 
 
 def run_workload(name, args, rank, world, local):
@@ -77,22 +105,17 @@ def run_workload(name, args, rank, world, local):
     n_total = batch * world
     # --streams S > 1: S model handles (own workspace each) on S HIP streams, steps issued round-robin -- a worker
     # that keeps S batches in flight, which is how the reference itself drives a GPU (free_MB // 8000 concurrent
-    # workers per device, clair3/CallVariantsFromCffiGPU.py:55-56).  Kernels that cannot fill 256 CUs on their own
-    # (the 33-step LSTM recurrences on 128 workgroups, the 12x5 stage, the FC tail) then overlap the next batch's
-    # large kernels.  Every step is still one complete forward pass over one full batch.
-    S = args.streams if args.streams > 0 else 3  # measured optimum for both workloads (2 / 3 / 4: FA 664 / 681 / 660 k, pileup 4.17 / 4.24 / 4.21 M)
+    # workers per device, clair3/CallVariantsFromCffiGPU.py:55-56).  Every step is still one complete forward pass.
+    S = args.streams if args.streams > 0 else 3
     models = [model] + [build_model(kind, channels, indel, local)[0] for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in models]
     # part of model set-up, like the weight upload: every handle sizes its device workspace on its first batch
-    # (hipMalloc) and torch's allocator opens a pool per stream -- neither belongs to a step, warm-up or timed
     model(x)
     for mi, st in zip(models, streams):
         with torch.cuda.stream(st):
             mi(x)
     torch.cuda.synchronize()
-    # ... and an idle MI355X needs ~20 ms of load before its clocks settle (measured: 20 timed steps read 361 k windows/s
-    # after 3 warm-up steps, 416 k after 30; 200 steps after 5: 417 k).  60 ms of the same forward passes, untimed, so
-    # that the W warm-up steps and the K timed steps see the device in the state a worker sees it in.
+    # an idle MI355X needs ~20 ms of load before its clocks settle: 60 ms of the same forward passes, untimed
     t_ramp = time.perf_counter() + 0.06
     while time.perf_counter() < t_ramp:
         for mi, st in zip(models, streams):
@@ -106,6 +129,8 @@ def run_workload(name, args, rank, world, local):
             dist.barrier()
             torch.cuda.synchronize()
 
+    last_rows = [None]
+
     def timed(n_streams):
         counter = [0]
 
@@ -117,6 +142,7 @@ def run_workload(name, args, rank, world, local):
             else:
                 with torch.cuda.stream(streams[i]):
                     y = models[i](x)
+            last_rows[0] = y
             if world > 1:
                 if n_streams > 1:
                     torch.cuda.current_stream(dev).wait_stream(streams[i])
@@ -124,11 +150,7 @@ def run_workload(name, args, rank, world, local):
                 return gatherer.add(y)
             return y
 
-        # N > 1: the rows of GATHER_EVERY steps travel to rank 0 in one collective ("one gather per
-        # super-batch"; a step is 0.4 ms of GPU work now and a collective costs the host ~0.1 ms); every timed row still
-        # reaches rank 0 inside the timed region -- the last partial group is flushed before the closing fence
         gatherer = c3dist.RowGatherer(n_total, every=GATHER_EVERY, dst=0)
-
         for _ in range(args.warmup):
             step()
         gatherer.flush()
@@ -153,18 +175,61 @@ def run_workload(name, args, rank, world, local):
 
     single = timed(1)
     multi = timed(S) if S > 1 else single
-    # Both passes time exactly K steps under the same fences; the headline is the better way of issuing them.  Keeping
-    # S batches in flight wins once K is a few dozen steps (it pays a fixed ~1.5 ms per timed region: DESIGN.md 5).
     elapsed, in_flight = (multi, S) if multi <= single else (single, 1)
+    # the device-resident entry is unchecked (asynchronous): the handles report afterwards whether any batch came near
+    # the range of the fp16x3 kernels
+    flags = [m.range_status() for m in models]
     res = {
         "workload": cfg, "batch_per_gpu": batch, "windows_per_step": n_total, "batches_in_flight": in_flight,
         "value": n_total * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
         "one_batch_in_flight": {"value": n_total * args.steps / single, "ms_per_step": 1e3 * single / args.steps},
         f"{S}_batches_in_flight": {"value": n_total * args.steps / multi, "ms_per_step": 1e3 * multi / args.steps},
         "flop_per_window": flop_w, "bytes_per_window": bytes_w,
+        "range_flag_raised": any(f for f, _ in flags), "on_fp32_fallback": any(o for _, o in flags),
+        "rows_rank0": last_rows[0].cpu().numpy() if rank == 0 else None,
     }
 
-    # ---- second, profiled pass: HIP events around every kernel launch on the launch stream ----
+    # ---- host-inclusive leg (H2D + kernels + D2H), N = 1 ----
+    if world == 1 and not args.no_host_leg:
+        hl = {"slots_in_flight": HOST_SLOTS, "handles": 1,
+              "path": "pageable numpy -> staging pool memcpy -> pinned -> H2D -> kernels -> D2H -> numpy (c3_predict_submit / _wait)"}
+        el, y = host_leg(model, x_host, args.steps, args.warmup)
+        assert y.shape == (batch, 90 if indel else 24) and np.isfinite(y).all()
+        hl.update({"value": batch * args.steps / el, "ms_per_step": 1e3 * el / args.steps, "batch": batch,
+                   "frac_of_device_resident_one_in_flight": (batch * args.steps / el) / res["one_batch_in_flight"]["value"]})
+        if not args.batch:
+            bref = 1000  # the reference's GPU batch (CallVariantsFromCffi.py:265-269: predictBatchSize * 5)
+            xb = syn.make_windows(kind, bref, seed=2000, channels=channels)
+            k = max(10, args.steps * batch // bref)
+            el, y = host_leg(model, xb, k, 3)
+            xd = torch.from_numpy(xb).to(dev)
+            for _ in range(3):
+                model(xd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                model(xd)
+            torch.cuda.synchronize()
+            el_dev = time.perf_counter() - t0
+            hl["batch_1000"] = {"value": bref * k / el, "ms_per_step": 1e3 * el / k, "steps": k,
+                                "device_resident_one_in_flight": bref * k / el_dev,
+                                "frac_of_device_resident": el_dev / el}
+            # zero-copy variant: the source buffer page-locked once (c3_host_register), no staging copy
+            try:
+                from clair3_amd import _lib
+                xr = np.array(xb, copy=True)
+                t0 = time.perf_counter()
+                _lib.host_register(xr)
+                t_reg = time.perf_counter() - t0
+                el, y = host_leg(model, xr, k, 3)
+                _lib.host_unregister(xr)
+                hl["batch_1000_registered_source"] = {"value": bref * k / el, "ms_per_step": 1e3 * el / k,
+                                                      "register_ms": 1e3 * t_reg, "bytes": int(xr.nbytes)}
+            except Exception as e:  # registration is an optional fast path; never fail the line on it
+                hl["batch_1000_registered_source"] = {"error": repr(e)}
+        res["host_inclusive"] = hl
+
+    # ---- profiled pass: HIP events around every kernel launch on the launch stream ----
     model.profile(True)
     model.profile_reset()
     for _ in range(args.steps):
@@ -173,51 +238,57 @@ def run_workload(name, args, rank, world, local):
     stats = model.profile_read()
     model.profile(False)
     res["kernels"] = {r["name"]: {"launches": r["launches"], "avg_us": 1e3 * r["total_ms"] / r["launches"],
-                                  "tflops": r["flops"] / r["total_ms"] / 1e9 if r["total_ms"] > 0 else None}
+                                  "tflops": r["flops"] / r["total_ms"] / 1e9 if r["total_ms"] > 0 else None,
+                                  "mfma_util": (r["mfma_flops"] / r["total_ms"] / 1e9 / r["mfma_peak_tflops"])
+                                  if r["total_ms"] > 0 and r["mfma_peak_tflops"] > 0 else None}
                       for r in stats}
     if kind == syn.FULL_ALIGNMENT:
-        dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res"))]
-        dom_name = ("3x3 convolution family: conv1_i8_kernel + gemm_mfma_kernel<ConvLoader> (stride-2 implicit GEMM) + "
-                    "wino_conv_kernel_p (persistent Winograd F(2x2,3x3) on the six stride-1 convs), 9 launches per step; fp16x3 split products except conv1")
+        dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res", "fa.stage"))]
+        dom_name = "3x3 convolution family of Clair3_F (conv1, three stride-2 convs, six residual-block convs): the launches named fa.conv* / fa.res* / fa.stage* in `kernels`"
     else:
-        dom = [r for r in stats if r["name"].startswith("p.lstm")]
-        dom_name = "lstm1_fused_kernel + lstm_recurrent_kernel_v2<160> (the two BiLSTM recurrences, 2 launches per step, fp16x3 split products on v_mfma_f32_16x16x32_f16)"
+        dom = [r for r in stats if r["name"].startswith(("p.lstm", "p.proj"))]
+        dom_name = "the two BiLSTM layers of Clair3_P (input projections + recurrences): the launches named p.lstm* / p.proj* in `kernels`"
     ms = sum(r["total_ms"] for r in dom)
     fl = sum(r["flops"] for r in dom)
+    mf = sum(r["mfma_flops"] for r in dom)
     launches = sum(r["launches"] for r in dom)
+    peak = max([r["mfma_peak_tflops"] for r in dom] + [0.0]) or 2500.0
     achieved = fl / ms / 1e9 if ms > 0 else 0.0
-    traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if kind == syn.FULL_ALIGNMENT else "pmc_traffic_pileup.json")
-    if os.path.exists(tpath) and channels != 9:
-        # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2
-        # + WRITE_SIZE, collected in their own runs by tools/gpu_round.sh `pmc`; bench.py cannot run rocprof on itself)
+    step_ms_profiled = sum(r["total_ms"] for r in stats) / max(args.steps, 1)
+    traffic, traffic_note, hbm_frac = None, None, None
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE.get(name, ""))
+    if name in TRAFFIC_FILE and os.path.exists(tpath) and not args.batch:
+        # HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in their own runs by
+        # tools/gpu_round.sh pmc / pmcp; bench.py cannot run rocprof on itself)
         with open(tpath) as fh:
             tj = json.load(fh)
         traffic = tj["hbm_bytes_per_launch"]
-        traffic_note = {"source": "profiles/pmc_traffic.json (%s)" % tj.get("tag", ""), "unit": "bytes per launch (PMC)",
-                        "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"]}
+        step_bytes = tj.get("hbm_bytes_per_step")
+        traffic_note = {"source": "profiles/%s (%s)" % (TRAFFIC_FILE[name], tj.get("tag", "")), "unit": "bytes per launch of the dominant family (PMC)",
+                        "hbm_bytes_per_step_all_kernels": step_bytes,
+                        "algorithmic_bytes_per_step": bytes_w * batch,
+                        "ratio_to_algorithmic": (step_bytes / (bytes_w * batch)) if step_bytes else None}
+        if step_bytes:
+            hbm_frac = step_bytes / (res["one_batch_in_flight"]["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
     res["roofline"] = {
-        "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note, "kernel": dom_name,
+        "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+        "mfma_util": (mf / ms / 1e9 / peak) if ms > 0 else None,
+        "traffic": traffic, "traffic_note": traffic_note, "hbm_frac": hbm_frac, "kernel": dom_name,
         "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
         "share_of_step_time": ms / max(sum(r["total_ms"] for r in stats), 1e-9),
-        "whole_forward_frac": res["value"] / world * flop_w / (FP32_MFMA_PEAK_TFLOPS * 1e12),
+        "step_us_sum_of_kernels": 1e3 * step_ms_profiled,
+        "whole_forward_frac": res["value"] / world * flop_w / (peak * 1e12),
+        "whole_forward_frac_one_in_flight": res["one_batch_in_flight"]["value"] / world * flop_w / (peak * 1e12),
+        "algorithmic_bytes_per_window": bytes_w,
         "hbm_algorithmic_gbs": res["value"] / world * bytes_w / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
+        "note": "achieved = ALGORITHMIC FLOP (direct 3x3 convolution / LSTM shapes of the reference, SURVEY 8d) / measured kernel time; "
+                "peak = dense peak of the matrix instruction in use (fp16 inputs, fp32 accumulate); every fp32 product is formed from "
+                "three fp16 piece products (fp16x3, DESIGN.md 1), so mfma_util ~ 3 x frac is what the matrix pipe actually executes",
     }
-    if kind == syn.FULL_ALIGNMENT:
-        res["roofline"]["note"] = ("achieved = ALGORITHMIC FLOP (direct 3x3 convolution, SURVEY 8d) / measured kernel time; peak = the "
-                                   "fp32-MFMA roof BASELINE.md prices this path against.  frac exceeds 1 because (a) the six stride-1 "
-                                   "layers run as Winograd F(2x2,3x3) (2.25x fewer multiplications) and (b) every contraction except "
-                                   "conv1 forms its fp32 products from two fp16 pieces per operand on v_mfma_f32_32x32x16_f16 (fp16x3: "
-                                   "h0w0 + h0w1 + h1w0, fp32 accumulation, fp32-level parity -- DESIGN.md 1; the 16-bit matrix roof is "
-                                   "2500 TFLOP/s, i.e. 833 per fp32-equivalent product).  C3HIP_* switches restore fp32 MFMAs per layer. "
-                                   "Matrix-pipe busy time per kernel: profiles/*_pmc_sq.md (SQ_VALU_MFMA_BUSY_CYCLES)")
-    res["roofline"]["fp16x3_roof_tflops"] = 2500.0 / 3.0
-    res["roofline"]["frac_of_fp16x3_roof"] = achieved / (2500.0 / 3.0)
     return res
 
 
-def cpu_worker(name, threads, budget_s, batch):
+def cpu_worker(name, threads, budget_s, batch, rows_path):
     """One clean process per thread count (OMP_NUM_THREADS is set by the parent): times the reference CPU
     arithmetic on the same synthetic batch and prints one JSON line."""
     import torch
@@ -228,53 +299,90 @@ def cpu_worker(name, threads, budget_s, batch):
     torch.set_num_threads(threads)
     sd = torch_port.to_torch(syn.make_state_dict(kind, channels, indel, seed=0))
     x = torch.from_numpy(syn.make_windows(kind, b, seed=1000, channels=channels))
+    if threads == 1:
+        x = x[: max(8, b // 8)]  # one thread: a bounded slice of the batch (rate per window is what is reported)
     kw = {"lstms": torch_port.make_lstms(sd)} if kind == "pileup" else {}
-    torch_port.forward(kind, sd, x[: max(1, b // 4)], indel, **kw)  # warm-up
+    torch_port.forward(kind, sd, x[: max(1, len(x) // 4)], indel, **kw)  # warm-up
     times = []
+    y = None
     t_start = time.perf_counter()
     while len(times) < 5 and (time.perf_counter() - t_start < budget_s or not times):
         t0 = time.perf_counter()
-        torch_port.forward(kind, sd, x, indel, **kw)
+        y = torch_port.forward(kind, sd, x, indel, **kw)
         times.append(time.perf_counter() - t0)
-    print(json.dumps({"threads": threads, "batch": b, "reps": len(times), "median_s": float(np.median(times)),
+    if rows_path and rows_path != "-":
+        np.save(rows_path, np.asarray(y, dtype=np.float32))
+    print(json.dumps({"threads": threads, "batch": int(len(x)), "reps": len(times), "median_s": float(np.median(times)),
                       "torch": torch.__version__}), flush=True)
 
 
-def cpu_baseline(name, budget_s, batch):
-    """Reference CPU arithmetic on this node's host cores (rank 0, N=1): bounded sample of the same workload.
-    oneDNN/OpenMP with one thread per visible core is far from the best setting on a 256-thread host, and
-    thread pools of different sizes disturb each other inside one process, so every candidate thread count
-    runs in its own subprocess; the fastest is reported -- the baseline should be the reference's CPU path
-    at its best, not a strawman."""
+def cpu_baseline(name, budget_s, batch, gpu_rows):
+    """Reference CPU arithmetic on this node's host cores (rank 0, N=1): bounded sample of the same workload, every
+    candidate thread count in its own process.  Reports (i) the in-process best and (ii) one thread x cores (how the
+    reference pipeline runs: `parallel -j` single-threaded workers, scripts/clair3_c_impl_pipeline.py:229-266)."""
     import subprocess
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    cands = sorted({t for t in (16, 32, 64, 128) if t <= cores} | ({cores} if cores < 16 else set()))
+    # a container may see every core of the host but own only a CPU-time quota (cgroup v2 cpu.max: "quota period")
+    quota = None
+    try:
+        q, per_us = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per_us))))
+    except Exception:
+        pass
+    usable = min(cores, quota) if quota else cores
+    cands = [1] + sorted({t for t in (16, 32, 64, 128) if t <= cores} | ({cores} if cores < 16 else set()))
     per = max(2.0, budget_s / len(cands))
     runs = []
+    rows_path = os.path.join(tempfile.gettempdir(), f"c3_bench_cpu_rows_{os.getpid()}_{name}.npy")
     for th in cands:
         env = dict(os.environ, OMP_NUM_THREADS=str(th), MKL_NUM_THREADS=str(th))
+        save = rows_path if th == cands[1 if len(cands) > 1 else 0] else "-"
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", name, str(th), str(per),
-                                str(batch)], env=env, capture_output=True, text=True, timeout=per * 6 + 180)
+                                str(batch), save], env=env, capture_output=True, text=True, timeout=per * 6 + 180)
             runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
         except Exception as e:  # a failed candidate must not kill the benchmark line
             print(f"[bench] cpu worker threads={th} failed: {e!r}", file=sys.stderr)
-        if len(runs) >= 2 and runs[-1]["median_s"] > 1.5 * min(r["median_s"] for r in runs):
+        multi = [r for r in runs if r["threads"] > 1]
+        if len(multi) >= 2 and multi[-1]["median_s"] > 1.5 * min(r["median_s"] for r in multi):
             break  # past the sweet spot: larger thread counts only get worse
     if not runs:
-        return None
-    best = min(runs, key=lambda r: r["median_s"])
-    return {"value": best["batch"] / best["median_s"], "unit": "candidate-windows/s", "cores": best["threads"],
-            "kind": "port",
-            "sample": f"{best['reps']} x one batch of {best['batch']} windows, median, own process; oracle/torch_port.py = "
-                      f"the ATen/oneDNN operators the reference modules call; threads = fastest of "
-                      f"{ {r['threads']: round(r['batch'] / r['median_s']) for r in runs} } windows/s on {cores} visible "
-                      f"cores; torch {best['torch']}",
-            "ms_per_batch": 1e3 * best["median_s"], "host_cores_visible": cores}
+        return None, None
+    rate = lambda r: r["batch"] / r["median_s"]
+    best = max(runs, key=rate)
+    one = next((r for r in runs if r["threads"] == 1), None)
+    out = {"value": rate(best), "unit": "candidate-windows/s", "cores": best["threads"], "kind": "port",
+           "sample": f"{best['reps']} x one batch of {best['batch']} windows, median, own process; oracle/torch_port.py = "
+                     f"the ATen/oneDNN operators the reference modules call; in-process rates by thread count "
+                     f"{ {r['threads']: round(rate(r)) for r in runs} } windows/s on {cores} visible cores; torch {best['torch']}",
+           "ms_per_batch": 1e3 * best["median_s"], "host_cores_visible": cores, "cpu_quota_cores": quota}
+    if one:
+        out["per_core"] = {"value": rate(one), "unit": "candidate-windows/s/core", "threads": 1,
+                           "sample": f"{one['reps']} x {one['batch']} windows, one thread"}
+        out["per_core_x_cores"] = {"value": rate(one) * usable, "cores": usable, "cpu_quota_cores": quota,
+                                   "note": "extrapolation: one-thread rate x usable cores = min(visible cores, cgroup cpu.max quota) -- "
+                                           "the pipeline-like mode (single-threaded workers side by side); an upper bound, memory "
+                                           "bandwidth and turbo make the real figure lower"}
+    conc = None
+    if gpu_rows is not None and os.path.exists(rows_path):
+        y_cpu = np.load(rows_path)
+        os.unlink(rows_path)
+        if y_cpu.shape == gpu_rows.shape:
+            heads = {"gt21": (0, 21), "zygosity": (21, 24)}
+            conc = {"windows": int(len(y_cpu)), "max_abs_dy": float(np.abs(y_cpu.astype(np.float64) - gpu_rows).max()),
+                    "vs": "cpu_baseline rows (oracle/torch_port.py, pinned to the reference's goldens at 2e-6) on the same batch"}
+            for k, (lo, hi) in heads.items():
+                a, b = gpu_rows[:, lo:hi].argmax(1), y_cpu[:, lo:hi].argmax(1)
+                top2 = np.sort(y_cpu[:, lo:hi], axis=1)[:, -2:]
+                diff = a != b
+                conc[k] = {"identical": int((~diff).sum()), "differ": int(diff.sum()),
+                           "differ_outside_near_ties_1e-5": int((diff & ((top2[:, 1] - top2[:, 0]) > 1e-5)).sum())}
+    return out, conc
 
 
 def main():
@@ -288,10 +396,12 @@ def main():
                     help="batches kept in flight per GPU (model handles x HIP streams); 0 = 3")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-worker", nargs=4, metavar=("WORKLOAD", "THREADS", "BUDGET", "BATCH"), help=argparse.SUPPRESS)
+    ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--cpu-worker", nargs=5, metavar=("WORKLOAD", "THREADS", "BUDGET", "BATCH", "ROWS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
-        cpu_worker(args.cpu_worker[0], int(args.cpu_worker[1]), float(args.cpu_worker[2]), int(args.cpu_worker[3]))
+        cpu_worker(args.cpu_worker[0], int(args.cpu_worker[1]), float(args.cpu_worker[2]), int(args.cpu_worker[3]),
+                   args.cpu_worker[4])
         return
 
     from clair3_amd import dist as c3dist
@@ -302,38 +412,45 @@ def main():
                   f"--nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
 
-    names = ["full_alignment", "pileup"] if args.workload == "all" else [args.workload]
+    names = ["full_alignment", "pileup", "full_alignment_dwell"] if args.workload == "all" else [args.workload]
     results = {n: run_workload(n, args, rank, world, local) for n in names}
     head = results[names[0]]
 
     if rank == 0:
+        def sub_line(n, r, budget):
+            rows = r.pop("rows_rank0", None)
+            sub = {"value": r["value"], "unit": "candidate-windows/s", "ms_per_step": r["ms_per_step"],
+                   "batches_in_flight": r["batches_in_flight"], "one_batch_in_flight": r["one_batch_in_flight"],
+                   **{k: v for k, v in r.items() if k.endswith("_batches_in_flight") and k != "one_batch_in_flight"},
+                   "config": {"workload": r["workload"], "batch_per_gpu": r["batch_per_gpu"]},
+                   "range_flag_raised": r["range_flag_raised"], "on_fp32_fallback": r["on_fp32_fallback"],
+                   "roofline": r["roofline"], "kernels": r["kernels"]}
+            if "host_inclusive" in r:
+                sub["host_inclusive"] = r["host_inclusive"]
+            if world == 1 and not args.no_cpu_baseline and budget > 0:
+                sub["cpu_baseline"], sub["gt_concordance"] = cpu_baseline(n, budget, args.batch, rows)
+                if sub["cpu_baseline"]:
+                    sub["speedup_vs_cpu_baseline"] = {
+                        "device_resident_vs_in_process_best": r["value"] / sub["cpu_baseline"]["value"],
+                        "host_inclusive_vs_in_process_best": (r["host_inclusive"]["value"] / sub["cpu_baseline"]["value"]) if "host_inclusive" in r else None,
+                        "device_resident_vs_per_core_x_cores": (r["value"] / sub["cpu_baseline"]["per_core_x_cores"]["value"]) if "per_core_x_cores" in sub["cpu_baseline"] else None,
+                    }
+            return sub
+
+        h = sub_line(names[0], head, args.cpu_budget)
         line = {
-            "metric": "candidate-windows/sec", "value": head["value"], "unit": "candidate-windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 storage, accumulation and results; products formed from two fp16 pieces per operand (fp16x3 split MFMA, DESIGN.md 1)",
+            "metric": "candidate-windows/sec", "value": h["value"], "unit": "candidate-windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32(fp16x3)", "data": "synthetic",
+            "dtype_note": "fp32 storage, accumulation and results; every fp32 product formed from two fp16 pieces per operand (three 16-bit MFMA products, DESIGN.md 1)",
             "config": {"workload": head["workload"], "batch_per_gpu": head["batch_per_gpu"],
                        "windows_per_step": head["windows_per_step"], "weights": "seeded random (no checkpoints offline)",
                        "sharding": f"windows x{world}, rows gathered to rank 0 every {GATHER_EVERY} steps (one RCCL gather)" if world > 1 else "single GPU",
-                       "inputs": "resident in HBM before the timed region", "batches_in_flight": head["batches_in_flight"]},
-            "one_batch_in_flight": head["one_batch_in_flight"],
-            **{k: v for k, v in head.items() if k.endswith("_batches_in_flight")},
-            "roofline": head["roofline"], "kernels": head["kernels"],
+                       "inputs": "resident in HBM before the timed region (host-to-host rate: host_inclusive)", "batches_in_flight": head["batches_in_flight"]},
+            **{k: v for k, v in h.items() if k not in ("value", "unit", "ms_per_step", "config", "batches_in_flight")},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(names[0], args.cpu_budget, args.batch)
-            if line["cpu_baseline"]:
-                line["speedup_vs_cpu_baseline"] = head["value"] / line["cpu_baseline"]["value"]
         for n in names[1:]:
-            r = results[n]
-            sub = {"value": r["value"], "unit": "candidate-windows/s", "ms_per_step": r["ms_per_step"],
-                   "batches_in_flight": r["batches_in_flight"], "one_batch_in_flight": r["one_batch_in_flight"],
-                   **{k: v for k, v in r.items() if k.endswith("_batches_in_flight")},
-                   "config": {"workload": r["workload"], "batch_per_gpu": r["batch_per_gpu"]},
-                   "roofline": r["roofline"], "kernels": r["kernels"]}
-            if world == 1 and not args.no_cpu_baseline:
-                sub["cpu_baseline"] = cpu_baseline(n, args.cpu_budget / 2, args.batch)
-            line[n] = sub
+            line[n] = sub_line(n, results[n], args.cpu_budget / 2 if n == "pileup" else 0)
         print(json.dumps(line), flush=True)
 
     if world > 1:

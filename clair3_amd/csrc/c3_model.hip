@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,7 @@
 #include "c3_proj.h"
 #include "c3_decode.h"
 #include "c3_lstm_fused.h"
+#include "c3_host.h"
 
 using namespace c3;
 
@@ -51,15 +53,32 @@ static int fail(const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------ host staging
 // The caller's windows are pageable numpy memory (clair3/CallVariantsFromCffi.py:112-133: np.load slices); they go
 // through a pinned buffer, cut into pieces: the H2D transfer of a piece is queued as soon as it is staged, so the DMA of
-// piece i runs under the memcpy of piece i + 1 (full alignment, 1000 windows = 23.5 MB per call: 294 k -> 321 k
-// windows/s through c3_predict).  Splitting the memcpy itself over threads was measured and gave nothing on top.
+// piece i runs under the memcpy of piece i + 1, and every piece's memcpy is split over the staging pool (c3_host.h).
+// Buffers the caller has registered (c3_host_register: page-locked for the device) skip the staging copy altogether.
+struct HostRange {
+    const char *p;
+    size_t n;
+};
+static std::vector<HostRange> g_registered;
+static std::mutex g_registered_mu;
+static bool is_registered(const void *p, size_t n) {
+    std::lock_guard<std::mutex> lk(g_registered_mu);
+    for (const HostRange &r : g_registered)
+        if ((const char *)p >= r.p && (const char *)p + n <= r.p + r.n) return true;
+    return false;
+}
+
 // stage [src, src + bytes) through `pin` into `dev` on stream s, piecewise
 static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s) {
+    if (is_registered(src, bytes)) {  // zero-copy: the DMA engine reads the caller's pages
+        HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, s));
+        return 0;
+    }
     // >= 4 MiB and at most four pieces: every queued transfer costs ~15 us of host time (2 MiB x 8 was slower again)
     const size_t piece = std::max<size_t>((size_t)4 << 20, ((bytes / 4) + 4095) & ~(size_t)4095);
     for (size_t off = 0; off < bytes; off += piece) {
         const size_t n = std::min(piece, bytes - off);
-        memcpy((char *)pin + off, (const char *)src + off, n);
+        StagePool::get().copy((char *)pin + off, (const char *)src + off, n);
         HIP_TRY(hipMemcpyAsync((char *)dev + off, (char *)pin + off, n, hipMemcpyHostToDevice, s));
     }
     return 0;
@@ -89,6 +108,8 @@ struct ProfRec {
     std::string name;
     hipEvent_t a, b;
     double flops, bytes;
+    double mfma_flops = 0.0;  // FLOP the matrix instructions of the launch EXECUTE (tile padding, piece products, Winograd reduction included)
+    double mfma_peak = 0.0;   // dense peak (TFLOP/s) of the matrix instruction the launch issues: 2500 (16-bit) or 157.3 (fp32)
 };
 
 struct HostSlot {
@@ -198,6 +219,8 @@ static void fa_geometry(const c3_model *m, int hh[10], int ww[10]) {
 }
 
 // ------------------------------------------------------------------------------------------ profiling scope
+// dense MFMA peaks of MI355X (MI355X_MICROARCH.md): v_mfma_f32_32x32x16_f16 / 16x16x32_f16 and the fp32-input forms
+static constexpr double kPeakF16 = 2500.0, kPeakF32 = 157.3;
 struct ProfScope {
     c3_model *m;
     hipStream_t s;
@@ -210,6 +233,8 @@ struct ProfScope {
         (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, s);
     }
+    // executed matrix work of the launch and the roof of the instruction it uses (c3_kernel_stat.mfma_flops / mfma_peak_tflops)
+    void mfma(double flops, bool f16) { r.mfma_flops = flops, r.mfma_peak = f16 ? kPeakF16 : kPeakF32; }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(r.b, s);
@@ -746,7 +771,9 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         ProfScope ps(m, s, tag_l4, 2.0 * n * FC * K4, 4.0 * (n * K4 + (double)FC * K4 + (double)S * n * FC));
         DenseLoaderParams lp{a, lda};
         EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
-        if (m->f16_ok && m->l4_split && m->l4_w3 && m->tail_mfma && m->w5f)  // (the scalar tail sums the partials itself and knows no scale)
+        const bool l4_f16 = m->f16_ok && m->l4_split && m->l4_w3 && m->tail_mfma && m->w5f;
+        ps.mfma(2.0 * ((n + 127) / 128 * 128) * FC * K4 * (l4_f16 ? (m->split_kind == 1 ? 6 : 3) : 1), l4_f16);
+        if (l4_f16)  // (the scalar tail sums the partials itself and knows no scale)
             TRY(LAUNCH_SPLIT(m, DenseLoader<4>, EPI_PARTIAL, 128, 64, s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w3));  // partials carry l4_wscale
         else
             TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
@@ -754,6 +781,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
     const double fl = 2.0 * n * (FC * 128.0 * m->nb + 128.0 * m->nout);
     if (m->tail_mfma && m->w5f) {
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
+        ps.mfma(2.0 * ((n + 15) / 16 * 16) * m->nb * (FC * 128.0 + 128.0 * 48.0), false);
         ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
         if (m->f16_ok && m->l4_split && m->l4_w3) rp.pre = m->l4_wscale, rp.post = 1.f / m->l4_wscale;  // same condition as the launch above (tail_mfma holds here)
         hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
@@ -807,7 +835,9 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             if ((m->wino_p_mask & (1u << l)) && Cout % 64 == 0) {  // persistent 32 x 64 workgroups
                 wp.tiles_n = Cout / 64, wp.tiles = ((wp.P + 31) / 32) * wp.tiles_n;
                 const int grid = std::min(wp.tiles, m->wg_slots / wp.tiles_n * wp.tiles_n);
-                if (m->f16_ok && m->wino_v16[l] && (m->wino_f16_mask & (1u << l))) {
+                const bool wf16 = m->f16_ok && m->wino_v16[l] && (m->wino_f16_mask & (1u << l));
+                ps.mfma(2.0 * ((wp.P + 31) / 32 * 32) * 16.0 * cin * Cout * (wf16 ? 3 : 1), wf16);
+                if (wf16) {
                     wp.v = m->wino_v16[l], wp.post_scale = 1.f / m->wino_wscale[l], wp.range_flag = m->range_flag;
                     if (wp.res)
                         hipLaunchKernelGGL((wino_conv_kernel_p<true, 0, 0, true>), dim3(grid), dim3(256), 0, s, wp);
@@ -831,6 +861,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             }
             HIP_TRY(hipGetLastError());
         } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_f16 && m->conv1_wfrag16 && m->f16_ok) {
+            ps.mfma(2.0 * ((M + 31) / 32 * 32) * 64.0 * 80.0 * 2, true);  // 5 k-steps of 16, two weight pieces
             Conv1F16Params cp;
             cp.x = x, cp.wfrag = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.bias = m->conv_b[0], cp.out = m->act[0];
             cp.range_flag = m->range_flag;
@@ -839,6 +870,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             hipLaunchKernelGGL(conv1_i8_f16_kernel, dim3(grid), dim3(256), 0, s, cp);
             HIP_TRY(hipGetLastError());
         } else if (l == 0 && cin == 8 && m->conv1_direct && m->conv1_wfrag) {
+            ps.mfma(2.0 * ((M + 31) / 32 * 32) * 64.0 * 72.0, false);
             Conv1Params cp;
             cp.x = x, cp.wfrag = m->conv1_wfrag, cp.bias = m->conv_b[0], cp.out = m->act[0];
             cp.B = (int)n, cp.H = hh[0], cp.W = ww[0], cp.OH = hh[1], cp.OW = ww[1], cp.M = M, cp.groups = (M + 31) / 32;
@@ -847,7 +879,9 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             HIP_TRY(hipGetLastError());
         } else if (l == 0) {
             Conv1LoaderParams lp{x, (const int8_t *)m->zeros, hh[0], ww[0], cin, hh[1], ww[1]};
-            if (m->f16_ok && m->conv1_f16 && m->conv_w3[0]) {
+            const bool c1f16 = m->f16_ok && m->conv1_f16 && m->conv_w3[0];
+            ps.mfma(2.0 * ((M + 127) / 128 * 128) * 64.0 * 96.0 * (c1f16 ? (m->split_kind == 1 ? 6 : 3) : 1), c1f16);
+            if (c1f16) {
                 ep.post_scale = 1.f / m->conv_wscale[0], ep.range_flag = m->range_flag;
                 TRY(LAUNCH_SPLIT(m, Conv1Loader<4>, EPI_BIAS_RELU, 128, 64, s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep, m->conv_w3[0]));
             } else {
@@ -858,7 +892,9 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
             const int nk = 9 * cin / kBK;
             const int64_t ldb = 9 * cin;
             const bool res = l % 3 == 2;
-            if (m->f16_ok && !res && m->conv_w3[l] && (m->conv_split_mask & (1u << l))) {
+            const bool cf16 = m->f16_ok && !res && m->conv_w3[l] && (m->conv_split_mask & (1u << l));
+            ps.mfma(2.0 * ((M + 127) / 128 * 128) * (double)Cout * 9.0 * cin * (cf16 ? (m->split_kind == 1 ? 6 : 3) : 1), cf16);
+            if (cf16) {
                 ep.post_scale = 1.f / m->conv_wscale[l], ep.range_flag = m->range_flag;
                 // fp16x3 keeps the fp32 kernel's LDS footprint, so conv3 (N = 128) can use 128x128 tiles at two workgroups
                 // per CU (43 -> 38 us); conv5 stays on 128x64 (480 workgroups), bf16x6 needs 72 KB per 128x64 tile
@@ -926,6 +962,12 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     if (starts && !fused1) return fail("region gathering needs the fused LSTM1 kernel (input_channels <= 20, C3HIP_LSTM1_FUSED != 0)");
     if (fused1) {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
+        {
+            const bool f16 = m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16);
+            const double tiles = (double)((n + 15) / 16 * 16) * Tn * 2;  // (window, step, direction) rows of the 16-window tiles
+            // recurrent part 512 x 128 as fp16x3 (or fp32); input part: int8 windows 512 x 32 against two weight pieces, else 512 x 20 fp32
+            ps.mfma(f16 ? tiles * 2.0 * 512 * (128 * 3 + (sizeof(T) == 1 ? 32 * 2 : 0)) : tiles * 2.0 * 512 * (128 + 20), f16);
+        }
         LstmFusedParams<T> lp{x, starts, m->l1_wih, m->l1_bias, m->whh[0], reinterpret_cast<const uint32_t *>(m->l1_wih16), m->h1, (int)n, Tn, m->C};
         if (m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16)) {
             lp.whh = m->whh16[0];
@@ -949,7 +991,9 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.proj2", 2.0 * M * 1280.0 * 256.0, 4.0 * M * (256.0 + 1280.0));
-        if (m->f16_ok && m->proj2_split && m->proj2_w3 && m->lstm2_v2) {
+        const bool p2f16 = m->f16_ok && m->proj2_split && m->proj2_w3 && m->lstm2_v2;
+        ps.mfma(2.0 * ((M + 127) / 128 * 128) * 1280.0 * 256.0 * (p2f16 ? (m->split_kind == 1 ? 6 : 3) : 1), p2f16);
+        if (p2f16) {
             DenseLoaderParams lp{m->h1, 256};
             EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
             ep.post_scale = 1.f / m->proj2_wscale;
@@ -982,6 +1026,10 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
+        {
+            const bool f16 = m->lstm2_v2 && m->f16_ok && m->lstm2_f16 && m->whh16[1];
+            ps.mfma((double)((n + 15) / 16 * 16) * Tn * 2 * 2.0 * 640 * 160 * (f16 ? 3 : 1), f16);
+        }
         if (m->lstm2_v2) {
             Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
             if (m->f16_ok && m->lstm2_f16 && m->whh16[1]) {
@@ -1438,6 +1486,30 @@ int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *ro
     return 0;
 }
 
+int c3_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return fail("null buffer");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lk(g_registered_mu);
+    g_registered.push_back({(const char *)p, bytes});
+    return 0;
+}
+
+int c3_host_unregister(void *p) {
+    {
+        std::lock_guard<std::mutex> lk(g_registered_mu);
+        bool found = false;
+        for (size_t i = 0; i < g_registered.size(); ++i)
+            if (g_registered[i].p == (const char *)p) {
+                g_registered.erase(g_registered.begin() + i);
+                found = true;
+                break;
+            }
+        if (!found) return fail("buffer was not registered with c3_host_register");
+    }
+    HIP_TRY(hipHostUnregister(p));
+    return 0;
+}
+
 int c3_model_synchronize(c3_model *m) {
     if (!m) return fail("null model");
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1572,6 +1644,8 @@ int c3_profile_read(c3_model *m, c3_kernel_stat *out, int max_entries) {
         it->second.total_ms += ms;
         it->second.flops += r.flops;
         it->second.bytes += r.bytes;
+        it->second.mfma_flops += r.mfma_flops;
+        it->second.mfma_peak_tflops = std::max(it->second.mfma_peak_tflops, r.mfma_peak);
     }
     int n = 0;
     for (auto &k : order) {

@@ -254,7 +254,8 @@ class _HipModel:
         if n < 0:
             raise _lib.C3Error(f"c3_profile_read: {_lib.last_error()}")
         return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms,
-                     flops=buf[i].flops, bytes=buf[i].bytes) for i in range(min(n, 64))]
+                     flops=buf[i].flops, bytes=buf[i].bytes, mfma_flops=buf[i].mfma_flops,
+                     mfma_peak_tflops=buf[i].mfma_peak_tflops) for i in range(min(n, 64))]
 
     def _destroy(self):
         if self._handle is not None:

@@ -110,6 +110,13 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
  * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);
 int c3_predict_wait(c3_model *m, int slot);
+/* Optional zero-copy input: page-lock a host range the caller will feed windows from -- a whole np.load'ed
+ * tensor file, or libclair3's fa_data.matrix buffer (preprocess/CreateTensorFullAlignmentFromCffi.py:136-168) -- so that
+ * c3_predict / c3_predict_submit on any sub-range of it DMA straight from the caller's pages instead of staging through the
+ * library's pinned buffer.  A registered source must stay unmodified until the matching c3_predict_wait returns (an
+ * unregistered one may be reused as soon as submit returns).  Unregister before freeing the memory. */
+int c3_host_register(void *host_ptr, size_t bytes);
+int c3_host_unregister(void *host_ptr);
 /* device-resident forward: x_dev / y_dev are device pointers on the model's device, stream is a
  * hipStream_t (NULL = the HIP null stream, i.e. PyTorch's default stream).  Asynchronous with respect to the
  * host; ordered like any other work on that stream.  Calls on one handle must not overlap each other (one
@@ -174,6 +181,8 @@ typedef struct {
     double total_ms;
     double flops; /* summed over the recorded launches */
     double bytes; /* algorithmic bytes moved (inputs+outputs+weights once per launch) */
+    double mfma_flops;       /* FLOP the matrix instructions EXECUTED (tile padding, fp16x3 piece products, Winograd reduction) */
+    double mfma_peak_tflops; /* dense peak of the matrix instruction the family issues: 2500 (16-bit inputs) or 157.3 (fp32 inputs); 0 = no matrix work */
 } c3_kernel_stat;
 int c3_profile_read(c3_model *m, c3_kernel_stat *out, int max_entries);
 

@@ -91,6 +91,12 @@ print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), '
     diagfa) timeout 600 python tests/diag/gpu_diag.py fa fa9 > gpurun_out/diag.txt 2>&1; echo "diag rc=$?" ;;
     counters) rocprofv3 -L > gpurun_out/counters.txt 2>&1; echo "counters rc=$?"; wc -l gpurun_out/counters.txt ;;
     pmcsq) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_sq" -o c3 -- python "$OLDPWD/bench.py" --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OLDPWD/gpurun_out/pmc_sq.err"); echo "pmc sq rc=$?" ;;
+    hostsweep) for th in 0 1 3 7; do echo "== C3HIP_STAGE_THREADS=$th"; C3HIP_STAGE_THREADS=$th timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --steps 100 2> gpurun_out/hostsweep.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+h=d['host_inclusive']
+print('  device one-in-flight %.0f | host B=256 %.0f (%.2f) | host B=1000 %.0f of %.0f (%.2f) | registered %s' % (d['one_batch_in_flight']['value'], h['value'], h['frac_of_device_resident_one_in_flight'], h['batch_1000']['value'], h['batch_1000']['device_resident_one_in_flight'], h['batch_1000']['frac_of_device_resident'], h.get('batch_1000_registered_source')))
+"; done ;;
     info)  (rocminfo | grep -E "Name|Compute Unit|Max Clock|Wavefront" | head -40; lscpu | head -20; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null) > gpurun_out/info.txt 2>&1 ;;
   esac
 done
