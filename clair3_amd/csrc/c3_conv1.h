@@ -159,6 +159,9 @@ struct Conv1F16Params {
     int B, H, W, OH, OW, M, groups;
 };
 
+// PLANES: the output leaves as plane activations (c3_conv3.h).  The two matrix operands swap places, so the accumulators
+// hold the block transposed -- lane = pixel, four consecutive channels per v >> 2.
+template <bool PLANES = false>
 __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
     for (int cb = 0; cb < 2; ++cb) {
         const float b = p.bias[32 * cb + m];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) biasv[cb][v] = b;
+        for (int v = 0; v < 16; ++v) biasv[cb][v] = PLANES ? p.bias[32 * cb + (v & 3) + 8 * (v >> 2) + 4 * kh] : b;
     }
     // this lane's tap of every k-step: (ky, kx) and its byte offset from the (shifted) pixel base
     int ky[5], kx[5];
@@ -223,7 +226,39 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
         return o;
     };
     int omax_i = 0;
+    // PLANES: the 32 x 64 block of the previous group goes through a wave-private LDS tile in its final byte order
+    // ([pixel][hi 64 x fp16 | lo 64 x fp16], rows 272 B apart), written as 8-byte pieces by the lanes that own them
+    // (slots 0, 2, .., 14: group 4 cb + q = channels 32 cb + 8 q + 4 kh .. + 3 of pixel m) and read back as 16-byte pieces
+    // that leave in ONE contiguous kilobyte per store instruction (slots 24..31) -- strided 8-byte stores cost 9 us per
+    // 50 MB here.  Same wave, program order: no barrier, the compiler's lgkmcnt waits order write -> read -> next write.
+    __shared__ __attribute__((aligned(16))) char st_all[PLANES ? 4 * 32 * 272 : 16];
+    char *const st = st_all + (PLANES ? wave * 32 * 272 : 0);
+    auto store_group = [&](const f32x16 (&r)[2], int idx) __attribute__((always_inline)) {
+        const int cb = idx >> 2, q = idx & 3;
+        f32x4 val;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int relu = max(__float_as_int(r[cb][4 * q + e]), 0);
+            omax_i = max(omax_i, relu);
+            val[e] = __int_as_float(relu);
+        }
+        u32x2 pc[2];
+        split2_f16(val, pc);
+        char *dst = st + m * 272 + (32 * cb + 8 * q + 4 * kh) * 2;
+        *reinterpret_cast<u32x2 *>(dst) = pc[0];
+        *reinterpret_cast<u32x2 *>(dst + 128) = pc[1];
+    };
+    auto store_piece = [&](uint32_t o0, int j) __attribute__((always_inline)) {
+        const int idx = lane + 64 * j;  // piece idx & 15 of pixel idx >> 4
+        const c1_u32x4 d = *reinterpret_cast<const c1_u32x4 *>(st + (idx >> 4) * 272 + (idx & 15) * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(d, orsrc, o0 + (uint32_t)(idx * 16), 0, 0);
+    };
     auto store_one = [&](const f32x16 (&r)[2], uint32_t o0, int idx) __attribute__((always_inline)) {
+        if constexpr (PLANES) {
+            if (idx < 16 && (idx & 1) == 0) store_group(r, idx >> 1);
+            if (idx >= 24) store_piece(o0, idx - 24);
+            return;
+        }
         const int cb = idx >> 4, v = idx & 15;
         const uint32_t off = o0 + (uint32_t)(((v & 3) + 8 * (v >> 2)) * 256 + cb * 128);
         const float val = r[cb][v];
@@ -243,8 +278,13 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 f32x16 c = t == 0 ? biasv[cb] : acc[cb];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, a[t]), __builtin_bit_cast(c1_f16x8, wf[t][cb][1]), c, 0, 0, 0);
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, a[t]), __builtin_bit_cast(c1_f16x8, wf[t][cb][0]), c, 0, 0, 0);
+                if constexpr (PLANES) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, wf[t][cb][1]), __builtin_bit_cast(c1_f16x8, a[t]), c, 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, wf[t][cb][0]), __builtin_bit_cast(c1_f16x8, a[t]), c, 0, 0, 0);
+                } else {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, a[t]), __builtin_bit_cast(c1_f16x8, wf[t][cb][1]), c, 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, a[t]), __builtin_bit_cast(c1_f16x8, wf[t][cb][0]), c, 0, 0, 0);
+                }
                 // the previous group's 32 stores, spread over this group's 20 matrix instructions
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -256,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto out_base = [&](int g) { return (uint32_t)((g * 32 + 4 * kh) * 256 + m * 4); };
+    auto out_base = [&](int g) { return PLANES ? (uint32_t)(g * 32 * 256) : (uint32_t)((g * 32 + 4 * kh) * 256 + m * 4); };
     f32x16 accA[2], accB[2] = {};  // accB is the first group's (dropped) "previous" result: defined, so that the range check sees zeros
     uint32_t prev_o0 = 0x80000000u;
     int g = gw;

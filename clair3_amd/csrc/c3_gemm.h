@@ -33,6 +33,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int st_u32x2 __attribute__((__vector_size__(8)));  // the data operand type of __builtin_amdgcn_raw_buffer_store_b64
 
 // SPLIT mode (bf16x6): an fp32 value is the exact sum of three bf16 pieces x = x0 + x1 + x2 (8 mantissa bits each);
 // x*w is formed from the six piece products x0w0, x0w1, x1w0, x0w2, x1w1, x2w0 on v_mfma_f32_32x32x16_bf16 (products
@@ -152,6 +153,66 @@ struct ConvLoader {
     __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {
 #pragma unroll
         for (int i = 0; i < R; ++i) out[i] = raw[i];
+    }
+};
+
+// The same gather over PLANE activations (c3_conv3.h: per pixel C/64 slabs of [hi 64 x fp16][lo 64 x fp16]): a thread's
+// four channels are 8 bytes of the hi plane and 8 bytes of the lo plane -- already the two fp16 pieces the SPLIT = 2 staging
+// writes to LDS, so there is no split work at all (kPlanes: stage() stores the raw pieces).  Cin % 64 == 0.
+struct PlaneConvLoaderParams {
+    const void *x;
+    const void *zeros;  // >= 256 readable zero bytes
+    int Hin, Win, Cin, Ho, Wo, stride;
+    int chunks_per_tap;  // Cin / 32
+};
+template <int R>
+struct PlaneConvLoader {
+    typedef PlaneConvLoaderParams Params;
+    static constexpr bool kPlanes = true;
+    struct Raw {
+        u32x2 hi, lo;
+    };
+    const char *x, *zeros;
+    int64_t off[R];  // byte offset of pixel (b, ih0, iw0) + this thread's 4 channels inside a half slab
+    uint32_t mask[R];
+    int Win, pixb, cpt_shift, cpt_mask;
+    __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
+        x = reinterpret_cast<const char *>(p.x), zeros = reinterpret_cast<const char *>(p.zeros), Win = p.Win, pixb = 4 * p.Cin;
+        cpt_mask = p.chunks_per_tap - 1, cpt_shift = 31 - __builtin_clz(p.chunks_per_tap);  // power of two
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            int m = m0 + lr + 32 * i;
+            if (m >= M) m = M - 1;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
+            off[i] = (((int64_t)b * p.Hin + ih0) * p.Win + iw0) * pixb + lc * 8;
+            uint32_t mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ih = ih0 + t / 3, iw = iw0 + t % 3;
+                if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) mk |= 1u << t;
+            }
+            mask[i] = mk;
+        }
+    }
+    __device__ __forceinline__ void issue(Raw (&raw)[R], int kc) const {
+        const int tap = kc >> cpt_shift, cc = kc & cpt_mask;  // chunk cc = channels 32 cc .. 32 cc + 31: half (cc & 1) of slab cc >> 1
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int64_t koff = (int64_t)(kh * Win + kw) * pixb + (cc >> 1) * 256 + (cc & 1) * 64;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const bool ok = (mask[i] >> tap) & 1u;
+            const char *src = ok ? x + off[i] + koff : zeros;
+            raw[i].hi = *reinterpret_cast<const u32x2 *>(src);
+            raw[i].lo = *reinterpret_cast<const u32x2 *>(src + 128);
+        }
+    }
+    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {  // bit patterns: {hi.x, hi.y, lo.x, lo.y}
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            out[i] = f32x4{__uint_as_float(raw[i].hi[0]), __uint_as_float(raw[i].hi[1]), __uint_as_float(raw[i].lo[0]), __uint_as_float(raw[i].lo[1])};
     }
 };
 
@@ -288,7 +349,8 @@ struct DenseLoader {
 };
 
 // ------------------------------------------------------------------------------------------ epilogues
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_RES_RELU = 2, EPI_PARTIAL = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_RES_RELU = 2, EPI_PARTIAL = 3,
+       EPI_BIAS_RELU_PLANES = 4 };  // bias + ReLU, output written as plane activations (c3_conv3.h) with ldc = N channels
 
 struct EpilogueParams {
     float *c;            // [M][ldc]   (EPI_PARTIAL: [split][M][ldc])
@@ -384,7 +446,11 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 u32x2 pc[NP];
-                if constexpr (SPLIT == 1) split3_bf16(av[i], pc);
+                if constexpr (requires { Loader::kPlanes; }) {  // the loader delivered the two fp16 pieces themselves
+                    static_assert(SPLIT == 2, "plane activations are fp16 piece pairs");
+                    pc[0] = u32x2{__float_as_uint(av[i][0]), __float_as_uint(av[i][1])};
+                    pc[1] = u32x2{__float_as_uint(av[i][2]), __float_as_uint(av[i][3])};
+                } else if constexpr (SPLIT == 1) split3_bf16(av[i], pc);
                 else split2_f16(av[i], pc);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneA + st_off_a[i]) = pc[q];
@@ -590,11 +656,21 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
                     for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], ep.post_scale, bv[e]);  // post_scale = 1: the plain add
                 }
                 if (EPI == EPI_BIAS_RES_RELU) val += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off + 32 * q, 0, 0));
-                if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU) {
+                if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_RELU_PLANES) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = __int_as_float(max(__float_as_int(val[e]), 0));
                 }
                 if constexpr (SPLIT != 0 && EPI != EPI_PARTIAL) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3]))));
+                if constexpr (EPI == EPI_BIAS_RELU_PLANES) {
+                    // channel n of pixel m: slab n >> 6, hi piece at 2 (n & 63), lo piece 128 bytes further; `off` is the pixel
+                    // row (4 ldc bytes) + 4 nb, so the plane offset of column nb + 8 q is (off - 4 nb) + ...
+                    const int n = nb + 8 * q;
+                    u32x2 pc[2];
+                    split2_f16(val, pc);
+                    const uint32_t po = m < gp.M ? (uint32_t)((int64_t)m * ep.ldc * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : 0xffffff00u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_u32x2, pc[0]), crsrc, po, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_u32x2, pc[1]), crsrc, po + 128, 0, 0);
+                } else
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), crsrc, off + 32 * q, 0, 0);
             }
         }

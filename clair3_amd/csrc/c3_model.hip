@@ -25,6 +25,7 @@
 #include "c3_decode.h"
 #include "c3_lstm_fused.h"
 #include "c3_host.h"
+#include "c3_conv3.h"
 
 using namespace c3;
 
@@ -157,6 +158,10 @@ struct c3_model {
     float *wino_v[9] = {};   // Winograd-domain weights of the stride-1 convs (layers 1,2,4,5,7,8)
     float *wino_v16[9] = {};  // the same as two fp16 pieces per weight, fragment order of the F16 persistent kernel (c3_wino_p.h)
     unsigned wino_f16_mask = 0x1b6;  // Winograd layers on the fp16x3 split products; env C3HIP_WINOGRAD_F16MASK
+    float *pconv_w[9] = {};  // stride-1 convs for conv3x3_planes_kernel (c3_conv3.h): [Cout/64][Cin/64][9][64][16 pieces of 16 B]
+    float pconv_wscale[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+    bool fa_planes = true;   // plane activations + direct fp16x3 convolutions (c3_conv3.h); env C3HIP_FA_PLANES=0 restores the fp32-activation kernels of round 1
+    bool last_planes = false;  // the last full-alignment forward left plane activations in act[] (c3_debug_fetch converts)
     float *conv_w3[9] = {};  // direct-conv weights as three bf16 pieces [3][Cout][K] (uint16 payload), layers in conv_split_mask
     unsigned conv_split_mask = 0x48;  // stride-2 convs conv3 / conv5 on the split-precision path (c3_gemm.h SPLIT); env C3HIP_CONV_SPLITMASK
     // fp16x3: a weight tensor is packed times a power of two chosen per tensor (pick_wscale: as close to 256 as keeps
@@ -708,6 +713,28 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
             if (mx < 16384.f) TRY(upload(m, &m->conv1_wfrag16, pf16));
         }
     }
+    if (kConvStride[l] == 1 && Cin == Cout && Cin % 64 == 0 && m->fa_planes && m->split_kind == 2) {
+        // conv3x3_planes_kernel: chunk (column tile tn, input slab, tap) = 64 couts x 256 B; piece g < 8 = hi of channels
+        // 64 slab + 8 g .. + 7, g >= 8 = lo of channels 8 (g - 8) ..; times a power of two (pick_wscale), undone by post_scale
+        const int NS = Cin / 64;
+        const float sc = pick_wscale(pw.data(), pw.size());
+        m->pconv_wscale[l] = sc;
+        std::vector<float> pk((size_t)NS * NS * 9 * 64 * 64);  // 16 KB per chunk
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
+        for (int tn = 0; tn < NS; ++tn)
+            for (int slab = 0; slab < NS; ++slab)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int n = 0; n < 64; ++n)
+                        for (int g = 0; g < 16; ++g)
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = tn * 64 + n, ci = slab * 64 + 8 * (g & 7) + j;
+                                const float v = pw[(size_t)co * ldb + (size_t)tap * Cin + ci] * sc;  // exact
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const _Float16 piece = g < 8 ? h0 : h1;
+                                memcpy(&q16[((((((size_t)tn * NS + slab) * 9 + tap) * 64 + n) * 16 + g) * 8) + j], &piece, 2);
+                            }
+        TRY(upload(m, &m->pconv_w[l], pk));
+    }
     if (kConvStride[l] == 1 && Cin % kWinoBK == 0 && Cout % kWinoNT == 0) {
         // Winograd F(2x2,3x3) weights V = G g' G^T (g' = BN-folded), in MFMA B-fragment order
         //   [Cout/32][xi = 4i+j][Cin/16][g][lane][e] = V_xi[n = nt*32 + (lane&31)][k = 16c + 8g + 4(lane>>5) + e]
@@ -813,7 +840,135 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
     return 0;
 }
 
+// PyramidPolling geometry, clair3/model.py:250-279: the bins of the three levels clipped to the image
+static int spp_bins(const c3_model *m, int H, int W, SppParams &sp) {
+    sp.H = H, sp.W = W, sp.C = 256;
+    int nbins = 0;
+    const int pools[3] = {3, 2, 1};
+    for (int pi = 0; pi < 3; ++pi) {
+        const int p = pools[pi];
+        const int wh_ = (H + p - 1) / p, ww_ = (W + p - 1) / p;
+        const int oh_n = (H + wh_ - 1) / wh_, ow_n = (W + ww_ - 1) / ww_;
+        const int pad_h = std::max((oh_n - 1) * wh_ + wh_ - H, 0), pad_w = std::max((ow_n - 1) * ww_ + ww_ - W, 0);
+        const int pt = pad_h / 2, pl = pad_w / 2;
+        for (int oh = 0; oh < oh_n; ++oh)
+            for (int ow = 0; ow < ow_n; ++ow) {
+                if (nbins >= 16) return fail("unsupported geometry: more than 16 pyramid bins");
+                const int a0 = oh * wh_ - pt, a1 = a0 + wh_, c0 = ow * ww_ - pl, c1 = c0 + ww_;
+                sp.h0[nbins] = (short)std::max(a0, 0), sp.h1[nbins] = (short)std::min(a1, H);
+                sp.w0[nbins] = (short)std::max(c0, 0), sp.w1[nbins] = (short)std::min(c1, W);
+                sp.pad[nbins] = (a0 < 0 || a1 > H || c0 < 0 || c1 > W) ? 1 : 0;
+                ++nbins;
+            }
+    }
+    if (nbins * 256 != m->K4) return fail("unsupported geometry: %d pyramid bins (L4 expects %d inputs)", nbins, m->K4);
+    sp.nbins = nbins;
+    return 0;
+}
+
+// ---- plane-activation pipeline (c3_conv3.h): the default whenever the handle is on the fp16x3 kernels ----
+static bool fa_planes_ok(const c3_model *m) {
+    if (!m->fa_planes || !m->f16_ok || m->split_kind != 2) return false;
+    int hh[10], ww[10];
+    fa_geometry(m, hh, ww);
+    for (int l : {1, 2, 4, 5, 7, 8})
+        if (!m->pconv_w[l] || ww[l] > kPlMaxW) return false;
+    for (int l : {3, 6})
+        if (!m->conv_w3[l]) return false;
+    if (m->C == 8 ? !(m->conv1_direct && m->conv1_f16 && m->conv1_wfrag16) : !m->conv_w3[0]) return false;
+    return true;
+}
+
+static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float *y) {
+    int hh[10], ww[10];
+    fa_geometry(m, hh, ww);
+    int cin = m->C;
+    for (int l = 0; l < 9; ++l) {
+        const int Cout = kConvCout[l];
+        const int M = (int)(n * hh[l + 1] * ww[l + 1]);
+        const double flops = 2.0 * M * Cout * 9.0 * cin;
+        const double bytes = (l == 0 ? 1.0 : 4.0) * n * hh[l] * ww[l] * cin + 4.0 * M * Cout * (l % 3 == 2 ? 2 : 1) + 4.0 * Cout * 9.0 * cin;
+        ProfScope ps(m, s, kFaLayerTag[l], flops, bytes);
+        if (l == 0 && cin == 8) {
+            ps.mfma(2.0 * ((M + 31) / 32 * 32) * 64.0 * 80.0 * 2, true);
+            Conv1F16Params cp;
+            cp.x = x, cp.wfrag = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.bias = m->conv_b[0], cp.out = m->act[0];
+            cp.range_flag = m->range_flag;
+            cp.B = (int)n, cp.H = hh[0], cp.W = ww[0], cp.OH = hh[1], cp.OW = ww[1], cp.M = M, cp.groups = (M + 31) / 32;
+            const int grid = std::min((cp.groups + 3) / 4, m->wg_slots);
+            hipLaunchKernelGGL(conv1_i8_f16_kernel<true>, dim3(grid), dim3(256), 0, s, cp);
+            HIP_TRY(hipGetLastError());
+        } else if (l == 0) {
+            ps.mfma(2.0 * ((M + 127) / 128 * 128) * 64.0 * 96.0 * 3, true);
+            Conv1LoaderParams lp{x, (const int8_t *)m->zeros, hh[0], ww[0], cin, hh[1], ww[1]};
+            EpilogueParams ep{m->act[0], m->conv_b[0], nullptr, Cout, 0};
+            ep.post_scale = 1.f / m->conv_wscale[0], ep.range_flag = m->range_flag;
+            TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU_PLANES, 128, 64, 2>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep, m->conv_w3[0])));
+        } else if (kConvStride[l] == 2) {
+            ps.mfma(2.0 * ((M + 127) / 128 * 128) * (double)Cout * 9.0 * cin * 3, true);
+            PlaneConvLoaderParams lp{m->act[l - 1], m->zeros, hh[l], ww[l], cin, hh[l + 1], ww[l + 1], 2, cin / kBK};
+            EpilogueParams ep{m->act[l], m->conv_b[l], nullptr, Cout, 0};
+            ep.post_scale = 1.f / m->conv_wscale[l], ep.range_flag = m->range_flag;
+            const int nk = 9 * cin / kBK;
+            const int64_t ldb = 9 * cin;
+            if (!(m->conv_bn64_mask & (1u << l)))
+                TRY((launch_gemm<PlaneConvLoader<4>, EPI_BIAS_RELU_PLANES, 128, 128, 2>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep, m->conv_w3[l])));
+            else
+                TRY((launch_gemm<PlaneConvLoader<4>, EPI_BIAS_RELU_PLANES, 128, 64, 2>(s, lp, m->conv_w[l], ldb, M, Cout, nk, 1, ep, m->conv_w3[l])));
+        } else {
+            const bool res = l % 3 == 2;
+            PlaneConvParams cp;
+            cp.x = m->act[l - 1], cp.w = m->pconv_w[l], cp.bias = m->conv_b[l], cp.res = res ? m->act[l - 2] : nullptr, cp.out = m->act[l];
+            cp.range_flag = m->range_flag, cp.post_scale = 1.f / m->pconv_wscale[l];
+            cp.M = M, cp.H = hh[l], cp.W = ww[l];
+            static const int stagger_env = getenv("C3HIP_PLANES_STAGGER") ? atoi(getenv("C3HIP_PLANES_STAGGER")) : 0;
+            cp.stagger = stagger_env;
+            const int tiles_m = (M + kPlBM - 1) / kPlBM;
+            cp.tiles = tiles_m * (Cout / 64);
+            ps.mfma(2.0 * tiles_m * kPlBM * (double)Cout * 9.0 * cin * 3, true);
+            // persistent: one workgroup per tile when they all fit (2 per CU), else wg_slots rounded down so that a
+            // workgroup's tiles share their column tile (c3_conv3.h)
+            int g = cp.tiles;
+            const int cus = m->wg_slots / 2, unit = 8 * (Cout / 64);  // one 512-thread workgroup (114 KB of LDS) per CU
+            if (g > cus) g = std::max(unit, cus / unit * unit);
+            const dim3 grid(g), block(kPlThreads);
+            if (Cout == 64) {
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false>), grid, block, 0, s, cp);
+            } else if (Cout == 128) {
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<128, true>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<128, false>), grid, block, 0, s, cp);
+            } else {
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<256, true>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<256, false>), grid, block, 0, s, cp);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        cin = Cout;
+    }
+    {
+        ProfScope ps(m, s, "fa.spp", 0.0, 4.0 * n * (hh[9] * ww[9] * 256.0 + m->K4));
+        if (hh[9] == 12 && ww[9] == 5) {
+            if (14 * 256 != m->K4) return fail("unsupported geometry: L4 expects %d inputs", m->K4);
+            const int grid = (int)std::min<int64_t>(n, 8192);
+            hipLaunchKernelGGL((spp_planes_fixed_kernel<12, 5>), dim3(grid), dim3(256), 0, s, (const void *)m->act[8], m->spp, (int)n, 256);
+        } else {
+            SppParams sp;
+            TRY(spp_bins(m, hh[9], ww[9], sp));
+            sp.in = m->act[8], sp.out = m->spp, sp.B = (int)n;
+            const int64_t total = n * m->K4;
+            const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+            hipLaunchKernelGGL(spp_planes_kernel, dim3(grid), dim3(256), 0, s, sp);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    m->last_planes = true;
+    return run_tail(m, s, m->spp, m->K4, n, y, "fa.l4", "fa.tail");
+}
+
 static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float *y) {
+    if (fa_planes_ok(m)) return run_fa_planes(m, s, x, n, y);
+    m->last_planes = false;
     int hh[10], ww[10];
     fa_geometry(m, hh, ww);
     int cin = m->C;
@@ -917,29 +1072,9 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
         cin = Cout;
     }
     {
-        // PyramidPolling geometry, clair3/model.py:250-279
         SppParams sp;
-        sp.in = m->act[8], sp.out = m->spp, sp.B = (int)n, sp.H = hh[9], sp.W = ww[9], sp.C = 256;
-        int nbins = 0;
-        const int pools[3] = {3, 2, 1};
-        for (int pi = 0; pi < 3; ++pi) {
-            const int p = pools[pi], H = hh[9], W = ww[9];
-            const int wh_ = (H + p - 1) / p, ww_ = (W + p - 1) / p;
-            const int oh_n = (H + wh_ - 1) / wh_, ow_n = (W + ww_ - 1) / ww_;
-            const int pad_h = std::max((oh_n - 1) * wh_ + wh_ - H, 0), pad_w = std::max((ow_n - 1) * ww_ + ww_ - W, 0);
-            const int pt = pad_h / 2, pl = pad_w / 2;
-            for (int oh = 0; oh < oh_n; ++oh)
-                for (int ow = 0; ow < ow_n; ++ow) {
-                    if (nbins >= 16) return fail("unsupported geometry: more than 16 pyramid bins");
-                    const int a0 = oh * wh_ - pt, a1 = a0 + wh_, c0 = ow * ww_ - pl, c1 = c0 + ww_;
-                    sp.h0[nbins] = (short)std::max(a0, 0), sp.h1[nbins] = (short)std::min(a1, H);
-                    sp.w0[nbins] = (short)std::max(c0, 0), sp.w1[nbins] = (short)std::min(c1, W);
-                    sp.pad[nbins] = (a0 < 0 || a1 > H || c0 < 0 || c1 > W) ? 1 : 0;
-                    ++nbins;
-                }
-        }
-        if (nbins * 256 != m->K4) return fail("unsupported geometry: %d pyramid bins (L4 expects %d inputs)", nbins, m->K4);
-        sp.nbins = nbins;
+        TRY(spp_bins(m, hh[9], ww[9], sp));
+        sp.in = m->act[8], sp.out = m->spp, sp.B = (int)n;
         ProfScope ps(m, s, "fa.spp", 0.0, 4.0 * n * (hh[9] * ww[9] * 256.0 + m->K4));
         if (hh[9] == 12 && ww[9] == 5) {  // ONT geometry: fully unrolled specialisation
             const int grid = (int)std::min<int64_t>(n, 8192);  // one block = the 256 channels of one window
@@ -1174,6 +1309,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_LSTM1_F16")) m->lstm1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_F16")) m->conv1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_FA_PLANES")) m->fa_planes = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
         c3_model_destroy(m);
@@ -1534,6 +1670,7 @@ int c3_model_destroy(c3_model *m) {
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);
         if (m->wino_v[l]) (void)hipFree(m->wino_v[l]);
         if (m->conv_w3[l]) (void)hipFree(m->conv_w3[l]);
+        if (m->pconv_w[l]) (void)hipFree(m->pconv_w[l]);
         if (m->wino_v16[l]) (void)hipFree(m->wino_v16[l]);
     }
     for (auto &sl : m->slot) {
@@ -1595,7 +1732,18 @@ int c3_debug_fetch(c3_model *m, const char *name, float *host_out, int64_t n_flo
     }
     if (!src) return fail("unknown debug tensor \"%s\"", name);
     if (n != n_floats) return fail("debug tensor %s has %lld floats, caller expects %lld", name, (long long)n, (long long)n_floats);
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    if (m->kind == C3_KIND_FULL_ALIGNMENT && m->last_planes && s.compare(0, 3, "act") == 0) {
+        // the layer holds plane activations (c3_conv3.h): hand the caller the fp32 values they stand for
+        const int C = kConvCout[s[3] - '0'];
+        float *tmp = nullptr;
+        HIP_TRY(hipMalloc((void **)&tmp, (size_t)n * sizeof(float)));
+        hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const void *)src, tmp, n / C, C);
+        hipError_t e = hipMemcpy(host_out, tmp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail("debug fetch copy failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     HIP_TRY(hipMemcpy(host_out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }

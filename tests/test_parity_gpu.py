@@ -323,6 +323,7 @@ def test_split_bf16_convolutions_are_as_close_to_the_oracle_as_the_fp32_ones(mon
     fp16x3 = two fp16 pieces, three piece products, the default; bf16x6 = three bf16 pieces, six products).  Their
     outputs (act3, act6) and the final rows must sit as close to the fp64 oracle as the fp32-MFMA kernels do -- not
     merely inside the 1e-4 gate."""
+    monkeypatch.setenv("C3HIP_FA_PLANES", "0")  # the fp32-activation kernels of round 1 (the plane pipeline is the default)
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=31, peaked=True)
     x = syn.make_fa_windows(9, seed=32)
     y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
@@ -352,6 +353,7 @@ def test_fp16x3_winograd_stays_at_fp32_level(monkeypatch, oracle_mod):
     F16).  Every layer output against the fp64 oracle, next to the same kernels on fp32 MFMAs: the split products may
     cost a small factor in rounding noise (both are ~1e-6 of the layer's range, 100x inside the 1e-4 gate on the
     probabilities), never more."""
+    monkeypatch.setenv("C3HIP_FA_PLANES", "0")  # the fp32-activation kernels of round 1 (the plane pipeline is the default)
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=41, peaked=True)
     x = syn.make_fa_windows(7, seed=42)
     y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
@@ -371,6 +373,38 @@ def test_fp16x3_winograd_stays_at_fp32_level(monkeypatch, oracle_mod):
     for k, v in errs["0x1b6"].items():
         assert v < 1e-5, (k, v)
         assert v <= 5 * errs["0"][k] + 3e-7, (k, errs)
+
+
+def test_plane_pipeline_stays_at_fp32_level(monkeypatch, oracle_mod):
+    """the default full-alignment path: plane activations (every value kept as its two fp16 pieces) and direct fp16x3
+    convolutions (c3_conv3.h).  Every layer output against the fp64 oracle, next to the all-fp32-MFMA kernels on fp32
+    activations: the same order of rounding noise, 100x inside the 1e-4 gate on the probabilities.  Also the dwell model
+    (conv1 through the tiled GEMM with the plane epilogue) and a batch that is not a multiple of any tile."""
+    errs = {}
+    for ch, seed in ((8, 41), (9, 43)):
+        sd = syn.make_state_dict(syn.FULL_ALIGNMENT, ch, True, seed=seed, peaked=True)
+        x = syn.make_fa_windows(7, seed=42, channels=ch)
+        y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+        for mode, env in (("planes", {}), ("fp32", {"C3HIP_FA_PLANES": "0", "C3HIP_WINOGRAD_F16MASK": "0", "C3HIP_CONV_SPLITMASK": "0",
+                                                    "C3HIP_CONV1_F16": "0", "C3HIP_L4_SPLIT": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m = make_model(syn.FULL_ALIGNMENT, ch, True, sd, keep=True)
+            y = m.predict_numpy(x)
+            e = {}
+            for l in range(9):
+                a = m.debug_fetch(f"act{l}", d[f"act{l}"].shape)
+                assert np.isfinite(a).all(), (mode, l)
+                e[f"act{l}"] = float(np.abs(a - d[f"act{l}"]).max()) / max(1.0, float(np.abs(d[f"act{l}"]).max()))
+            e["y"] = util.assert_rows_match(y, y_o, what=f"C={ch} {mode}")
+            errs[(ch, mode)] = e
+            for k in env:
+                monkeypatch.delenv(k)
+        print(f"C={ch}:", {k: (round(errs[(ch, 'planes')][k] * 1e6, 2), round(errs[(ch, 'fp32')][k] * 1e6, 2)) for k in errs[(ch, "fp32")]},
+              "(x1e-6: planes, fp32)")
+        for k, v in errs[(ch, "planes")].items():
+            assert v < 1e-5, (ch, k, v)
+            assert v <= 5 * errs[(ch, "fp32")][k] + 3e-7, (ch, k, errs)
 
 
 def test_large_folded_weights_keep_their_fp16_pieces_in_range(oracle_mod):
@@ -507,11 +541,14 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=23)
     x_p = syn.make_pileup_windows(70, seed=24)
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
-    fa_sets = [{"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
+    fa_sets = [{"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_BN64MASK": "0"}, {"C3HIP_CONV_BN64MASK": "0x48"},
+               {"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
                {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"},
                {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
                {"C3HIP_SPLIT_KIND": "1"}, {"C3HIP_WINOGRAD_F16MASK": "0"}, {"C3HIP_WINOGRAD_F16MASK": "0x24"}]
-    for env in fa_sets:
+    for i, env in enumerate(fa_sets):
+        if i >= 3:
+            env = dict(env, C3HIP_FA_PLANES="0")  # switches of the fp32-activation kernels
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f, what=f"FA {env}")

@@ -97,6 +97,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 h=d['host_inclusive']
 print('  device one-in-flight %.0f | host B=256 %.0f (%.2f) | host B=1000 %.0f of %.0f (%.2f) | registered %s' % (d['one_batch_in_flight']['value'], h['value'], h['frac_of_device_resident_one_in_flight'], h['batch_1000']['value'], h['batch_1000']['device_resident_one_in_flight'], h['batch_1000']['frac_of_device_resident'], h.get('batch_1000_registered_source')))
 "; done ;;
+    cprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w tools/conv_probe.hip -o /tmp/conv_probe && timeout 300 /tmp/conv_probe > gpurun_out/conv_probe.txt 2>&1; echo "cprobe rc=$?"; cat gpurun_out/conv_probe.txt ;;
     info)  (rocminfo | grep -E "Name|Compute Unit|Max Clock|Wavefront" | head -40; lscpu | head -20; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null) > gpurun_out/info.txt 2>&1 ;;
   esac
 done
