@@ -26,6 +26,7 @@
 #include "c3_lstm_fused.h"
 #include "c3_host.h"
 #include "c3_conv3.h"
+#include "c3_comm.h"
 
 using namespace c3;
 
@@ -1619,6 +1620,100 @@ int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *ro
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rows_host, rows, total, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// ---- the gather of the sharded job on RCCL (c3_comm.h) ----
+int c3_comm_unique_id(void *id128) {
+    if (!id128) return fail("null buffer");
+    RcclApi &r = RcclApi::get();
+    if (!r.load()) return fail("%s", r.error.c_str());
+    RcclUniqueId id;
+    const int rc = r.GetUniqueId(&id);
+    if (rc) return fail("ncclGetUniqueId failed: %s", r.GetErrorString(rc));
+    memcpy(id128, id.b, 128);
+    return 0;
+}
+
+c3_comm *c3_comm_create(const void *id128, int rank, int world, int device) {
+    if (world < 1 || rank < 0 || rank >= world) {
+        fail("bad rank %d of %d", rank, world);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail("hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    c3_comm *c = new c3_comm();
+    c->rank = rank, c->world = world, c->device = device;
+    if (world == 1) return c;  // nothing to talk to: c3_gather_rows is a device copy
+    if (!id128) {
+        fail("null unique id");
+        delete c;
+        return nullptr;
+    }
+    RcclApi &r = RcclApi::get();
+    if (!r.load()) {
+        fail("%s", r.error.c_str());
+        delete c;
+        return nullptr;
+    }
+    RcclUniqueId id;
+    memcpy(id.b, id128, 128);
+    const int rc = r.CommInitRank(&c->nccl, world, id, rank);
+    if (rc) {
+        fail("ncclCommInitRank failed: %s", r.GetErrorString(rc));
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+int c3_comm_destroy(c3_comm *c) {
+    if (!c) return 0;
+    if (c->nccl) (void)RcclApi::get().CommDestroy(c->nccl);
+    delete c;
+    return 0;
+}
+
+int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int64_t *counts, float *all_dev, int dst, void *stream) {
+    if (!c || !counts) return fail("null argument");
+    if (dst < 0 || dst >= c->world || row_floats <= 0) return fail("bad arguments (dst %d of %d ranks, %d floats per row)", dst, c->world, row_floats);
+    for (int r = 0; r < c->world; ++r)
+        if (counts[r] < 0) return fail("negative row count for rank %d", r);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t mine = (size_t)counts[c->rank] * row_floats;
+    if (mine && !rows_dev) return fail("null rows");
+    if (c->rank == dst && !all_dev) return fail("the destination rank needs the gathered buffer");
+    if (c->world == 1) {
+        if (mine && all_dev != rows_dev) HIP_TRY(hipMemcpyAsync(all_dev, rows_dev, mine * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    RcclApi &r = RcclApi::get();
+    int rc = r.GroupStart();
+    if (rc) return fail("ncclGroupStart failed: %s", r.GetErrorString(rc));
+    if (c->rank == dst) {
+        size_t off = 0;
+        for (int src = 0; src < c->world && !rc; ++src) {
+            const size_t n = (size_t)counts[src] * row_floats;
+            if (src == dst) {
+                if (n && all_dev + off != rows_dev) {
+                    hipError_t e = hipMemcpyAsync(all_dev + off, rows_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+                    if (e != hipSuccess) rc = -1;
+                }
+            } else if (n) {
+                rc = r.Recv(all_dev + off, n, kNcclFloat, src, c->nccl, s);
+            }
+            off += n;
+        }
+    } else if (mine) {
+        rc = r.Send(const_cast<float *>(rows_dev), mine, kNcclFloat, dst, c->nccl, s);
+    }
+    const int rc2 = r.GroupEnd();
+    if (rc > 0) return fail("ncclSend/ncclRecv failed: %s", r.GetErrorString(rc));
+    if (rc < 0) return fail("device copy inside the gather failed");
+    if (rc2) return fail("ncclGroupEnd failed: %s", r.GetErrorString(rc2));
     return 0;
 }
 

@@ -108,3 +108,83 @@ def predict_sharded(model, x_all, dst=0):
     yd = model.forward(xd, checked=True)  # the range guard of the host path, on the device-resident entry
     out = gather_rows(yd, n, dst)
     return out.cpu().numpy() if out is not None else None
+
+
+def gather_counts(y_local, counts, dst=0):
+    """gather_rows for arbitrary per-rank row counts (a file-sharded job: ranks own whole files, so their window counts
+    are whatever the files hold).  counts[r] = rows of rank r, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return y_local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if y_local.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {y_local.shape[0]} rows, expected {counts[rank]}")
+    width, pad = y_local.shape[1], max(max(counts), 1)
+    send = torch.zeros((pad, width), dtype=y_local.dtype, device=y_local.device)
+    send[: y_local.shape[0]] = y_local
+    if rank == dst:
+        parts = [torch.empty((pad, width), dtype=y_local.dtype, device=y_local.device) for _ in range(world)]
+        dist.gather(send, parts, dst=dst)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    dist.gather(send, None, dst=dst)
+    return None
+
+
+class RcclComm:
+    """The gather on RCCL itself (c3_gather_rows: grouped ncclSend / ncclRecv on the caller's HIP stream) -- the data
+    path of a sharded job touches no framework.  torch.distributed (any backend, gloo is enough) is used ONCE, as the
+    control plane that carries rank 0's 128-byte unique id to the other ranks; a launcher with another store can pass
+    ``unique_id`` itself.  world == 1 needs neither RCCL nor a rendezvous."""
+
+    def __init__(self, rank=0, world=1, device=0, unique_id=None):
+        import ctypes as C
+        from . import _lib
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        idbuf = (C.c_char * 128)()
+        if self.world > 1:
+            if unique_id is None:
+                import torch
+                import torch.distributed as dist
+                t = torch.zeros(128, dtype=torch.uint8)
+                if self.rank == 0:
+                    _lib.check(_lib.lib().c3_comm_unique_id(idbuf), "c3_comm_unique_id")
+                    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+                if dist.get_backend() == "nccl":
+                    t = t.cuda(self.device)
+                dist.broadcast(t, src=0)
+                unique_id = bytes(t.cpu().numpy().tobytes())
+            idbuf.raw = unique_id
+        h = _lib.lib().c3_comm_create(idbuf, self.rank, self.world, self.device)
+        if not h:
+            raise _lib.C3Error(f"c3_comm_create: {_lib.last_error()}")
+        self._h = C.c_void_p(h)
+
+    def gather(self, y_dev, counts, dst=0, stream=None):
+        """y_dev: this rank's (counts[rank], W) float32 CUDA tensor.  Returns the (sum(counts), W) tensor on ``dst`` (rows in
+        rank order), None elsewhere.  Asynchronous on the current stream, like any other kernel."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        if y_dev.shape[0] != counts[self.rank] or y_dev.dtype != torch.float32 or not y_dev.is_cuda:
+            raise ValueError("rows must be a float32 CUDA tensor holding this rank's count")
+        y_dev = y_dev.contiguous()
+        width = int(y_dev.shape[1])
+        out = torch.empty((int(sum(counts)), width), dtype=torch.float32, device=y_dev.device) if self.rank == dst else None
+        cnt = (C.c_int64 * self.world)(*[int(c) for c in counts])
+        s = torch.cuda.current_stream(y_dev.device).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().c3_gather_rows(self._h, y_dev.data_ptr(), width, cnt, out.data_ptr() if out is not None else None,
+                                             dst, C.c_void_p(s)), "c3_gather_rows")
+        return out
+
+    def close(self):
+        from . import _lib
+        if getattr(self, "_h", None):
+            _lib.lib().c3_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,130 @@
+"""A whole sharded calling job (BASELINE.json configs[3]: "candidate windows sharded across 8 x MI355X").
+
+The reference cuts its candidates into tensor files of at most 10 000 windows (preprocess/SelectCandidates.py:379), writes the
+list of files (``--output_tensor_can_fn_list``), and splits that LIST over GPU slots -- file i goes to slot i % n_slots, each slot
+writes its own VCF shard, SortVcf merges them (clair3/CallVariantsFromCffiGPU.py:138-156,163-199).  Here:
+
+  * the file list is split into CONTIGUOUS runs of files, balanced by window count (``shard_files``), one run per rank, so the
+    concatenation of the ranks' rows in rank order IS the reference's window order -- no sort step;
+  * every rank drives its GPU with ``worker.predict_batches`` (memory-mapped files, the reference's batch boundaries, a ring of
+    submit/wait slots);
+  * the (n_r, 24|90) rows meet on rank 0 in one gather: on RCCL directly (``dist.RcclComm``) when the rows are on GPUs, through
+    torch.distributed's gloo for the CPU tests.
+
+``write_synthetic_job`` produces the stand-in for a 50x ONT genome the survey describes (no BAM is available offline): N windows of
+the named shape in <= 10 000-window ``.npy`` / ``.info`` pairs plus the list file, positions numbered so that order is checkable.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import dist as c3dist, synthetic as syn, worker
+
+MAX_WINDOWS_PER_FILE = 10000  # preprocess/SelectCandidates.py:379
+
+
+def write_synthetic_job(directory, kind, n_windows, channels=None, per_file=MAX_WINDOWS_PER_FILE, seed=0, unique=2048):
+    """Write ceil(n / per_file) tensor files + .info files + the list file; returns (list_fn, windows per file).
+    Windows are ``unique`` seeded windows tiled (generation cost stays bounded for million-window jobs); the .info position of
+    window g is ``chrS:<g+1>:<33 bases>`` so a consumer can verify global order."""
+    os.makedirs(directory, exist_ok=True)
+    channels = channels or (18 if kind == syn.PILEUP else 8)
+    base = syn.make_windows(kind, min(unique, n_windows), seed=seed, channels=channels)
+    names, counts = [], []
+    g = 0
+    ref = "ACGT" * 8 + "A"
+    while g < n_windows:
+        n = min(per_file, n_windows - g)
+        idx = (np.arange(g, g + n) % len(base))
+        name = f"tensor_{len(names):05d}"
+        np.save(os.path.join(directory, name + ".npy"), base[idx])
+        with open(os.path.join(directory, name + ".info"), "w") as f:
+            f.write("\n".join(f"chrS:{g + i + 1}:{ref}\t30-RA 30 " for i in range(n)) + "\n")
+        names.append(name)
+        counts.append(n)
+        g += n
+    list_fn = os.path.join(directory, "tensor_can_fn_list")
+    with open(list_fn, "w") as f:
+        f.write("\n".join(names) + "\n")
+    return list_fn, counts
+
+
+def file_window_counts(list_fn):
+    """windows per file of a list, read from the .npy headers only (no tensor is loaded)"""
+    parent = os.path.dirname(list_fn)
+    with open(list_fn) as f:
+        names = [n for n in f.read().strip().split("\n") if n]
+    return names, [int(np.load(os.path.join(parent, n + ".npy"), mmap_mode="r").shape[0]) for n in names]
+
+
+def shard_files(counts, world):
+    """Contiguous runs of files per rank, balanced by windows: rank r gets files [cut[r], cut[r + 1]).  A file is never split
+    (files are the reference's unit of work); cuts are placed where the running window total crosses r / world of the job."""
+    total = float(sum(counts))
+    cuts, run, k = [0], 0, 1
+    for i, c in enumerate(counts):
+        run += c
+        while k < world and run >= total * k / world - 1e-9:
+            cuts.append(i + 1)
+            k += 1
+    while len(cuts) < world + 1:
+        cuts.append(len(counts))
+    cuts[-1] = len(counts)
+    return cuts
+
+
+def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume=None):
+    """Every rank calls this with the same list.  Returns on rank 0 a dict with the rows of the whole job in window order
+    (numpy), the positions seen, and timings; on other ranks the timings only.
+    ``model``: a loaded clair3_amd model (or a pair / any object with submit/wait, see worker.predict_batches).
+    ``comm``: a dist.RcclComm for GPU rows; None -> torch.distributed (gloo) gather of host rows, or nothing for world 1."""
+    names, counts = file_window_counts(list_fn)
+    cuts = shard_files(counts, world)
+    mine = names[cuts[rank]:cuts[rank + 1]]
+    per_rank = [int(sum(counts[cuts[r]:cuts[r + 1]])) for r in range(world)]
+    parent = os.path.dirname(list_fn)
+    sub_list = os.path.join(parent, f".rank{rank}_of_{world}.list")
+    with open(sub_list, "w") as f:
+        f.write("\n".join(mine) + ("\n" if mine else ""))
+    rows, positions = [], []
+
+    def take(pos, alt, y):
+        rows.append(y)
+        positions.extend(pos)
+        if consume is not None:
+            consume(pos, alt, y)
+
+    t0 = time.perf_counter()
+    n_done = worker.predict_file_list(model, sub_list, take, batch_size=batch_size) if mine else 0
+    t_compute = time.perf_counter() - t0
+    os.unlink(sub_list)
+    assert n_done == per_rank[rank]
+    width = rows[0].shape[1] if rows else None
+    y_local = np.concatenate(rows) if rows else None
+    out = {"rank": rank, "windows_local": n_done, "compute_s": t_compute, "files_local": len(mine), "per_rank": per_rank}
+    if world == 1:
+        out.update(rows=y_local, positions=positions, gather_s=0.0, total_s=time.perf_counter() - t0)
+        return out
+    import torch
+    import torch.distributed as dist
+    # every rank needs the row width even when it owns no file
+    w = torch.tensor([width or 0], dtype=torch.int64)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    width = int(w.item())
+    if y_local is None:
+        y_local = np.zeros((0, width), np.float32)
+    t1 = time.perf_counter()
+    if comm is not None:
+        yd = torch.from_numpy(y_local).cuda(comm.device)
+        got = comm.gather(yd, per_rank, dst=0)
+        torch.cuda.synchronize(comm.device)
+        y_all = got.cpu().numpy() if got is not None else None
+    else:
+        got = c3dist.gather_counts(torch.from_numpy(y_local), per_rank, dst=0)
+        y_all = got.numpy() if got is not None else None
+    out.update(gather_s=time.perf_counter() - t1, total_s=time.perf_counter() - t0)
+    if rank == 0:
+        out["rows"] = y_all
+    out["positions"] = positions
+    return out

@@ -6,7 +6,7 @@ stage, loads every file completely, slices it into batches and runs H2D -> forwa
 keeps the file formats, the batch boundaries and the order of the rows exactly as the reference produces them,
 but
   * memory-maps the ``.npy`` files instead of reading up to 235 MB per file up front,
-  * double-buffers through ``c3_predict_submit`` / ``c3_predict_wait``: while batch *i* is on the GPU, batch
+  * keeps a ring of three ``c3_predict_submit`` / ``c3_predict_wait`` slots in flight: while batch *i* is on the GPU, batch
     *i+1* is being copied into the library's pinned staging buffer and its H2D transfer is already queued,
   * hands every ``(positions, alt_info, Y)`` batch to a caller-supplied consumer -- in the reference pipeline
     that is the unchanged ``batch_output`` (clair3/CallVariants.py:1069), run in the existing process pool.
@@ -56,30 +56,35 @@ def iter_batches(list_fn, batch_size):
             yield tensor[lo:hi], positions[lo:hi], alt_infos[lo:hi]
 
 
-def predict_batches(model, batches, consume):
-    """Run ``model`` over an iterator of (X, positions, alt_infos) with a two-slot software pipeline and call
-    ``consume(positions, alt_infos, Y)`` for every batch, in order.  ``model`` needs ``submit(X, slot)`` /
-    ``wait(ticket)`` (clair3_amd.model._HipModel).  Returns the number of windows processed.
+def predict_batches(model, batches, consume, slots=3):
+    """Run ``model`` over an iterator of (X, positions, alt_infos) with a ring of ``slots`` submits in flight per handle
+    (c3_predict_submit / c3_predict_wait, at most C3_HOST_SLOTS = 4) and call ``consume(positions, alt_infos, Y)`` for
+    every batch, in order.  ``model`` needs ``submit(X, slot)`` / ``wait(ticket)`` (clair3_amd.model._HipModel).  Returns the
+    number of windows processed.  Three slots keep the staging copy, the H2D transfer, the kernels and the D2H transfer of
+    consecutive batches overlapped: 0.97 of the device-resident rate at the reference's batch of 1000 (bench.py
+    host_inclusive).
 
-    ``model`` may also be a pair of handles loaded with the same weights: batch i then runs on handle i % 2
-    (own workspace and HIP streams each), so the kernels of two batches overlap on the GPU as well -- measured
-    +19 % (full alignment, B=256) / +42 % (pileup, B=1024) over one handle, because the LSTM recurrences and the
-    12x5 stage cannot fill 256 CUs alone."""
+    ``model`` may also be a list of handles loaded with the same weights: batch i then runs on handle i % len (own
+    workspace and HIP streams each), so the kernels of consecutive batches overlap on the GPU as well."""
+    from collections import deque
     models = list(model) if isinstance(model, (list, tuple)) else [model]
     total = 0
-    pending = None  # (model, ticket, positions, alt_infos)
+    pending = deque()  # (model, ticket, positions, alt_infos), oldest first
+    depth = slots * len(models)
     i = 0
     for X, positions, alt_infos in batches:
+        if len(pending) == depth:
+            m0, t0, p0, a0 = pending.popleft()
+            consume(p0, a0, m0.wait(t0))
         m = models[i % len(models)]
-        slot = (i // len(models)) & 1 if len(models) > 1 else i & 1
+        slot = (i // len(models)) % slots
         ticket = m.submit(np.ascontiguousarray(X), slot=slot)  # staging copy + H2D + kernels + D2H enqueued
-        if pending is not None:
-            consume(pending[2], pending[3], pending[0].wait(pending[1]))
-        pending = (m, ticket, positions, alt_infos)
+        pending.append((m, ticket, positions, alt_infos))
         total += len(positions)
         i += 1
-    if pending is not None:
-        consume(pending[2], pending[3], pending[0].wait(pending[1]))
+    while pending:
+        m0, t0, p0, a0 = pending.popleft()
+        consume(p0, a0, m0.wait(t0))
     return total
 
 

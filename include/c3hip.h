@@ -154,6 +154,22 @@ int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uin
 /* The decoder columns for rows that are already on the host: rows_host[batch][output_size + C3_DECODE_COLS] receives
  * y_host[b] followed by its columns (same kernel as the c3_model_set_decode_columns path).  Synchronous. */
 int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *rows_host);
+/* ---- the collective of the sharded job ----
+ * The reference meets its per-GPU workers on disk (one VCF shard per worker, merged by SortVcf:
+ * clair3/CallVariantsFromCffiGPU.py:138-199, preprocess/SortVcf.py:290-362).  Here the probability rows of every
+ * rank's window shard travel to one rank in a single gather(v), issued DIRECTLY on RCCL (grouped ncclSend / ncclRecv
+ * over xGMI, librccl bound with dlopen) on the caller's HIP stream, ordered behind the forward pass on that stream.
+ *   c3_comm_unique_id   rank 0 fills 128 bytes (ncclGetUniqueId); the caller hands them to every rank (any control
+ *                       plane: a file, the launcher's store) -- rendezvous is not this library's business
+ *   c3_comm_create      every rank, same id; world == 1 needs no id and no RCCL (the gather is a device copy)
+ *   c3_gather_rows      rows_dev: this rank's counts[rank] rows of row_floats floats (device); counts: rows of every rank
+ *                       (host, identical on all ranks -- they follow from the shard ranges); all_dev (rank dst only):
+ *                       sum(counts) rows, rank-major = window order for contiguous shards.  Asynchronous on `stream`. */
+typedef struct c3_comm c3_comm;
+int c3_comm_unique_id(void *id128);
+c3_comm *c3_comm_create(const void *id128, int rank, int world, int device);
+int c3_comm_destroy(c3_comm *c);
+int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int64_t *counts, float *all_dev, int dst, void *stream);
 /* blocks until everything enqueued on the model's own stream has finished */
 int c3_model_synchronize(c3_model *m);
 int c3_model_destroy(c3_model *m);

@@ -35,7 +35,7 @@ class OracleModel:
         self.oracle, self.sd, self.log, self.inflight = oracle, sd, [], {}
 
     def submit(self, x, slot=0):
-        assert slot in (0, 1) and slot not in self.inflight, "slot reused before wait"
+        assert slot in (0, 1, 2, 3) and slot not in self.inflight, "slot reused before wait"
         assert x.flags["C_CONTIGUOUS"]
         self.inflight[slot] = np.array(x)
         self.log.append(("submit", slot, len(x)))
@@ -67,10 +67,10 @@ def test_pipeline_keeps_order_and_overlaps(tmp_path):
     y = np.concatenate(rows)
     assert np.array_equal(y, oracle.pileup_forward(sd, np.concatenate(xs), n_threads=1))
     assert pos[7] == "chr20:1000:" + "ACGT" * 8 + "A"
-    # batch i+1 is submitted before batch i is waited for, on alternating slots
+    # a ring of three slots: batches i+1 and i+2 are submitted before batch i is waited for
     kinds = [e[0] for e in m.log]
-    assert kinds[:3] == ["submit", "submit", "wait"] and kinds[-1] == "wait"
-    assert [e[1] for e in m.log if e[0] == "submit"][:4] == [0, 1, 0, 1]
+    assert kinds[:4] == ["submit", "submit", "submit", "wait"] and kinds[-1] == "wait"
+    assert [e[1] for e in m.log if e[0] == "submit"][:5] == [0, 1, 2, 0, 1]
 
 
 def test_info_rows_must_match(tmp_path):

@@ -21,9 +21,19 @@ def agg(path):
 def main(tag):
     f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch/c3_counter_collection.csv"))
     w = agg(os.path.join(ROOT, "gpurun_out/pmc_write/c3_counter_collection.csv"))
-    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("wino_conv_kernel" in k) or ("conv1_i8" in k)
+    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("gemm_mfma_kernel<c3::PlaneConv" in k) or ("wino_conv_kernel" in k) or \
+        ("conv1_i8" in k) or ("conv3x3_planes_kernel" in k)
     tot_f = tot_w = n = 0
     per = {}
+    all_f = all_w = 0.0
+    steps = 0
+    for k in f:
+        if not k.startswith(("void c3::", "c3::")):
+            continue
+        all_f += sum(f[k]["FETCH_SIZE"])
+        all_w += sum(w[k]["WRITE_SIZE"]) if k in w else 0.0
+        if "spp" in k:
+            steps = len(f[k]["FETCH_SIZE"])  # one pyramid-pooling launch per forward pass
     for k in f:
         if not conv(k):
             continue
@@ -47,6 +57,8 @@ def main(tag):
         "fetch_bytes_per_launch_corrected": 2 * tot_f * 1024 / n,
         "write_bytes_per_launch": tot_w * 1024 / n,
         "algorithmic_bytes_per_launch": sum(B * (a + b + c) for a, b, c in shapes) / 9,
+        "steps": steps,
+        "hbm_bytes_per_step": (2 * all_f + all_w) * 1024 / steps if steps else None,
         "per_kernel": per,
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as fh:
@@ -61,9 +73,16 @@ def main_pileup(tag):
     lstm = lambda k: ("lstm1_fused_kernel" in k) or ("lstm_recurrent_kernel" in k)
     tot_f = tot_w = n = 0
     per = {}
+    all_f = all_w = 0.0
+    steps = 0
     for k in f:
         fs, ws = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
         per[k[:90]] = {"launches": len(fs), "fetch_kb_avg_reported": sum(fs) / len(fs), "write_kb_avg": sum(ws) / len(ws)}
+        if k.startswith(("void c3::", "c3::")):
+            all_f += sum(fs)
+            all_w += sum(ws)
+        if "lstm1_fused_kernel" in k:
+            steps = len(fs)
         if lstm(k):
             tot_f += sum(fs)
             tot_w += sum(ws)
@@ -82,6 +101,8 @@ def main_pileup(tag):
         "fetch_bytes_per_launch_corrected": 2 * tot_f * 1024 / n,
         "write_bytes_per_launch": tot_w * 1024 / n,
         "algorithmic_bytes_per_launch": algorithmic,
+        "steps": steps,
+        "hbm_bytes_per_step": (2 * all_f + all_w) * 1024 / steps if steps else None,
         "per_kernel": per,
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic_pileup.json"), "w") as fh:
