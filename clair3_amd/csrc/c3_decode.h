@@ -40,8 +40,27 @@ constexpr int kDecodeClasses = 10;
 // all four:
 //   [0..8]   maxima of classes 1..9          [9..12]  homo_Ref probability for reference base A, C, G, T
 //   [13..21] positions of those maxima       [22]     early-exit bits (bit b: base b takes the early exit)
-// positions and bits as float values (all < 2^24: exact).
-constexpr int kDecodeCols = 23;
+//   [23..26] the class output_from (:722-751) settles on FIRST for reference base A, C, G, T: 0 when the overall maximum is
+//            the homo_Ref probability (or the base takes the early exit), else the first class in the order of its
+//            if / elif chain (:753-978: homo_SNP, hetero_SNP, homo_Ins, hetero_ACGT_Ins, hetero_InsIns, homo_Del,
+//            hetero_ACGT_Del, hetero_DelDel, hetero_InsDel) whose list contains that maximum
+//   [27..30] 100 x QUAL of that first decision, quality_score_from (:375-381) of the overall maximum, as an integer:
+//            QUAL = col / 100.0 is the double round(tmp, 2) returns
+// positions, classes, bits and 100 x QUAL as float values (all < 2^24: exact).
+constexpr int kDecodeCols = 31;
+
+// quality_score_from (clair3/CallVariants.py:375-381) of a float32 probability, times 100 and rounded to an integer.  The
+// reference evaluates `((1.0 - p) + 1e-10) / (p + 1e-10)` on a numpy float32 scalar -- float32 arithmetic under numpy >= 2
+// (python floats are weak scalars), which is what the goldens were generated with -- and takes math.log of the result in
+// double precision; Phred_Trans = -10 * log(e, 10) (:27).
+__device__ __forceinline__ float qual_x100(float p) {
+    const float num = __fadd_rn(__fsub_rn(1.0f, p), 1e-10f), den = __fadd_rn(p, 1e-10f);
+    const float q = __fdiv_rn(num, den);
+    const double phred_trans = -10.0 * 0.43429448190325176;  // -10 * log10(e)
+    double tmp = phred_trans * log((double)q) + 10.0;
+    tmp = tmp > 0.0 ? tmp : 0.0;
+    return (float)rint(tmp * 100.0);
+}
 
 // one wave per row; candidates of a class are dealt to the lanes in enumeration order, then a 64-lane max with
 // smallest-index tie-break (key = value bits << 32 | ~index: probabilities are >= 0, so float order == bit order)
@@ -56,6 +75,9 @@ __global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
     const float hr = z[0], hv = z[1], ht = z[2];
     float *cols = COLS ? p.cols + (int64_t)row * p.ldy : nullptr;
 
+    // COLS: the overall maximum of classes 1..9 and the first class of the reference's if / elif chain that holds it
+    float best19 = -1.f;
+    int best_rank = 99, best_cls = 0;
     auto reduce_store = [&](int cls, unsigned long long key) {
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) {
@@ -64,20 +86,40 @@ __global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
         }
         if (lane == 0) {
             if constexpr (COLS) {
-                if (cls) cols[cls - 1] = __uint_as_float((unsigned)(key >> 32)), cols[12 + cls] = (float)(int32_t)(~(unsigned)key);
+                if (cls) {
+                    const float v = __uint_as_float((unsigned)(key >> 32));
+                    cols[cls - 1] = v, cols[12 + cls] = (float)(int32_t)(~(unsigned)key);
+                    const int rank_of[10] = {0, 1, 2, 3, 6, 4, 5, 7, 8, 9};  // position of class cls in the if / elif chain
+                    const int rk = rank_of[cls];
+                    if (v > best19 || (v == best19 && rk < best_rank)) best19 = v, best_rank = rk, best_cls = cls;
+                }
             } else {
                 p.maxp[(int64_t)row * kDecodeClasses + cls] = __uint_as_float((unsigned)(key >> 32));
                 p.argmax[(int64_t)row * kDecodeClasses + cls] = (int32_t)(~(unsigned)key);
             }
         }
     };
+    float ref_b = 0.f;   // lanes 0..3: homo_Ref probability / early exit for reference base A, C, G, T
+    bool early_b = false;
     // class 0 and the early exit for each of the four possible reference bases (lanes 0..3)
     auto all_bases = [&](float scale, bool lengths_ok) {
         const int hs[4] = {0, 4, 7, 9};
         const float gb = g[hs[lane & 3]];
         const unsigned long long bits = __ballot(lane < 4 && lengths_ok && hr >= 0.5f && gb >= 0.5f);
-        if (lane < 4) cols[9 + lane] = p.indel ? __fmul_rn(scale, gb) : __fmul_rn(hr, gb);
+        ref_b = p.indel ? __fmul_rn(scale, gb) : __fmul_rn(hr, gb);
+        early_b = (bits >> (lane & 3)) & 1u;
+        if (lane < 4) cols[9 + lane] = ref_b;
         if (lane == 0) cols[22] = (float)(unsigned)(bits & 15u);
+    };
+    // per reference base (lanes 0..3 hold its homo_Ref probability and early bit after all_bases): winner class + 100 x QUAL
+    auto first_decision = [&]() {
+        const float b19 = __shfl(best19, 0);
+        const int c19 = __shfl(best_cls, 0);
+        if (lane < 4) {
+            const bool is_ref = early_b || !(b19 > ref_b);  // is_reference is tested first: a tie goes to homo_Ref
+            cols[23 + lane] = is_ref ? 0.f : (float)c19;
+            cols[27 + lane] = qual_x100(is_ref ? ref_b : b19);
+        }
     };
     auto mk = [](float v, int idx) { return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)~idx; };
     const unsigned long long none = 0ull;  // below every real candidate (idx 0xffffffff never occurs)
@@ -96,6 +138,7 @@ __global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
         reduce_store(7, lane < 4 ? mk(__fmul_rn(g[11 + (lane & 3)], ht), lane) : none);
         reduce_store(8, lane == 0 ? mk(__fmul_rn(ht, g[10]), 0) : none);
         reduce_store(9, lane == 0 ? mk(__fmul_rn(ht, g[20]), 0) : none);
+        if constexpr (COLS) first_decision();
         return;
     }
 
@@ -154,6 +197,7 @@ __global__ __launch_bounds__(256) void outcome_maxima_kernel(DecodeParams p) {
         }
         reduce_store(9, key);
     }
+    if constexpr (COLS) first_decision();
 }
 
 }  // namespace c3

@@ -95,9 +95,36 @@ def decode_columns(model, y):
     return rows
 
 
+def first_decisions(rows, ref_bases, output_size):
+    """Vectorised read-out of the decoder columns for rows whose reference base IS known (the worker knows it from the
+    .info position string): what output_from (clair3/CallVariants.py:722-751) decides on its first pass and what
+    output_with prints as QUAL (:1325) when no candidate is rejected --
+        cls    0 homo_Ref ... 9 hetero_InsDel (CLASS_NAMES)      pos    position of the winning entry in its class list
+        qual   quality_score_from(maximum) as the same double     prob   the maximum itself (float32)
+        early  the homo-reference early exit
+    ``class_entry(cls, pos)`` turns (cls, pos) into lengths / bases; only the allele-string lookup in alt_info is left to
+    Python.  rows: (B, output_size + DECODE_COLS) as returned with model.decode_columns(True)."""
+    rows = np.asarray(rows, dtype=np.float32)
+    cols = rows[:, output_size:]
+    if cols.shape[1] != DECODE_COLS:
+        raise _lib.C3Error(f"rows carry {cols.shape[1]} decoder columns, expected {DECODE_COLS}")
+    if isinstance(ref_bases, (bytes, bytearray)):
+        ref_bases = ref_bases.decode()
+    b = np.frombuffer(ref_bases.encode(), dtype=np.uint8) if isinstance(ref_bases, str) else np.asarray(ref_bases, dtype=np.uint8)
+    base = np.zeros(256, np.int8)
+    base[[ord("A"), ord("C"), ord("G"), ord("T")]] = (0, 1, 2, 3)
+    bi = base[b].astype(np.int64)
+    r = np.arange(len(rows))
+    cls = cols[r, 23 + bi].astype(np.int8)
+    pos = np.where(cls > 0, cols[r, 13 + np.maximum(cls.astype(np.int64), 1) - 1], 0).astype(np.int32)
+    prob = np.where(cls > 0, cols[r, np.maximum(cls.astype(np.int64), 1) - 1], cols[r, 9 + bi]).astype(np.float32)
+    early = ((cols[:, 22].astype(np.int32) >> bi) & 1).astype(bool)
+    return {"cls": cls, "pos": pos, "qual": cols[r, 27 + bi].astype(np.float64) / 100.0, "prob": prob, "early": early}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # decoder columns -> the reference's output_from
-DECODE_COLS = 23
+DECODE_COLS = 31
 _CLASS_LEN = {True: (1, 4, 6, 16, 16, 64, 136, 64, 241, 256), False: (1, 4, 6, 1, 1, 4, 1, 4, 1, 1)}
 
 

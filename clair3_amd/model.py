@@ -86,7 +86,7 @@ class _HipModel:
                 self._load(self._pending_sd)
         return self
 
-    DECODE_COLS = 23  # C3_DECODE_COLS (include/c3hip.h)
+    DECODE_COLS = 31  # C3_DECODE_COLS (include/c3hip.h)
 
     @property
     def row_size(self):

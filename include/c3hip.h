@@ -90,9 +90,12 @@ int c3_model_output_size(const c3_model *m);
  *   [0..8]   max of the class lists homo_SNP, hetero_SNP, homo_Ins, homo_Del, hetero_ACGT_Ins, hetero_InsIns,
  *            hetero_ACGT_Del, hetero_DelDel, hetero_InsDel        [9..12] homo_Ref probability if the base is A, C, G, T
  *   [13..21] position of the first occurrence of each maximum     [22]    bit b set: base b takes the early exit
- * (positions and bits stored as float values).  Rows stay valid input of the reference's batch_output: it slices
+ *   [23..26] the class output_from settles on first (:722-751) if the base is A, C, G, T: 0 = homo_Ref (the overall maximum, or
+ *            the early exit), else the first class of its if / elif chain (:753-978) whose list holds the overall maximum
+ *   [27..30] 100 x QUAL of that first decision (quality_score_from, :375-381), an integer: QUAL = column / 100.0
+ * (positions, classes, bits and 100 x QUAL stored as float values).  Rows stay valid input of the reference's batch_output: it slices
  * columns [0:21] [21:24] [24:57] [57:90] (CallVariants.py:1072-1080) and never looks further right. */
-#define C3_DECODE_COLS 23
+#define C3_DECODE_COLS 31
 int c3_model_set_decode_columns(c3_model *m, int enable);
 int c3_model_row_size(const c3_model *m);
 /* bytes of one input window for dtype x_dtype (594 / 2376 / 23496 / 26433 for the ONT shapes) */

@@ -65,15 +65,49 @@ def outcome_maxima(y, ref21, add_indel_length):
     return maxp, arg, early
 
 
+ELIF_ORDER = (1, 2, 3, 5, 6, 4, 7, 8, 9)  # output_from's if / elif chain, clair3/CallVariants.py:753-978
+
+
+def quality_score(p):
+    """clair3/CallVariants.py:375-381 on a numpy float32 scalar (numpy >= 2: the python floats are weak, the quotient is
+    formed in float32; math.log and the rest in double)"""
+    from math import e, log
+    p = np.float32(p)
+    phred_trans = -10 * log(e, 10)
+    tmp = max(phred_trans * log(((1.0 - p) + 1e-10) / (p + 1e-10)) + 10, 0)
+    return float(round(tmp, 2))
+
+
+def first_decision(y, ref21, add_indel_length):
+    """(winner class, QUAL) of output_from's first pass (:722-751) per row: 0 when the overall maximum is the homo_Ref
+    probability or the row takes the early exit, else the first class of the if / elif chain holding the maximum."""
+    maxp, arg, early = outcome_maxima(y, ref21, add_indel_length)
+    winner = np.zeros(len(maxp), dtype=np.int8)
+    qual = np.zeros(len(maxp), dtype=np.float64)
+    for r in range(len(maxp)):
+        if early[r]:
+            qual[r] = quality_score(maxp[r, 0])
+            continue
+        m = maxp[r].max()
+        if m != maxp[r, 0]:
+            winner[r] = next(c for c in ELIF_ORDER if maxp[r, c] == m)
+        qual[r] = quality_score(m)
+    return winner, qual
+
+
 def decode_columns(y, add_indel_length):
-    """The 23 decoder columns of include/c3hip.h (C3_DECODE_COLS) for every row: maxima and first positions of classes
-    1..9 (independent of the reference base), homo_Ref probability and early-exit bit for each base A, C, G, T."""
+    """The 31 decoder columns of include/c3hip.h (C3_DECODE_COLS) for every row: maxima and first positions of classes
+    1..9 (independent of the reference base); homo_Ref probability, early-exit bit, first-decision class and 100 x QUAL for
+    each base A, C, G, T."""
     y = np.asarray(y, dtype=np.float32)
-    out = np.zeros((len(y), 23), dtype=np.float32)
+    out = np.zeros((len(y), 31), dtype=np.float32)
     for b, k in enumerate((0, 4, 7, 9)):
         maxp, arg, early = outcome_maxima(y, np.full(len(y), k), add_indel_length)
         out[:, 9 + b] = maxp[:, 0]
         out[:, 22] += early.astype(np.float32) * (1 << b)
+        winner, qual = first_decision(y, np.full(len(y), k), add_indel_length)
+        out[:, 23 + b] = winner
+        out[:, 27 + b] = np.rint(qual * 100.0)
         if b == 0:
             out[:, 0:9] = maxp[:, 1:]
             out[:, 13:22] = arg[:, 1:]

@@ -140,6 +140,21 @@ def decode_rate():
         decode_oracle.outcome_maxima(y[:256], ref[:256], indel)
         cpu = 256 / (time.time() - t)
         print(f"  {kind:15s} {n} rows x {y.shape[1]} floats: c3_outcome_maxima {gpu:,.0f} rows/s | python enumeration {cpu:,.0f} rows/s/core", flush=True)
+    # host read-out of the first decision (class, position, QUAL) from rows that carry the columns: what is left for one core
+    for kind, ch, indel, n in ((syn.FULL_ALIGNMENT, 8, True, 65536), (syn.PILEUP, 18, False, 65536)):
+        cls = Clair3_P if kind == syn.PILEUP else Clair3_F
+        m = cls(add_indel_length=indel, predict=True, input_channels=ch).to("cuda:0")
+        m.load_state_dict(syn.make_state_dict(kind, ch, indel, seed=0))
+        m.decode_columns(True)
+        wide = np.tile(m.predict_numpy(syn.make_windows(kind, 512, seed=2)), (n // 512, 1))
+        letters = "ACGT" * (n // 4)
+        decode.first_decisions(wide, letters, m.output_size)
+        t = time.time()
+        for _ in range(5):
+            d = decode.first_decisions(wide, letters, m.output_size)
+        rate = 5 * n / (time.time() - t)
+        print(f"  {kind:15s} first_decisions (class, position, QUAL from the device columns): {rate:,.0f} rows/s/core; "
+              f"classes seen {np.bincount(d['cls'], minlength=10).tolist()}", flush=True)
     # what the decoder columns cost on the prediction path (host windows in, host rows out, one batch at a time)
     print("== c3_predict with / without the decoder columns (c3_model_set_decode_columns)")
     for kind, ch, indel, B in ((syn.FULL_ALIGNMENT, 8, True, 256), (syn.FULL_ALIGNMENT, 8, True, 1000), (syn.PILEUP, 18, False, 1024)):

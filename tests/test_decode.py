@@ -108,7 +108,7 @@ def test_oracle_columns_agree_with_the_per_base_maxima():
     """decode_oracle.decode_columns is outcome_maxima evaluated for the four bases: pinned by the same goldens"""
     g = golden(True)
     cols = decode_oracle.decode_columns(g["y"], True)
-    assert cols.shape == (len(g["y"]), 23) and cols.dtype == np.float32
+    assert cols.shape == (len(g["y"]), 31) and cols.dtype == np.float32
     base = np.array([{0: 0, 4: 1, 7: 2, 9: 3}[int(k)] for k in g["ref21"]])
     rows = np.arange(len(base))
     assert np.array_equal(((cols[:, 22].astype(np.int32) >> base) & 1).astype(bool), g["early"])
@@ -116,6 +116,25 @@ def test_oracle_columns_agree_with_the_per_base_maxima():
     live = ~g["early"]
     assert np.array_equal(cols[live, 0:9].view(np.uint32), g["maxp"][live, 1:].view(np.uint32))
     assert np.array_equal(cols[live, 13:22].astype(np.int32), g["argmax"][live, 1:])
+
+
+@pytest.mark.parametrize("indel", [True, False])
+def test_first_decision_and_qual_match_the_real_reference(indel):
+    """winner class (output_from :722-751 on the real lists) and QUAL (the real quality_score_from) stored by
+    make_golden_decode.py == the oracle's restatement, exactly; and the host read-out of the oracle's columns returns them"""
+    from clair3_amd import decode
+    g = golden(indel)
+    winner, qual = decode_oracle.first_decision(g["y"], g["ref21"], indel)
+    assert np.array_equal(winner, g["winner"]) and np.array_equal(qual, g["qual"])
+    assert len(set(g["winner"].tolist())) >= 8 and (g["qual"] > 0).sum() > 20  # the goldens exercise most classes
+    wide = np.concatenate([g["y"], decode_oracle.decode_columns(g["y"], indel)], axis=1)
+    letters = "".join({0: "A", 4: "C", 7: "G", 9: "T"}[int(k)] for k in g["ref21"])
+    d = decode.first_decisions(wide, letters, g["y"].shape[1])
+    assert np.array_equal(d["cls"], g["winner"]) and np.array_equal(d["qual"], g["qual"]) and np.array_equal(d["early"], g["early"])
+    live = ~g["early"]
+    rows = np.arange(len(wide))[live]
+    assert np.array_equal(d["pos"][live], g["argmax"][rows, g["winner"][live].astype(int)] * (g["winner"][live] > 0))
+    assert np.array_equal(d["prob"][live].view(np.uint32), g["maxp"][rows, g["winner"][live].astype(int)].view(np.uint32))
 
 
 @pytest.mark.gpu
