@@ -57,7 +57,6 @@ struct PlaneConvParams {
     float post_scale;     // the weights are packed times a power of two (pick_wscale); undone here, exactly
     int M, H, W;
     int tiles;            // ceil(M / 128) * (C / 64)
-    int stagger = 0;      // start-up delay per phase step in units of ~1024 cycles (see the kernel: breaks the lockstep of the grid)
 };
 
 // split four fp32 values into their fp16 pieces and store them behind `off` (hi plane) / `off + 128` (lo plane)
@@ -160,16 +159,6 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         }
     };
     trace(1);
-    // All workgroups start together and do identical work, so without help they stay in lockstep: everybody loads, then
-    // everybody computes, then everybody stores -- memory and matrix pipes take turns instead of overlapping (measured: launch
-    // time = sum, not max, of the two).  Workgroups therefore start in four phases, a fraction of a tile apart; the two
-    // workgroups that share a CU (slots s and s + 32 of an XCD under round-robin placement) land in different phases.
-    if (p.stagger > 0) {
-        const int slot = blockIdx.x >> 3;
-        const int phase = slot & 3;
-        for (int i = 0; i < phase * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-
     // ---- prologue: zero row, first halo slab, weight chunk 0 -> LDS, chunk 1 -> registers
     // Weight chunks travel through THREE register sets (set = tap % 3; 9 taps per slab, so the rotation is the same in every
     // slab and tile): requested three chunks ahead, written to LDS two chunks later.  Two chunks of slack, because loads

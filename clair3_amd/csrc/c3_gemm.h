@@ -638,6 +638,65 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         const_cast<float *>(EPI == EPI_BIAS_RES_RELU ? ep.res : ep.c), 0, (uint32_t)((int64_t)gp.M * ep.ldc * 4), 0x00020000);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     float omax = 0.f;
+    if constexpr (SPLIT == 2 && BM == 128 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_PLANES)) {
+        // Coalesced epilogue.  A lane owns 4 consecutive columns of ONE row per store, so a wave's store instruction above
+        // touches 32 different rows with 16 bytes each -- partial lines, one request per row.  These two epilogues write the
+        // largest tensors of their networks (173 MB of LSTM2 pre-activations per 1024 windows; the stride-2 convolutions'
+        // plane activations), so the tile crosses LDS (free now; rows 272 B apart, 64 columns per pass) and leaves as whole
+        // 16-byte pieces of 8 consecutive columns, 8 lanes per row segment of 256 B (fp32) / 128 B per plane.
+        constexpr int kRowE = 272;
+        static_assert(2 * kStage >= 128 * kRowE, "the staged tile must fit the operand buffers");
+#pragma unroll
+        for (int sl = 0; sl < BN / 64; ++sl) {  // 64-column slices of the tile
+            __syncthreads();  // operand reads of the last chunk / item reads of the previous slice are done
+            if (BN == 64 || wn == sl) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int c = 0; c < CB; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int col = (BN == 64 ? wn * 32 : 0) + c * 32 + 4 * (lane >> 5) + 8 * q;  // inside the slice
+                            const f32x4 bv = *reinterpret_cast<const f32x4 *>(ep.bias + n0 + sl * 64 + col);
+                            f32x4 val = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], ep.post_scale, bv[e]);
+                            *reinterpret_cast<f32x4 *>(smem + (wm * 64 + i * 32 + (lane & 31)) * kRowE + col * 4) = val;
+                        }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + 256 * j;
+                const int r = idx >> 3, g = idx & 7;  // row of the tile, group of 8 columns of the slice
+                const int m = m0 + r, n = n0 + sl * 64 + g * 8;
+                f32x4 a = *reinterpret_cast<const f32x4 *>(smem + r * kRowE + g * 32);
+                f32x4 b = *reinterpret_cast<const f32x4 *>(smem + r * kRowE + g * 32 + 16);
+                if constexpr (EPI == EPI_BIAS) {
+                    const uint32_t off = m < gp.M ? (uint32_t)(((int64_t)m * ep.ldc + n) * 4) : 0xffffff00u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), crsrc, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), crsrc, off + 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = __int_as_float(max(__float_as_int(a[e]), 0));
+                        b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
+                    }
+                    omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+                    u32x2 pa[2], pb[2];
+                    split2_f16(a, pa);
+                    split2_f16(b, pb);
+                    const u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+                    const uint32_t po = m < gp.M ? (uint32_t)((int64_t)m * ep.ldc * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : 0xffffff00u;
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, crsrc, po, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, crsrc, po + 128, 0, 0);
+                }
+            }
+        }
+        if constexpr (EPI == EPI_BIAS_RELU_PLANES)
+            if (ep.range_flag && !(omax < kF16Range)) atomicOr(ep.range_flag, 1u);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);

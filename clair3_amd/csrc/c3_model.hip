@@ -922,8 +922,6 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             cp.x = m->act[l - 1], cp.w = m->pconv_w[l], cp.bias = m->conv_b[l], cp.res = res ? m->act[l - 2] : nullptr, cp.out = m->act[l];
             cp.range_flag = m->range_flag, cp.post_scale = 1.f / m->pconv_wscale[l];
             cp.M = M, cp.H = hh[l], cp.W = ww[l];
-            static const int stagger_env = getenv("C3HIP_PLANES_STAGGER") ? atoi(getenv("C3HIP_PLANES_STAGGER")) : 0;
-            cp.stagger = stagger_env;
             const int tiles_m = (M + kPlBM - 1) / kPlBM;
             cp.tiles = tiles_m * (Cout / 64);
             ps.mfma(2.0 * tiles_m * kPlBM * (double)Cout * 9.0 * cin * 3, true);

@@ -70,11 +70,6 @@ template <int C> static int shape(const char *name, int B, int H, int W, int slo
     printf("  MFMA + LDS reads + barriers  %6.1f us\n", run<C, 7>(cp, g));
     printf("  no per-chunk barrier (racy)  %6.1f us\n", run<C, 32>(cp, g));
     for (int s : {slots / 2}) printf("  full at grid %4d            %6.1f us\n", grid_for(s), run<C, 0>(cp, grid_for(s)));
-    for (int st : {1, 2, 4, 8, 16}) {
-        PlaneConvParams c2 = cp;
-        c2.stagger = st;
-        printf("  full, stagger %2d             %6.1f us\n", st, run<C, 0>(c2, g));
-    }
     {   // shader-clock trace of workgroups 0 and 301, wave 0 (RES = false: p.res is the trace buffer)
         long long *tb; CK(hipMalloc(&tb, 2 * 256 * 16)); CK(hipMemset(tb, 0, 2 * 256 * 16));
         PlaneConvParams ct = cp;
