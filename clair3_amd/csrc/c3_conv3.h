@@ -76,14 +76,14 @@ __device__ __forceinline__ f32x4 load_planes4(const __amdgpu_buffer_rsrc_t rsrc,
 }
 
 // ABL: ablation switches of tools/conv_probe.hip (0 in the product): 1 no weight loads, 2 no halo loads after the first tile,
-// 4 no epilogue, 8 no matrix instructions, 16 no LDS fragment reads, 32 no per-chunk barrier, 64 shader-clock trace of two
+// 4 no epilogue, 8 no matrix instructions, 64 shader-clock trace of two
 // workgroups (wave 0) at phase boundaries into p.res ([2][256] x {tag, clock}).
 template <int C, bool RES, int ABL = 0>
 __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConvParams p) {
     constexpr int NS = C / 64;     // input slabs = output column tiles
     constexpr int PIXB = 4 * C;    // bytes per pixel
     constexpr int NCH = 9 * NS;    // weight chunks per tile
-    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 2 * kPlBBytes];
+    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes];
     char *const halo = smem;
     char *const bbuf = smem + kPlHaloBytes;
 
@@ -159,11 +159,14 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         }
     };
     trace(1);
-    // ---- prologue: zero row, first halo slab, weight chunk 0 -> LDS, chunk 1 -> registers
-    // Weight chunks travel through THREE register sets (set = tap % 3; 9 taps per slab, so the rotation is the same in every
-    // slab and tile): requested three chunks ahead, written to LDS two chunks later.  Two chunks of slack, because loads
-    // and stores retire through one in-order counter (vmcnt): the first wait on a load requested AFTER a tile's epilogue
-    // stores also waits for those stores to be acknowledged (~1-2 us under load).
+    // ---- prologue: zero row, first halo slab, weight chunks 0 and 1 -> LDS, chunk 2 -> registers
+    // Weight chunks: THREE LDS buffers (buffer = tap % 3) and THREE register sets (set = tap % 3; 9 taps per slab, so both
+    // rotations repeat in every slab and tile and are compile-time constants in the unrolled tap loop).  Chunk g is requested
+    // at the top of chunk g - 3, written to LDS in the middle of chunk g - 2 (behind that chunk's only barrier) and first read at
+    // the end of chunk g - 1, when its first fragments are prefetched -- so the fragment pipeline runs ACROSS chunk boundaries
+    // and no matrix instruction ever waits for an LDS read issued right in front of it.  (With two buffers and the barrier at
+    // the chunk boundary the compiler's schedule exposed two LDS round trips plus the barrier per chunk: 2400 cycles per chunk
+    // for 1536 cycles of matrix work on the two waves of a SIMD.)
     pl_u32x4 hreg[kPlHaloLoads];
     pl_u32x4 rb[3][NBP];
     halo_issue(hreg, m0, 0);
@@ -174,14 +177,36 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     trace(2);
     halo_write(hreg);
     b_write(rb[0], 0);
+    b_write(rb[1], 1);
     lds_barrier();
     trace(3);
 
-    int gcc = 0;  // chunks processed so far: LDS weight buffer gcc & 1 holds the current chunk
+    // fragment registers, two stages; stage 0 holds k-step 0 / 2, stage 1 k-step 1 / 3 of the current chunk
+    pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
+    const char *asrc[2];  // this lane's two halo rows for the current tap (+ the k-half offset)
+    uint32_t mask[2] = {0u, 0u};
+    auto set_asrc = [&](int tap) __attribute__((always_inline)) {
+        const int toff = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = ((mask[i] >> tap) & 1u) ? lrow[i] + toff : T;
+            asrc[i] = halo + r * kPlRowB + kh * 16;
+        }
+    };
+    auto frags = [&](int buf, int ks, int st) __attribute__((always_inline)) {
+        const char *const bsrc = bbuf + buf * kPlBBytes + b_rd;
+        wh[st] = *reinterpret_cast<const pl_u32x4 *>(bsrc + ks * 32);
+        wl[st] = *reinterpret_cast<const pl_u32x4 *>(bsrc + 128 + ks * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(asrc[i] + ks * 32);
+            xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(asrc[i] + 128 + ks * 32);
+        }
+    };
+
     float omax = 0.f;
     for (;;) {
         // tap validity of this lane's two output pixels: bit t set when tap t = (dh + 1) * 3 + (dw + 1) lies inside the window
-        uint32_t mask[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + lrow[i];
@@ -206,80 +231,66 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        // first fragments of the tile's first chunk (the halo rows and LDS buffer 0 are in place behind a barrier)
+        set_asrc(0);
+        frags(0, 0, 0);
 
-        // chunk cc = slab * 9 + tap.  Iteration: register set (tap + 1) % 3 (chunk cc + 1, requested two iterations ago) goes
-        // to LDS buffer (gcc + 1) & 1; set tap % 3 (chunk cc, already in LDS) is re-used for the request of chunk cc + 3;
-        // matrix instructions of chunk cc on buffer gcc & 1; one barrier.  The last tap of a slab also fetches the next halo (next slab, or slab 0 of this
-        // workgroup's next tile) into registers during its matrix phase.
+        // chunk cc = slab * 9 + tap, on LDS buffer tap % 3.  The last tap of a slab also fetches the next halo (next slab, or
+        // slab 0 of this workgroup's next tile) into registers during its matrix phase.
 #pragma unroll 1
         for (int slab = 0; slab < NS; ++slab)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int cc = slab * 9 + tap;
-            const int toff = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
             const bool last = cc == NCH - 1;
-            if constexpr (!(ABL & 1)) {
-                b_write(rb[(tap + 1) % 3], (gcc + 1) & 1);
-                b_issue(rb[tap % 3], cc + 3 < NCH ? cc + 3 : cc + 3 - NCH);
-            }
+            if constexpr (!(ABL & 1)) b_issue(rb[tap % 3], cc + 3 < NCH ? cc + 3 : cc + 3 - NCH);  // set tap % 3 went to LDS two chunks ago
             const bool sw = tap == 8 && (!last || more);
             if (tap == 8) {
                 if constexpr (!(ABL & 2))
                     if (sw) halo_issue(hreg, last ? m0n : m0, last ? 0 : slab + 1);
             }
             __builtin_amdgcn_sched_barrier(0);  // the global loads stay ahead of the matrix phase they fly under
-
-            const char *const bsrc = bbuf + (gcc & 1) * kPlBBytes + b_rd;
-            const char *asrc[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = ((mask[i] >> tap) & 1u) ? lrow[i] + toff : T;
-                asrc[i] = halo + r * kPlRowB + kh * 16;
-            }
-            pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
-            auto frags = [&](int ks, int st) __attribute__((always_inline)) {
-                wh[st] = *reinterpret_cast<const pl_u32x4 *>(bsrc + ks * 32);
-                wl[st] = *reinterpret_cast<const pl_u32x4 *>(bsrc + 128 + ks * 32);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(asrc[i] + ks * 32);
-                    xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(asrc[i] + 128 + ks * 32);
-                }
-            };
-            if constexpr (ABL & 16) {  // stale-register operands, kept opaque
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    wh[st] = wl[st] = rb[0][st];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) xh[st][i] = xl[st][i] = rb[1 + i][st];
-                }
-            } else
-            frags(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int st = ks & 1;
-                if constexpr (!(ABL & 16))
-                if (ks < 3) frags(ks + 1, st ^ 1);
+                // request the NEXT k-step's fragments (for k-step 3: k-step 0 of the next chunk, unless the halo rows are
+                // about to change), then this k-step's matrix instructions -- in that order, pinned
+                if (ks < 3) {
+                    frags(tap % 3, ks + 1, st ^ 1);
+                } else if (tap != 8) {
+                    set_asrc(tap + 1);
+                    frags((tap + 1) % 3, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 8)) {
-                // the three piece products, smallest first, the two pixel blocks interleaved (two independent chains)
-                acc[0] = mma(acc[0], wh[st], xl[st][0]);
-                acc[1] = mma(acc[1], wh[st], xl[st][1]);
-                acc[0] = mma(acc[0], wl[st], xh[st][0]);
-                acc[1] = mma(acc[1], wl[st], xh[st][1]);
-                acc[0] = mma(acc[0], wh[st], xh[st][0]);
-                acc[1] = mma(acc[1], wh[st], xh[st][1]);
+                    // the three piece products, smallest first, the two pixel blocks interleaved (two independent chains)
+                    acc[0] = mma(acc[0], wh[st], xl[st][0]);
+                    acc[1] = mma(acc[1], wh[st], xl[st][1]);
+                    acc[0] = mma(acc[0], wl[st], xh[st][0]);
+                    acc[1] = mma(acc[1], wl[st], xh[st][1]);
+                    acc[0] = mma(acc[0], wh[st], xh[st][0]);
+                    acc[1] = mma(acc[1], wh[st], xh[st][1]);
                 } else {
                     acc[0][ks] += __uint_as_float(wh[st][0] ^ xl[st][0][1] ^ xh[st][1][2] ^ wl[st][3]);  // keep the reads alive
                 }
-            }
-            ++gcc;
-            __builtin_amdgcn_sched_barrier(0);  // no fragment reads of the next tap hoisted above this point (register pressure)
-            if (!last) {
-                if (tap == 8) {  // slab switch inside the tile
-                    lds_barrier();  // every wave has finished reading the old slab
-                    if constexpr (!(ABL & 2)) halo_write(hreg);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 1) {
+                    // the chunk's one barrier: every wave is past the previous chunk, whose LDS buffer (tap + 2) % 3 now takes
+                    // chunk cc + 2 (requested at the top of the previous chunk); it is first read at the end of chunk cc + 1
+                    // (a bare s_barrier: nothing of this wave has to drain -- the reads in flight are this chunk's own prefetch, and
+                    // its last LDS writes are a whole chunk old, behind reads that have long returned)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if constexpr (!(ABL & 1)) b_write(rb[(tap + 2) % 3], (tap + 2) % 3);
                 }
-                if constexpr (!(ABL & 32)) lds_barrier();
+            }
+            if (tap == 8 && !last) {  // slab switch inside the tile
+                lds_barrier();        // every wave has finished reading the old slab
+                if constexpr (!(ABL & 2)) halo_write(hreg);
+                lds_barrier();
+                set_asrc(0);
+                frags(0, 0, 0);
             }
             trace(10 + tap);
         }

@@ -1,8 +1,7 @@
 // tools/conv_probe.hip -- phase ablation of conv3x3_planes_kernel (run on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 tools/conv_probe.hip -o /tmp/conv_probe && /tmp/conv_probe
 // Times the kernel on the three residual-block shapes of a B=256 full-alignment batch, whole and with parts switched off
-// (ABL bits: 1 no weight loads, 2 no halo loads after the first tile, 4 no epilogue, 8 no matrix instructions, 16 no LDS
-// fragment reads, 32 no per-chunk barrier), and at several grid sizes.  Numbers only -- correctness is the parity tests' job.
+// (ABL bits: 1 no weight loads, 2 no halo loads after the first tile, 4 no epilogue, 8 no matrix instructions), and at several grid sizes.  Numbers only -- correctness is the parity tests' job.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -64,11 +63,7 @@ template <int C> static int shape(const char *name, int B, int H, int W, int slo
     printf("  no epilogue                  %6.1f us\n", run<C, 4>(cp, g));
     printf("  no loads, no epilogue        %6.1f us\n", run<C, 7>(cp, g));
     printf("  no MFMA                      %6.1f us\n", run<C, 8>(cp, g));
-    printf("  no LDS fragment reads        %6.1f us\n", run<C, 16>(cp, g));
-    printf("  MFMA + barriers only         %6.1f us\n", run<C, 23>(cp, g));
-    printf("  MFMA only (no barriers)      %6.1f us\n", run<C, 55>(cp, g));
     printf("  MFMA + LDS reads + barriers  %6.1f us\n", run<C, 7>(cp, g));
-    printf("  no per-chunk barrier (racy)  %6.1f us\n", run<C, 32>(cp, g));
     for (int s : {slots / 2}) printf("  full at grid %4d            %6.1f us\n", grid_for(s), run<C, 0>(cp, grid_for(s)));
     {   // shader-clock trace of workgroups 0 and 301, wave 0 (RES = false: p.res is the trace buffer)
         long long *tb; CK(hipMalloc(&tb, 2 * 256 * 16)); CK(hipMemset(tb, 0, 2 * 256 * 16));
