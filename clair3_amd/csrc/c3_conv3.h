@@ -13,22 +13,26 @@
 // products per 32x32x16 block) the matrix pipe is 5x cheaper and the vector work is what bounds the kernel (16 % MFMA-busy,
 // profiles/r01_q_pmc_sq.md).  The direct form has NO per-value vector work in its loop: operands go LDS -> register -> MFMA.
 //
-// One workgroup = 128 consecutive output pixels (flattened over batch, rows, columns) x 64 output channels:
-//  * the input pixels all nine taps of those 128 outputs touch are the flat range [m0 - W - 1, m0 + 127 + W + 1] -- ONE
-//    contiguous run of pixel rows.  For each 64-channel slab it is loaded into LDS once (164 rows x 256 B for W = 17) and
+// One workgroup (512 threads, one per CU, persistent over tiles) = 256 consecutive output pixels (flattened over batch,
+// rows, columns) x 64 output channels:
+//  * the input pixels all nine taps of those 256 outputs touch are the flat range [m0 - W - 1, m0 + 255 + W + 1] -- ONE
+//    contiguous run of pixel rows.  For each 64-channel slab it is loaded into LDS once (292 rows x 256 B for W = 17) and
 //    every tap reads it at a row offset dh*W + dw; taps that fall off the window (top/bottom row, left/right column, other
 //    window) are redirected to an all-zero row by a per-lane 9-bit mask -- no im2col, 9x less A traffic than the tiled GEMM;
-//  * weights stream through LDS one (slab, tap) chunk at a time: 64 couts x 64 channels x 2 pieces = 16 KB, double buffered,
-//    global loads two chunks ahead (register stage), one barrier per chunk = per 24 matrix instructions of every wave;
+//  * weights stream through LDS one (slab, tap) chunk at a time: 64 couts x 64 channels x 2 pieces = 16 KB, three LDS
+//    buffers and three register sets, one bare barrier in the middle of a chunk; fragment reads run one k-step ahead of the
+//    matrix instructions, across chunk boundaries too (see the prologue comment in the kernel);
 //  * LDS rows are 272 B apart (256 B of data + 16 B pad): the ds_read_b128 of 16 consecutive rows covers all 64 banks once,
 //    and the (piece, k-step) position inside a row is an immediate offset -- the loop has no address arithmetic besides one
 //    select + multiply per tap;
-//  * waves are 2 (pixels) x 2 (couts): 64 x 32 outputs each = two 32x32 accumulators, weights as the FIRST matrix operand, so a
-//    lane ends up with 4 consecutive output channels of one pixel: the epilogue adds bias (+ residual), applies ReLU, splits
-//    into the two fp16 pieces and stores 8 bytes per plane;
-//  * 79.7 KB of LDS and <= 256 registers: two workgroups per CU, one hides the other's prologue and epilogue;
-//  * every barrier is an LDS-only barrier (lds_barrier: s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() also waits for
-//    the epilogue's global stores and for every prefetch load in flight (vmcnt(0)): measured 24 of 64 us per launch.
+//  * waves are 4 (pixels) x 2 (couts): 64 x 32 outputs each = two 32x32 accumulators, weights as the FIRST matrix operand, so a
+//    lane ends up with 4 consecutive output channels of one pixel; the epilogue adds the bias, sends the tile through LDS and
+//    leaves as (pixel, 8-channel) items: residual, ReLU, split into the two fp16 pieces, two 16-byte stores (8 lanes per
+//    128-byte plane row);
+//  * 132 KB of LDS, <= 248 registers, no spills;
+//  * every barrier is LDS-only (lds_barrier / bare s_barrier): __syncthreads() also waits for the epilogue's global stores
+//    and for every prefetch load in flight (loads and stores retire through one in-order counter).
+// Measurements, history and what bounds the kernel (the power-limited matrix stream): DESIGN.md 3.2 / 3.8.
 #pragma once
 #include "c3_gemm.h"
 #include "c3_kernels.h"
@@ -41,7 +45,7 @@ constexpr int kPlBM = 256, kPlBN = 64;
 constexpr int kPlThreads = 512;                       // 8 waves: 4 (pixels) x 2 (couts), 64 x 32 outputs each
 constexpr int kPlRowB = 272;                           // LDS row stride
 constexpr int kPlMaxW = 17;                            // widest image the halo tile is sized for (45x17 stage of the ONT window)
-constexpr int kPlHaloRows = kPlBM + 2 * kPlMaxW + 2;   // 164
+constexpr int kPlHaloRows = kPlBM + 2 * kPlMaxW + 2;   // 292
 constexpr int kPlHaloBytes = (kPlHaloRows + 1) * kPlRowB;  // + the zero row
 constexpr int kPlBBytes = 64 * kPlRowB;
 constexpr int kPlHaloLoads = (kPlHaloRows * 16 + kPlThreads - 1) / kPlThreads;  // 16-byte pieces per thread
@@ -56,7 +60,7 @@ struct PlaneConvParams {
     uint32_t *range_flag;
     float post_scale;     // the weights are packed times a power of two (pick_wscale); undone here, exactly
     int M, H, W;
-    int tiles;            // ceil(M / 128) * (C / 64)
+    int tiles;            // ceil(M / 256) * (C / 64)
 };
 
 // split four fp32 values into their fp16 pieces and store them behind `off` (hi plane) / `off + 128` (lo plane)
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 
         // ---- epilogue.  Weights were the first operand: acc[i][e] = output pixel (lane & 31) of block i, channel
         // (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the wave's 32.  The tile crosses LDS once (the halo region is free now:
-        // 128 rows x 272 B of fp32) so that every global access of the epilogue is a full 16 bytes of 8 consecutive
+        // 256 rows x 272 B of fp32) so that every global access of the epilogue is a full 16 bytes of 8 consecutive
         // channels, 8 lanes per 128-byte plane row: (pixel, channel group) items, residual added, ReLU, split, two stores.
         lds_barrier();  // all waves are done with the halo rows
         trace(30);
