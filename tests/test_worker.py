@@ -124,3 +124,40 @@ def test_batches_equal_the_reference_generator(tmp_path):
         sys.path.remove(ref)
         for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")]:
             del sys.modules[k]
+
+
+@pytest.mark.gpu
+def test_windows_fed_straight_from_a_foreign_buffer(tmp_path):
+    """SURVEY 8f N2 remainder: libclair3 hands its tensors over as one calloc'ed int8 block (`fa_data.matrix`,
+    preprocess/CreateTensorFullAlignmentFromCffi.py:136-168, src/clair3_full_alignment_dwell.h:184-190) that the reference
+    copies into numpy before anything else.  The C ABI takes the block as it is: page-lock it once (c3_host_register) and submit
+    sub-ranges of it -- no numpy copy, no staging copy.  Rows against the oracle, registered == unregistered bit for bit."""
+    import ctypes as C
+    from clair3_amd import _lib
+    from clair3_amd.model import Clair3_F
+    from oracle import oracle
+    from tests import util
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=17)
+    m = Clair3_F(add_indel_length=True, predict=True).to("cuda:0")
+    m.load_state_dict(sd)
+    n, wbytes = 150, 89 * 33 * 8
+    x = syn.make_fa_windows(n, seed=18)
+    libc = C.CDLL(None)
+    libc.calloc.restype = C.c_void_p
+    libc.free.argtypes = [C.c_void_p]
+    block = libc.calloc(n * wbytes, 1)  # what calculate_clair3_full_alignment returns in fa_data.matrix
+    C.memmove(block, x.ctypes.data, n * wbytes)
+    L = _lib.lib()
+    _lib.check(L.c3_host_register(C.c_void_p(block), n * wbytes), "c3_host_register")
+    y = np.empty((n, 90), np.float32)
+    cuts = [0, 64, 65, 150]  # the reference's batches are slices of the block
+    for k, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
+        _lib.check(L.c3_predict_submit(m._handle, C.c_void_p(block + lo * wbytes), _lib.DTYPE_I8, hi - lo,
+                                       C.c_void_p(y.ctypes.data + lo * 90 * 4), k), "c3_predict_submit")
+    for k in range(3):
+        _lib.check(L.c3_predict_wait(m._handle, k), "c3_predict_wait")
+    assert util.assert_rows_match(y, oracle.fa_forward(sd, x, True), what="rows from the registered block") < 2e-5
+    assert np.array_equal(y, m.predict_numpy(x))
+    _lib.check(L.c3_host_unregister(C.c_void_p(block)), "c3_host_unregister")
+    assert L.c3_host_unregister(C.c_void_p(block)) != 0  # second time: not registered any more
+    libc.free(block)
