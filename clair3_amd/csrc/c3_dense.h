@@ -1,0 +1,182 @@
+// c3_dense.h -- C[M][N] (fp32) = A (plane activations, c3_conv3.h) x W^T + bias on v_mfma_f32_32x32x16_f16, fp16x3 products.
+//
+// Used for the LSTM2 input projection of Clair3_P (clair3/model.py:96-107,132-133: gx2 = h1 W_ih2^T + b_ih + b_hh for both
+// directions at once): M = 33 B rows of 256 features -> 1280 gate pre-activations, 21.6 MFLOP per window, the largest kernel
+// of the pileup step.  The tiled GEMM of c3_gemm.h spent 105 us on it at B = 1024 (32-channel chunks, 8-byte loads, operand
+// split in the loader, 12 matrix instructions per barrier and wave: MfmaUtil 27 %).  Here:
+//  * LSTM1 writes h1 as planes (hi / lo fp16 pieces, 64-channel slabs of 256 B), so both operands reach LDS as plain 16-byte
+//    copies: 4 + 4 pieces per thread and 64-channel chunk;
+//  * one workgroup (512 threads = 8 waves as 2 x 4, 64 x 32 outputs per wave, one per CU, persistent) = 128 x 128 tiles;
+//    K = 256 is four chunks per tile, so the chunk stream runs on across tiles: chunk g + 1 sits in registers while chunk g
+//    is multiplied, and goes to the other LDS buffer at the top of chunk g + 1;
+//  * fragment reads run one k-step ahead of the matrix instructions (pinned order, as in conv3x3_planes_kernel);
+//  * the finished tile leaves through the LDS buffer its last chunk occupied: (row, 8-column) items, two 16-byte stores,
+//    16 lanes per 512-byte row segment (173 MB of fp32 per 1024 windows: the store shape matters, c3_conv3.h).
+// LDS rows are 272 B apart (conflict-free ds_read_b128 of 16 consecutive rows, immediate (piece, k-step) offsets).
+#pragma once
+#include "c3_conv3.h"
+
+namespace c3 {
+
+constexpr int kDnBM = 128, kDnBN = 128, kDnThreads = 512;
+constexpr int kDnABytes = kDnBM * kPlRowB, kDnBBytes = kDnBN * kPlRowB;  // one 64-channel chunk of each operand
+constexpr int kDnStage = kDnABytes + kDnBBytes;                           // 69 632 B; two stages
+
+struct DensePlanesParams {
+    const void *a;      // plane activations [M][K/64][hi 64 | lo 64] fp16
+    const void *w;      // [N/128][K/64][128 rows][16 pieces of 16 B]: pieces 0-7 = hi of k 8g..8g+7 of the chunk, 8-15 = lo; times 2^s
+    const float *bias;  // [N]
+    float *c;           // [M][N] fp32
+    float post_scale;   // 2^-s
+    int M, N, K;
+    int tiles_n, tiles;  // N / 128, ceil(M / 128) * tiles_n
+};
+
+__global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanesParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
+    const int frow = lane & 31, kh = lane >> 5;
+    const int NK = p.K / 64;
+    const int G = gridDim.x;
+    const int rowb = (p.K / 64) * 256;  // bytes per row of A
+
+    const __amdgpu_buffer_rsrc_t arsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.a), 0, (uint32_t)((int64_t)p.M * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t crsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
+
+    // chunk stream of this workgroup: (tile v, v + G, ...) x (k chunk 0 .. NK - 1)
+    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
+        const int tile = xcd_tile_index(v, p.tiles);
+        const int tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+        m0 = tm * kDnBM;
+    };
+    // this thread's four pieces of each operand chunk: piece idx = tid + 512 j -> row idx >> 4, position idx & 15
+    auto issue = [&](pl_u32x4 (&ra)[4], pl_u32x4 (&rb)[4], int m0, int tn, int kc) __attribute__((always_inline)) {
+        const char *wsrc = reinterpret_cast<const char *>(p.w) + ((size_t)tn * NK + kc) * (kDnBN * 256) + tid * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + kDnThreads * j;
+            const int m = m0 + (idx >> 4);
+            const uint32_t off = m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
+            ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
+            rb[j] = *reinterpret_cast<const pl_u32x4 *>(wsrc + j * (kDnThreads * 16));
+        }
+    };
+    const int st_off = (tid >> 4) * kPlRowB + (tid & 15) * 16;  // 32 rows further per j
+    auto stage = [&](const pl_u32x4 (&ra)[4], const pl_u32x4 (&rb)[4], int buf) __attribute__((always_inline)) {
+        char *dst = smem + buf * kDnStage + st_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<pl_u32x4 *>(dst + j * 32 * kPlRowB) = ra[j];
+            *reinterpret_cast<pl_u32x4 *>(dst + kDnABytes + j * 32 * kPlRowB) = rb[j];
+        }
+    };
+    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+    };
+    const int a_rd[2] = {(wm * 64 + frow) * kPlRowB + kh * 16, (wm * 64 + 32 + frow) * kPlRowB + kh * 16};
+    const int b_rd = kDnABytes + (wn * 32 + frow) * kPlRowB + kh * 16;
+
+    int v = blockIdx.x;
+    if (v >= p.tiles) return;
+    int m0, tn;
+    tile_mn(v, m0, tn);
+    pl_u32x4 ra[4], rb[4];
+    issue(ra, rb, m0, tn, 0);
+    stage(ra, rb, 0);
+    // the chunk after the first: same tile if NK > 1, else the next tile's
+    int vq = v, m0q = m0, tnq = tn, kq = 1;  // (tile, chunk) of the chunk held in registers
+    if (kq == NK) {
+        kq = 0, vq = v + G;
+        if (vq < p.tiles) tile_mn(vq, m0q, tnq);
+    }
+    if (vq < p.tiles) issue(ra, rb, m0q, tnq, kq);
+    lds_barrier();
+
+    int g = 0;  // chunks done: the current chunk sits in LDS stage g & 1
+    for (;;) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int kc = 0; kc < NK; ++kc) {
+            const char *cur = smem + (g & 1) * kDnStage;
+            // the chunk in registers -> the other stage (its readers passed the barrier that ended the previous chunk), then
+            // the request for the chunk after it
+            const bool have_next = vq < p.tiles;
+            if (have_next) stage(ra, rb, (g + 1) & 1);
+            if (have_next) {
+                if (++kq == NK) {
+                    kq = 0, vq += G;
+                    if (vq < p.tiles) tile_mn(vq, m0q, tnq);
+                }
+                if (vq < p.tiles) issue(ra, rb, m0q, tnq, kq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
+            auto frags = [&](int ks, int st) __attribute__((always_inline)) {
+                wh[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + ks * 32);
+                wl[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + 128 + ks * 32);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + ks * 32);
+                    xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + 128 + ks * 32);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int st = ks & 1;
+                if (ks < 3) frags(ks + 1, st ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = mma(acc[0], wh[st], xl[st][0]);
+                acc[1] = mma(acc[1], wh[st], xl[st][1]);
+                acc[0] = mma(acc[0], wl[st], xh[st][0]);
+                acc[1] = mma(acc[1], wl[st], xh[st][1]);
+                acc[0] = mma(acc[0], wh[st], xh[st][0]);
+                acc[1] = mma(acc[1], wh[st], xh[st][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier();
+            ++g;
+        }
+        // ---- epilogue through the stage the tile's last chunk occupied ((g - 1) & 1; the next chunk is in the other one)
+        char *stg = smem + ((g - 1) & 1) * kDnStage;
+        constexpr int kRowE = 528;  // 128 columns x 4 B + 16 B pad: 16-byte accesses of consecutive rows land on different banks
+        static_assert(kDnBM * kRowE <= kDnStage, "staged tile must fit one stage");
+        const int cb0 = wn * 32 + 4 * kh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + tn * kDnBN + cb0 + 8 * q);
+                f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                *reinterpret_cast<f32x4 *>(stg + (wm * 64 + i * 32 + frow) * kRowE + (cb0 + 8 * q) * 4) = val;
+            }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + kDnThreads * j;
+            const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
+            const int m = m0 + r;
+            const pl_u32x4 a = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32);
+            const pl_u32x4 b = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32 + 16);
+            const uint32_t off = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + c8 * 8) * 4) : kPlOob;
+            __builtin_amdgcn_raw_buffer_store_b128(a, crsrc, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(b, crsrc, off + 16, 0, 0);
+        }
+        v += G;
+        if (v >= p.tiles) break;
+        tile_mn(v, m0, tn);
+        lds_barrier();  // the staged tile has been read; the next chunk's stage() may overwrite it
+    }
+}
+
+}  // namespace c3

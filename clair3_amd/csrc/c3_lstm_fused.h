@@ -28,6 +28,8 @@ struct LstmFusedParams {
                             // 128 W_ih[gate*H + wave*16 + (lane&15)][8 (lane>>4) + j] (0 beyond C); the kernel feeds x / 128
     float *hout;        // [B][T][2H]; column = dir*H + unit
     int B, T, C;
+    void *hplanes = nullptr;  // F16: write h as plane activations instead ([B*T][2H/64 slabs][hi 64 | lo 64] fp16, c3_conv3.h):
+                              // the two pieces the recurrence forms anyway, and what dense_planes_kernel (c3_dense.h) reads
 };
 
 constexpr int kFusedKS = 5;  // k-steps of 4 covering C <= 20 input channels
@@ -132,10 +134,16 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
     const __amdgpu_buffer_rsrc_t hrsrc =
         __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (uint32_t)((int64_t)p.B * p.T * 2 * H * 4), 0x00020000);
     uint32_t ho[4];  // byte offset of hout[window 4s+v][0][h_col]; windows beyond B are out of range (store dropped)
+    const bool planes = F16 && p.hplanes != nullptr;  // same bytes per (window, step): 2H x 4
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(planes ? p.hplanes : (void *)p.hout, 0,
+                                                                            (uint32_t)((int64_t)p.B * p.T * 2 * H * 4), 0x00020000);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int b = b0 + 4 * s + v;
-        ho[v] = b < p.B ? (uint32_t)((((int64_t)b * p.T) * (2 * H) + h_col) * 4) : 0x80000000u;
+        if (planes)  // hi piece of channel h_col: slab h_col >> 6, 2 bytes per channel; the lo piece 128 bytes further
+            ho[v] = b < p.B ? (uint32_t)(((int64_t)b * p.T) * (2 * H) * 4 + (h_col >> 6) * 256 + (h_col & 63) * 2) : 0x80000000u;
+        else
+            ho[v] = b < p.B ? (uint32_t)((((int64_t)b * p.T) * (2 * H) + h_col) * 4) : 0x80000000u;
     }
     float xn[kFusedKS];
     if constexpr (F16P) load_x16(dir ? p.T - 1 : 0, xn16);
@@ -205,8 +213,15 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
             for (int e = 0; e < 2; ++e) {
                 if constexpr (F16) {
                     const _Float16 h0 = (_Float16)h[e];
+                    const _Float16 h1 = (_Float16)(h[e] - (float)h0);
                     *reinterpret_cast<_Float16 *>(hb16(cur ^ 1, 0, 4 * s + v + e, wave * 16 + col)) = h0;
-                    *reinterpret_cast<_Float16 *>(hb16(cur ^ 1, 1, 4 * s + v + e, wave * 16 + col)) = (_Float16)(h[e] - (float)h0);
+                    *reinterpret_cast<_Float16 *>(hb16(cur ^ 1, 1, 4 * s + v + e, wave * 16 + col)) = h1;
+                    if (planes) {
+                        const uint32_t o = ho[v + e] + (uint32_t)(t * 2 * H * 4);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h0), prsrc, o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), prsrc, o + 128, 0, 0);
+                        continue;
+                    }
                 } else {
                     hbuf[cur ^ 1][4 * s + v + e][wave * 16 + col] = h[e];
                 }

@@ -27,6 +27,7 @@
 #include "c3_host.h"
 #include "c3_conv3.h"
 #include "c3_comm.h"
+#include "c3_dense.h"
 
 using namespace c3;
 
@@ -193,6 +194,9 @@ struct c3_model {
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout
     float *l4_w3 = nullptr;                  // the same as three bf16 pieces (SPLIT path); env C3HIP_L4_SPLIT
     bool l4_split = true;
+    float *proj2_pw = nullptr;               // LSTM2 projection weights as dense_planes_kernel chunks (c3_dense.h); env C3HIP_PROJ2_PLANES
+    float proj2_pwscale = 1.f;
+    bool proj2_planes = true;
     float *proj2_w3 = nullptr;               // LSTM2 projection weights as bf16 pieces for the tiled SPLIT GEMM; env C3HIP_PROJ2_SPLIT
     bool proj2_split = true;
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
@@ -538,6 +542,26 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                                 pw[(size_t)(32 * cb + (lane & 31)) * Kp + 128 * (lane >> 5) + 4 * i + e];
             TRY(upload(m, &m->proj2_frag, pf));
             if (m->proj2_split) TRY(upload_split_pieces(m, &m->proj2_w3, pw, &m->proj2_wscale));
+            if (m->proj2_planes && m->split_kind == 2 && N % kDnBN == 0) {
+                // dense_planes_kernel: chunk (column tile of 128, k chunk of 64) = 128 rows x 256 B; piece g < 8 = hi of
+                // k 64 kc + 8 g .. + 7, g >= 8 = lo of the same k; times a power of two (pick_wscale)
+                const float sc = pick_wscale(pw.data(), pw.size());
+                m->proj2_pwscale = sc;
+                const int NKc = 256 / 64;
+                std::vector<float> pk((size_t)N * 256);
+                uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
+                for (int tn = 0; tn < N / kDnBN; ++tn)
+                    for (int kc = 0; kc < NKc; ++kc)
+                        for (int r = 0; r < kDnBN; ++r)
+                            for (int g = 0; g < 16; ++g)
+                                for (int j = 0; j < 8; ++j) {
+                                    const float v = pw[(size_t)(tn * kDnBN + r) * Kp + kc * 64 + 8 * (g & 7) + j] * sc;  // exact
+                                    const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                    const _Float16 piece = g < 8 ? h0 : h1;
+                                    memcpy(&q16[(((((size_t)tn * NKc + kc) * kDnBN + r) * 16 + g) * 8) + j], &piece, 2);
+                                }
+                TRY(upload(m, &m->proj2_pw, pk));
+            }
         }
         TRY(upload(m, &m->proj_w[layer], pw));
         TRY(upload(m, &m->proj_b[layer], pb));
@@ -1094,6 +1118,10 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     const int M = (int)(n * Tn);
     const bool fused1 = m->lstm1_fused && m->l1_wih != nullptr;
     if (starts && !fused1) return fail("region gathering needs the fused LSTM1 kernel (input_channels <= 20, C3HIP_LSTM1_FUSED != 0)");
+    // LSTM1 -> planes -> dense_planes_kernel (c3_dense.h) whenever the fp16x3 fused LSTM1 runs and the projection is packed for it
+    const bool h1_planes = fused1 && m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16) && m->proj2_planes &&
+                           m->proj2_pw && m->lstm2_v2;
+    m->last_planes = h1_planes;
     if (fused1) {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
         {
@@ -1105,6 +1133,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         LstmFusedParams<T> lp{x, starts, m->l1_wih, m->l1_bias, m->whh[0], reinterpret_cast<const uint32_t *>(m->l1_wih16), m->h1, (int)n, Tn, m->C};
         if (m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16)) {
             lp.whh = m->whh16[0];
+            if (h1_planes) lp.hplanes = m->h1;  // h1 leaves as fp16 piece planes for dense_planes_kernel
             hipLaunchKernelGGL((lstm1_fused_kernel<T, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
         } else {
             hipLaunchKernelGGL(lstm1_fused_kernel<T>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
@@ -1125,9 +1154,16 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.proj2", 2.0 * M * 1280.0 * 256.0, 4.0 * M * (256.0 + 1280.0));
-        const bool p2f16 = m->f16_ok && m->proj2_split && m->proj2_w3 && m->lstm2_v2;
-        ps.mfma(2.0 * ((M + 127) / 128 * 128) * 1280.0 * 256.0 * (p2f16 ? (m->split_kind == 1 ? 6 : 3) : 1), p2f16);
-        if (p2f16) {
+        const bool p2f16 = h1_planes || (m->f16_ok && m->proj2_split && m->proj2_w3 && m->lstm2_v2);
+        ps.mfma(2.0 * ((M + 127) / 128 * 128) * 1280.0 * 256.0 * (p2f16 ? (m->split_kind == 1 && !h1_planes ? 6 : 3) : 1), p2f16);
+        if (h1_planes) {
+            DensePlanesParams dp;
+            dp.a = m->h1, dp.w = m->proj2_pw, dp.bias = m->proj_b[1], dp.c = m->gx2, dp.post_scale = 1.f / m->proj2_pwscale;
+            dp.M = M, dp.N = 1280, dp.K = 256, dp.tiles_n = 1280 / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
+            const int grid = std::min(dp.tiles, m->wg_slots / 2);
+            hipLaunchKernelGGL(dense_planes_kernel, dim3(grid), dim3(kDnThreads), 0, s, dp);
+            HIP_TRY(hipGetLastError());
+        } else if (p2f16) {
             DenseLoaderParams lp{m->h1, 256};
             EpilogueParams ep{m->gx2, m->proj_b[1], nullptr, 1280, 0};
             ep.post_scale = 1.f / m->proj2_wscale;
@@ -1293,6 +1329,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_SPLIT_KIND")) m->split_kind = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("C3HIP_WINOGRAD_F16MASK")) m->wino_f16_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_PROJ2_SPLIT")) m->proj2_split = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_PROJ2_PLANES")) m->proj2_planes = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_PROJ2_STREAM")) m->proj2_stream = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_DIRECT")) m->conv1_direct = atoi(e) != 0;
@@ -1752,7 +1789,7 @@ int c3_model_destroy(c3_model *m) {
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
                    m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias,
-                   m->conv1_wfrag, m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3};
+                   m->conv1_wfrag, m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3, m->proj2_pw};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     if (m->decode_dev) (void)hipFree(m->decode_dev);
@@ -1826,9 +1863,9 @@ int c3_debug_fetch(c3_model *m, const char *name, float *host_out, int64_t n_flo
     if (!src) return fail("unknown debug tensor \"%s\"", name);
     if (n != n_floats) return fail("debug tensor %s has %lld floats, caller expects %lld", name, (long long)n, (long long)n_floats);
     HIP_TRY(hipDeviceSynchronize());
-    if (m->kind == C3_KIND_FULL_ALIGNMENT && m->last_planes && s.compare(0, 3, "act") == 0) {
+    if (m->last_planes && ((m->kind == C3_KIND_FULL_ALIGNMENT && s.compare(0, 3, "act") == 0) || (m->kind == C3_KIND_PILEUP && s == "lstm1_out"))) {
         // the layer holds plane activations (c3_conv3.h): hand the caller the fp32 values they stand for
-        const int C = kConvCout[s[3] - '0'];
+        const int C = m->kind == C3_KIND_PILEUP ? 256 : kConvCout[s[3] - '0'];
         float *tmp = nullptr;
         HIP_TRY(hipMalloc((void **)&tmp, (size_t)n * sizeof(float)));
         hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const void *)src, tmp, n / C, C);

@@ -554,7 +554,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
         util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f, what=f"FA {env}")
         for k in env:
             monkeypatch.delenv(k)
-    for env in [{"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
+    for env in [{"C3HIP_PROJ2_PLANES": "0"}, {"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
                 {"C3HIP_PROJ2_SPLIT": "0"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"},
                 {"C3HIP_LSTM1_F16": "0"}, {"C3HIP_LSTM2_F16": "0"},
                 {"C3HIP_LSTM1_F16": "0", "C3HIP_LSTM2_F16": "0", "C3HIP_PROJ2_SPLIT": "0", "C3HIP_L4_SPLIT": "0"}]:
