@@ -140,11 +140,21 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int b = b0 + 4 * s + v;
-        if (planes)  // hi piece of channel h_col: slab h_col >> 6, 2 bytes per channel; the lo piece 128 bytes further
-            ho[v] = b < p.B ? (uint32_t)(((int64_t)b * p.T) * (2 * H) * 4 + (h_col >> 6) * 256 + (h_col & 63) * 2) : 0x80000000u;
-        else
-            ho[v] = b < p.B ? (uint32_t)((((int64_t)b * p.T) * (2 * H) + h_col) * 4) : 0x80000000u;
+        ho[v] = b < p.B ? (uint32_t)((((int64_t)b * p.T) * (2 * H) + h_col) * 4) : 0x80000000u;
     }
+    // planes: the step's h tile (16 windows x H units, two pieces) already sits in LDS in plane order; one step later -- behind
+    // the barrier that publishes it -- every thread copies ONE 16-byte piece of it to global memory: thread (piece, window,
+    // 8-unit group) -> 8 lanes per 128-byte plane row, instead of eight scattered 2-byte stores per thread and step
+    static_assert(!F16 || H == 128, "the plane copy assumes 512 threads = 2 pieces x 16 windows x 16 groups of 8 units");
+    const int cp_p = tid >> 8, cp_r = (tid >> 4) & 15, cp_c = tid & 15;
+    const uint32_t cp_off = planes && b0 + cp_r < p.B
+                                ? (uint32_t)(((int64_t)(b0 + cp_r) * p.T) * (2 * H) * 4 + (dir * 2 + (cp_c >> 3)) * 256 + cp_p * 128 + (cp_c & 7) * 16)
+                                : 0x80000000u;
+    auto copy_planes = [&](int buf, int t) __attribute__((always_inline)) {
+        typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
+        const u32x4c d = *reinterpret_cast<const u32x4c *>(hb16(buf, cp_p, cp_r, 8 * cp_c));
+        __builtin_amdgcn_raw_buffer_store_b128(d, prsrc, cp_off + (uint32_t)(t * 2 * H * 4), 0, 0);
+    };
     float xn[kFusedKS];
     if constexpr (F16P) load_x16(dir ? p.T - 1 : 0, xn16);
     else load_x(dir ? p.T - 1 : 0, xn);
@@ -216,12 +226,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
                     const _Float16 h1 = (_Float16)(h[e] - (float)h0);
                     *reinterpret_cast<_Float16 *>(hb16(cur ^ 1, 0, 4 * s + v + e, wave * 16 + col)) = h0;
                     *reinterpret_cast<_Float16 *>(hb16(cur ^ 1, 1, 4 * s + v + e, wave * 16 + col)) = h1;
-                    if (planes) {
-                        const uint32_t o = ho[v + e] + (uint32_t)(t * 2 * H * 4);
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h0), prsrc, o, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), prsrc, o + 128, 0, 0);
-                        continue;
-                    }
+                    if (planes) continue;  // copied out of LDS one step later (copy_planes)
                 } else {
                     hbuf[cur ^ 1][4 * s + v + e][wave * 16 + col] = h[e];
                 }
@@ -229,6 +234,8 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
             }
         }
         lds_barrier();
+        if constexpr (F16)
+            if (planes) copy_planes(cur ^ 1, t);  // the tile this step wrote; the next step writes the other buffer
     }
 }
 

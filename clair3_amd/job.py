@@ -83,10 +83,6 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
     cuts = shard_files(counts, world)
     mine = names[cuts[rank]:cuts[rank + 1]]
     per_rank = [int(sum(counts[cuts[r]:cuts[r + 1]])) for r in range(world)]
-    parent = os.path.dirname(list_fn)
-    sub_list = os.path.join(parent, f".rank{rank}_of_{world}.list")
-    with open(sub_list, "w") as f:
-        f.write("\n".join(mine) + ("\n" if mine else ""))
     rows, positions = [], []
 
     def take(pos, alt, y):
@@ -96,9 +92,8 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
             consume(pos, alt, y)
 
     t0 = time.perf_counter()
-    n_done = worker.predict_file_list(model, sub_list, take, batch_size=batch_size) if mine else 0
+    n_done = worker.predict_file_list(model, list_fn, take, batch_size=batch_size, first=cuts[rank], stop=cuts[rank + 1]) if mine else 0
     t_compute = time.perf_counter() - t0
-    os.unlink(sub_list)
     assert n_done == per_rank[rank]
     width = rows[0].shape[1] if rows else None
     y_local = np.concatenate(rows) if rows else None

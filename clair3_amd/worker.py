@@ -33,13 +33,14 @@ def read_info(path):
     return positions, alt_infos
 
 
-def iter_tensor_files(list_fn):
+def iter_tensor_files(list_fn, first=0, stop=None):
     """Yield (tensor, positions, alt_infos) for every entry of an ``--output_tensor_can_fn_list`` file; tensors are
-    memory-mapped.  Entries are relative to the list file's directory (CallVariantsFromCffi.py:112-113)."""
+    memory-mapped.  Entries are relative to the list file's directory (CallVariantsFromCffi.py:112-113).
+    ``first`` / ``stop`` restrict the walk to a contiguous run of entries (a rank's share of a sharded job)."""
     parent = os.path.dirname(list_fn)
     with open(list_fn, "r") as f:
         names = [n for n in f.read().strip().split("\n") if n != ""]
-    for name in names:
+    for name in names[first:stop]:
         tensor = np.load(os.path.join(parent, name + ".npy"), mmap_mode="r")
         positions, alt_infos = read_info(os.path.join(parent, name + ".info"))
         if len(tensor) != len(positions) or len(tensor) != len(alt_infos):
@@ -47,9 +48,9 @@ def iter_tensor_files(list_fn):
         yield tensor, positions, alt_infos
 
 
-def iter_batches(list_fn, batch_size):
+def iter_batches(list_fn, batch_size, first=0, stop=None):
     """Same batch boundaries as the reference: batches never span files, the last batch of a file is short."""
-    for tensor, positions, alt_infos in iter_tensor_files(list_fn):
+    for tensor, positions, alt_infos in iter_tensor_files(list_fn, first, stop):
         n = len(tensor)
         for lo in range(0, n, batch_size):
             hi = min(lo + batch_size, n)
@@ -88,6 +89,6 @@ def predict_batches(model, batches, consume, slots=3):
     return total
 
 
-def predict_file_list(model, list_fn, consume, batch_size=1000):
+def predict_file_list(model, list_fn, consume, batch_size=1000, first=0, stop=None):
     """The reference's GPU batch size is predictBatchSize * 5 = 1000 (CallVariantsFromCffi.py:265-269)."""
-    return predict_batches(model, iter_batches(list_fn, batch_size), consume)
+    return predict_batches(model, iter_batches(list_fn, batch_size, first, stop), consume)
