@@ -23,15 +23,24 @@ constexpr int kDnABytes = kDnBM * kPlRowB, kDnBBytes = kDnBN * kPlRowB;  // one 
 constexpr int kDnStage = kDnABytes + kDnBBytes;                           // 69 632 B; two stages
 
 struct DensePlanesParams {
-    const void *a;      // plane activations [M][K/64][hi 64 | lo 64] fp16
+    const void *a;      // plane activations [M][K/64][hi 64 | lo 64] fp16   (CONV: [B][Hin][Win][Cin/64][hi | lo])
     const void *w;      // [N/128][K/64][128 rows][16 pieces of 16 B]: pieces 0-7 = hi of k 8g..8g+7 of the chunk, 8-15 = lo; times 2^s
+                        // (CONV: k chunk kc = tap * (Cin/64) + slab, tap = kh * 3 + kw)
     const float *bias;  // [N]
-    float *c;           // [M][N] fp32
+    float *c;           // [M][N] fp32   (CONV: plane activations [M][N/64][hi | lo], bias + ReLU)
     float post_scale;   // 2^-s
     int M, N, K;
     int tiles_n, tiles;  // N / 128, ceil(M / 128) * tiles_n
+    // CONV: 3x3 / pad 1 / stride `stride` convolution as an implicit GEMM, M = B * Ho * Wo output pixels, K = 9 * Cin
+    int Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0, stride = 1;
+    uint32_t *range_flag = nullptr;
 };
 
+// CONV = false: the LSTM2 projection above.  CONV = true: the two stride-2 convolutions of Clair3_F (conv3, conv5;
+// clair3/model.py:382-387) on plane activations -- the same chunk stream with the A rows gathered per (tap, slab) from the
+// input pixels (out-of-window taps are out-of-range buffer offsets: zeros) and the epilogue of the plane pipeline (bias, ReLU,
+// split into fp16 pieces, range flag).  Replaces gemm_mfma_kernel<PlaneConvLoader> (32-channel chunks, 8-byte pieces).
+template <bool CONV = false>
 __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanesParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -40,12 +49,40 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
     const int frow = lane & 31, kh = lane >> 5;
     const int NK = p.K / 64;
     const int G = gridDim.x;
-    const int rowb = (p.K / 64) * 256;  // bytes per row of A
+    const int rowb = CONV ? p.Cin * 4 : (p.K / 64) * 256;  // bytes per row (pixel) of A
+    const int nsin = CONV ? p.Cin / 64 : 1;
 
-    const __amdgpu_buffer_rsrc_t arsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.a), 0, (uint32_t)((int64_t)p.M * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(p.a), 0, CONV ? (uint32_t)((int64_t)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win * rowb) : (uint32_t)((int64_t)p.M * rowb), 0x00020000);
     const __amdgpu_buffer_rsrc_t crsrc =
         __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
+    // CONV: input pixel (b, oh * stride - 1, ow * stride - 1) and tap validity of this thread's four rows of the tile whose
+    // chunks are being requested (recomputed when the request stream moves on to the next tile)
+    int rbase[4] = {0, 0, 0, 0};
+    uint32_t rmask[4] = {0u, 0u, 0u, 0u};
+    auto row_info = [&](int m0) __attribute__((always_inline)) {
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + (tid >> 4) + 32 * j;
+                uint32_t mk = 0;
+                int base = 0;
+                if (m < p.M) {
+                    const int b = m / hw, rem = m - b * hw;
+                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                    const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
+                    base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int ih = ih0 + t / 3, iw = iw0 + t % 3;
+                        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
+                    }
+                }
+                rbase[j] = base, rmask[j] = mk;
+            }
+        }
+    };
 
     // chunk stream of this workgroup: (tile v, v + G, ...) x (k chunk 0 .. NK - 1)
     auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
@@ -61,7 +98,14 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
         for (int j = 0; j < 4; ++j) {
             const int idx = tid + kDnThreads * j;
             const int m = m0 + (idx >> 4);
-            const uint32_t off = m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
+            uint32_t off;
+            if constexpr (CONV) {
+                const int tap = kc / nsin, slab = kc - tap * nsin;
+                const int kh3 = tap / 3, kw3 = tap - 3 * kh3;
+                off = ((rmask[j] >> tap) & 1u) ? (uint32_t)(rbase[j] + (kh3 * p.Win + kw3) * rowb + slab * 256 + (idx & 15) * 16) : kPlOob;
+            } else {
+                off = m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
+            }
             ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
             rb[j] = *reinterpret_cast<const pl_u32x4 *>(wsrc + j * (kDnThreads * 16));
         }
@@ -85,6 +129,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
     if (v >= p.tiles) return;
     int m0, tn;
     tile_mn(v, m0, tn);
+    row_info(m0);
     pl_u32x4 ra[4], rb[4];
     issue(ra, rb, m0, tn, 0);
     stage(ra, rb, 0);
@@ -92,12 +137,16 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
     int vq = v, m0q = m0, tnq = tn, kq = 1;  // (tile, chunk) of the chunk held in registers
     if (kq == NK) {
         kq = 0, vq = v + G;
-        if (vq < p.tiles) tile_mn(vq, m0q, tnq);
+        if (vq < p.tiles) {
+            tile_mn(vq, m0q, tnq);
+            row_info(m0q);
+        }
     }
     if (vq < p.tiles) issue(ra, rb, m0q, tnq, kq);
     lds_barrier();
 
     int g = 0;  // chunks done: the current chunk sits in LDS stage g & 1
+    float omax = 0.f;
     for (;;) {
         f32x16 acc[2];
 #pragma unroll
@@ -113,7 +162,10 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
             if (have_next) {
                 if (++kq == NK) {
                     kq = 0, vq += G;
-                    if (vq < p.tiles) tile_mn(vq, m0q, tnq);
+                    if (vq < p.tiles) {
+                        tile_mn(vq, m0q, tnq);
+                        row_info(m0q);
+                    }
                 }
                 if (vq < p.tiles) issue(ra, rb, m0q, tnq, kq);
             }
@@ -166,17 +218,38 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
             const int idx = tid + kDnThreads * j;
             const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
             const int m = m0 + r;
-            const pl_u32x4 a = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32);
-            const pl_u32x4 b = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32 + 16);
-            const uint32_t off = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + c8 * 8) * 4) : kPlOob;
-            __builtin_amdgcn_raw_buffer_store_b128(a, crsrc, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(b, crsrc, off + 16, 0, 0);
+            if constexpr (CONV) {
+                f32x4 a = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32);
+                f32x4 b = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32 + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = __int_as_float(max(__float_as_int(a[e]), 0));  // ReLU on the bit pattern
+                    b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
+                }
+                omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+                u32x2 pa[2], pb[2];
+                split2_f16(a, pa);
+                split2_f16(b, pb);
+                const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+                const int n = tn * kDnBN + c8 * 8;  // channel: slab n >> 6, hi piece at 2 (n & 63), lo piece 128 bytes further
+                const uint32_t off = m < p.M ? (uint32_t)m * (uint32_t)(p.N * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : kPlOob;
+                __builtin_amdgcn_raw_buffer_store_b128(hi, crsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, crsrc, off + 128, 0, 0);
+            } else {
+                const pl_u32x4 a = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32);
+                const pl_u32x4 b = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32 + 16);
+                const uint32_t off = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + c8 * 8) * 4) : kPlOob;
+                __builtin_amdgcn_raw_buffer_store_b128(a, crsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(b, crsrc, off + 16, 0, 0);
+            }
         }
         v += G;
         if (v >= p.tiles) break;
         tile_mn(v, m0, tn);
         lds_barrier();  // the staged tile has been read; the next chunk's stage() may overwrite it
     }
+    if constexpr (CONV)
+        if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
 }
 
 }  // namespace c3

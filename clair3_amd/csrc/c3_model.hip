@@ -160,8 +160,10 @@ struct c3_model {
     float *wino_v[9] = {};   // Winograd-domain weights of the stride-1 convs (layers 1,2,4,5,7,8)
     float *wino_v16[9] = {};  // the same as two fp16 pieces per weight, fragment order of the F16 persistent kernel (c3_wino_p.h)
     unsigned wino_f16_mask = 0x1b6;  // Winograd layers on the fp16x3 split products; env C3HIP_WINOGRAD_F16MASK
-    float *pconv_w[9] = {};  // stride-1 convs for conv3x3_planes_kernel (c3_conv3.h): [Cout/64][Cin/64][9][64][16 pieces of 16 B]
+    float *pconv_w[9] = {};  // stride-1 convs for conv3x3_planes_kernel (c3_conv3.h): [Cout/64][Cin/64][9][64][16 pieces of 16 B];
+                             // stride-2 convs for dense_planes_kernel<true> (c3_dense.h): [Cout/128][9 Cin/64][128][16 pieces]
     float pconv_wscale[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+    bool conv_s2_planes = true;  // conv3 / conv5 on dense_planes_kernel<true> (c3_dense.h); env C3HIP_CONV_S2_PLANES=0: tiled GEMM with PlaneConvLoader
     bool fa_planes = true;   // plane activations + direct fp16x3 convolutions (c3_conv3.h); env C3HIP_FA_PLANES=0 restores the fp32-activation kernels of round 1
     bool last_planes = false;  // the last full-alignment forward left plane activations in act[] (c3_debug_fetch converts)
     float *conv_w3[9] = {};  // direct-conv weights as three bf16 pieces [3][Cout][K] (uint16 payload), layers in conv_split_mask
@@ -760,6 +762,26 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                             }
         TRY(upload(m, &m->pconv_w[l], pk));
     }
+    if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kDnBN == 0 && m->fa_planes && m->conv_s2_planes && m->split_kind == 2) {
+        // dense_planes_kernel<true>: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
+        const int NS = Cin / 64, NKc = 9 * NS;
+        const float sc = pick_wscale(pw.data(), pw.size());
+        m->pconv_wscale[l] = sc;
+        std::vector<float> pk((size_t)Cout * NKc * 64);
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
+        for (int tn = 0; tn < Cout / kDnBN; ++tn)
+            for (int kc = 0; kc < NKc; ++kc)
+                for (int r = 0; r < kDnBN; ++r)
+                    for (int g = 0; g < 16; ++g)
+                        for (int j = 0; j < 8; ++j) {
+                            const int tap = kc / NS, slab = kc % NS;
+                            const float v = pw[(size_t)(tn * kDnBN + r) * ldb + (size_t)tap * Cin + slab * 64 + 8 * (g & 7) + j] * sc;  // exact
+                            const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                            const _Float16 piece = g < 8 ? h0 : h1;
+                            memcpy(&q16[(((((size_t)tn * NKc + kc) * kDnBN + r) * 16 + g) * 8) + j], &piece, 2);
+                        }
+        TRY(upload(m, &m->pconv_w[l], pk));
+    }
     if (kConvStride[l] == 1 && Cin % kWinoBK == 0 && Cout % kWinoNT == 0) {
         // Winograd F(2x2,3x3) weights V = G g' G^T (g' = BN-folded), in MFMA B-fragment order
         //   [Cout/32][xi = 4i+j][Cin/16][g][lane][e] = V_xi[n = nt*32 + (lane&31)][k = 16c + 8g + 4(lane>>5) + e]
@@ -899,7 +921,7 @@ static bool fa_planes_ok(const c3_model *m) {
     for (int l : {1, 2, 4, 5, 7, 8})
         if (!m->pconv_w[l] || ww[l] > kPlMaxW) return false;
     for (int l : {3, 6})
-        if (!m->conv_w3[l]) return false;
+        if (!m->conv_w3[l] && !m->pconv_w[l]) return false;
     if (m->C == 8 ? !(m->conv1_direct && m->conv1_f16 && m->conv1_wfrag16) : !m->conv_w3[0]) return false;
     return true;
 }
@@ -929,6 +951,15 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             EpilogueParams ep{m->act[0], m->conv_b[0], nullptr, Cout, 0};
             ep.post_scale = 1.f / m->conv_wscale[0], ep.range_flag = m->range_flag;
             TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU_PLANES, 128, 64, 2>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep, m->conv_w3[0])));
+        } else if (kConvStride[l] == 2 && m->pconv_w[l]) {
+            DensePlanesParams dp;
+            dp.a = m->act[l - 1], dp.w = m->pconv_w[l], dp.bias = m->conv_b[l], dp.c = m->act[l], dp.post_scale = 1.f / m->pconv_wscale[l];
+            dp.M = M, dp.N = Cout, dp.K = 9 * cin, dp.tiles_n = Cout / kDnBN, dp.tiles = (M + kDnBM - 1) / kDnBM * dp.tiles_n;
+            dp.Hin = hh[l], dp.Win = ww[l], dp.Cin = cin, dp.Ho = hh[l + 1], dp.Wo = ww[l + 1], dp.stride = 2, dp.range_flag = m->range_flag;
+            ps.mfma(2.0 * ((M + kDnBM - 1) / kDnBM * kDnBM) * (double)Cout * 9.0 * cin * 3, true);
+            const int grid = std::min(dp.tiles, m->wg_slots / 2);  // one 512-thread workgroup (136 KB of LDS) per CU
+            hipLaunchKernelGGL(dense_planes_kernel<true>, dim3(grid), dim3(kDnThreads), 0, s, dp);
+            HIP_TRY(hipGetLastError());
         } else if (kConvStride[l] == 2) {
             ps.mfma(2.0 * ((M + 127) / 128 * 128) * (double)Cout * 9.0 * cin * 3, true);
             PlaneConvLoaderParams lp{m->act[l - 1], m->zeros, hh[l], ww[l], cin, hh[l + 1], ww[l + 1], 2, cin / kBK};
@@ -1161,7 +1192,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             dp.a = m->h1, dp.w = m->proj2_pw, dp.bias = m->proj_b[1], dp.c = m->gx2, dp.post_scale = 1.f / m->proj2_pwscale;
             dp.M = M, dp.N = 1280, dp.K = 256, dp.tiles_n = 1280 / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
             const int grid = std::min(dp.tiles, m->wg_slots / 2);
-            hipLaunchKernelGGL(dense_planes_kernel, dim3(grid), dim3(kDnThreads), 0, s, dp);
+            hipLaunchKernelGGL(dense_planes_kernel<false>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             HIP_TRY(hipGetLastError());
         } else if (p2f16) {
             DenseLoaderParams lp{m->h1, 256};
@@ -1346,6 +1377,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_CONV1_F16")) m->conv1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_FA_PLANES")) m->fa_planes = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_CONV_S2_PLANES")) m->conv_s2_planes = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
         fail("hipMalloc(zero page) failed");
         c3_model_destroy(m);
