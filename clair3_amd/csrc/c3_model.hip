@@ -1605,7 +1605,12 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
     if (batch < 0 || n_cols < 0) return fail("negative size");
     if (batch == 0) return 0;
     if (!region_host || !starts_host || !y_host) return fail("null buffer");
-    if (x_dtype != C3_DTYPE_I8 && x_dtype != C3_DTYPE_I32) return fail("pileup regions must be int8 or int32");
+    if (x_dtype != C3_DTYPE_I8 && x_dtype != C3_DTYPE_I32 && x_dtype != C3_DTYPE_I64)
+        return fail("pileup regions must be int8, int32 or int64 / size_t (got dtype %d)", x_dtype);
+    // int64 = plp_data.matrix itself (size_t counts, src/clair3_pileup.h:113): narrowed to int32 on its way into the staging
+    // buffer, which is what the reference's PIPE mode feeds the model (CreateTensorPileupFromCffi.py:143-146 -> int32 windows)
+    const bool narrow = x_dtype == C3_DTYPE_I64;
+    if (narrow) x_dtype = C3_DTYPE_I32;
     for (int64_t i = 0; i < batch; ++i)
         if (starts_host[i] < 0 || (int64_t)starts_host[i] + m->positions > n_cols)
             return fail("window %lld starts at column %d: outside the %lld-column region", (long long)i, starts_host[i], (long long)n_cols);
@@ -1618,7 +1623,13 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
     const size_t sb = (size_t)batch * sizeof(int32_t);
     const size_t yb = (size_t)batch * m->row * sizeof(float);
     TRY(ensure_slot(m, sl, rb + sb, yb));
-    memcpy(sl.pin_x, region_host, (size_t)n_cols * m->C * item);
+    if (narrow) {
+        const int64_t *src = static_cast<const int64_t *>(region_host);
+        int32_t *dst = static_cast<int32_t *>(sl.pin_x);
+        for (size_t i = 0, e = (size_t)n_cols * m->C; i < e; ++i) dst[i] = (int32_t)src[i];
+    } else {
+        memcpy(sl.pin_x, region_host, (size_t)n_cols * m->C * item);
+    }
     memcpy((char *)sl.pin_x + rb, starts_host, sb);
     HIP_TRY(hipMemcpyAsync(sl.dev_x, sl.pin_x, rb + sb, hipMemcpyHostToDevice, m->stream));
     TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y, (const int32_t *)((char *)sl.dev_x + rb)));

@@ -279,9 +279,11 @@ class Clair3_P(_HipModel):
         (n_cols, 18) matrix of one pileup region, ``starts`` the per-candidate offsets the reference slices at
         (preprocess/CreateTensorPileupFromCffi.py:362-364).  Same rows, bit for bit, as predict_numpy on the slices."""
         region = np.ascontiguousarray(region)
-        dt = _NP_DTYPE.get(region.dtype)
+        # int64 / uint64: the size_t matrix of plp_data viewed in place (np.frombuffer(ffi.buffer(plp_data.matrix, ...)),
+        # CreateTensorPileupFromCffi.py:140-146) -- no .copy(), no astype
+        dt = _lib.DTYPE_I64 if region.dtype in (np.dtype(np.int64), np.dtype(np.uint64)) else _NP_DTYPE.get(region.dtype)
         if dt is None or region.ndim != 2 or region.shape[1] != self.input_channels:
-            raise _lib.C3Error(f"region must be (n_cols, {self.input_channels}) int8/int32, got {region.dtype} {region.shape}")
+            raise _lib.C3Error(f"region must be (n_cols, {self.input_channels}) int8/int32/int64, got {region.dtype} {region.shape}")
         starts = np.ascontiguousarray(starts, dtype=np.int32)
         y = np.empty((len(starts), self.row_size), dtype=np.float32)
         _lib.check(_lib.lib().c3_predict_pileup_region(self._handle, region.ctypes.data, dt, region.shape[0],

@@ -135,8 +135,9 @@ int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64
  * the handle has been switched to the fp32 matrix instructions.  Synchronises the device. */
 int c3_model_range_status(c3_model *m, int *flag_out, int *on_fp32_out);
 /* Pileup only: windows gathered on the device out of ONE region matrix instead of `batch` pre-sliced
- * copies.  region_host: (n_cols, C) int8|int32 counts exactly as calculate_clair3_pileup returns them for a region
- * (src/clair3_pileup.h:113; preprocess/CreateTensorPileupFromCffi.py:143-146); starts_host[b] = first column of window
+ * copies.  region_host: (n_cols, C) int8|int32|int64 counts exactly as calculate_clair3_pileup returns them for a region
+ * (src/clair3_pileup.h:113; preprocess/CreateTensorPileupFromCffi.py:143-146) -- C3_DTYPE_I64 is plp_data.matrix itself
+ * (size_t), narrowed to int32 while it is staged, so the numpy copy of :143-146 is not needed either; starts_host[b] = first column of window
  * b, i.e. the `offset` the reference slices at (CreateTensorPileupFromCffi.py:362-364: result[0][offset:offset+33]).
  * Equivalent to c3_predict on the sliced windows, bit for bit; candidate filtering stays with the caller. */
 int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, int64_t n_cols, const int32_t *starts_host,
