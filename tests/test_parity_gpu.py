@@ -541,7 +541,8 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=23)
     x_p = syn.make_pileup_windows(70, seed=24)
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
-    fa_sets = [{"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_BN64MASK": "0"}, {"C3HIP_CONV_BN64MASK": "0x48"},
+    fa_sets = [{"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0"},
+               {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0x48"},  # stride-2 convs of the plane path on the tiled GEMM
                {"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
                {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"},
                {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
