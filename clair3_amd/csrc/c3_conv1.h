@@ -167,6 +167,11 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, kh = lane >> 5;
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    __shared__ __attribute__((aligned(16))) float bias_lds[PLANES ? 64 : 4];
+    if constexpr (PLANES) {  // before any wave leaves
+        if (tid < 64) bias_lds[tid] = p.bias[tid];
+        __syncthreads();
+    }
     if (gw >= p.groups) return;
 
     const int rowB = p.W * 8;
@@ -181,12 +186,19 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int q = 0; q < 2; ++q) wf[t][cb][q] = *reinterpret_cast<const c1_u32x4 *>(p.wfrag + (((t * 2 + cb) * 2 + q) * 64 + lane) * 4);
-    f32x16 biasv[2];
+    // !PLANES: the bias is the C operand of a group's first matrix instructions (one resident value per column block).
+    // PLANES: the transposed accumulators would need 16 distinct bias values per column block = 32 resident registers, and
+    // with them the kernel spilled 12 dwords -- whose reloads sit in the request code, each behind an s_waitcnt vmcnt(0)
+    // that (one in-order counter for loads, stores and scratch) also waits for the tap loads just issued and for the
+    // previous group's stores.  The groups start from the constant 0 instead and store_group() adds the bias from LDS.
+    f32x16 biasv[PLANES ? 1 : 2];
+    if constexpr (!PLANES) {
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const float b = p.bias[32 * cb + m];
+        for (int cb = 0; cb < 2; ++cb) {
+            const float b = p.bias[32 * cb + m];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) biasv[cb][v] = PLANES ? p.bias[32 * cb + (v & 3) + 8 * (v >> 2) + 4 * kh] : b;
+            for (int v = 0; v < 16; ++v) biasv[cb][v] = b;
+        }
     }
     // this lane's tap of every k-step: (ky, kx) and its byte offset from the (shifted) pixel base
     int ky[5], kx[5];
@@ -235,10 +247,11 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
     char *const st = st_all + (PLANES ? wave * 32 * 272 : 0);
     auto store_group = [&](const f32x16 (&r)[2], int idx) __attribute__((always_inline)) {
         const int cb = idx >> 2, q = idx & 3;
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_lds + 32 * cb + 8 * q + 4 * kh);
         f32x4 val;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int relu = max(__float_as_int(r[cb][4 * q + e]), 0);
+            const int relu = max(__float_as_int(r[cb][4 * q + e] + b4[e]), 0);
             omax_i = max(omax_i, relu);
             val[e] = __int_as_float(relu);
         }
@@ -277,7 +290,17 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
         for (int t = 0; t < 5; ++t) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                f32x16 c = t == 0 ? biasv[cb] : acc[cb];
+                f32x16 c;
+                if constexpr (PLANES) {
+                    if (t == 0) {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) c[v] = 0.f;
+                    } else {
+                        c = acc[cb];
+                    }
+                } else {
+                    c = t == 0 ? biasv[cb] : acc[cb];
+                }
                 if constexpr (PLANES) {
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, wf[t][cb][1]), __builtin_bit_cast(c1_f16x8, a[t]), c, 0, 0, 0);
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, wf[t][cb][0]), __builtin_bit_cast(c1_f16x8, a[t]), c, 0, 0, 0);

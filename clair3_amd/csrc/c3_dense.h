@@ -40,9 +40,28 @@ struct DensePlanesParams {
 // clair3/model.py:382-387) on plane activations -- the same chunk stream with the A rows gathered per (tap, slab) from the
 // input pixels (out-of-window taps are out-of-range buffer offsets: zeros) and the epilogue of the plane pipeline (bias, ReLU,
 // split into fp16 pieces, range flag).  Replaces gemm_mfma_kernel<PlaneConvLoader> (32-channel chunks, 8-byte pieces).
-template <bool CONV = false>
+// DIRECT (CONV = false only): the fp32 tile leaves straight from the accumulators -- a lane owns 4 consecutive columns of a
+// row (the weights are the first matrix operand), i.e. one 16-byte store per (row block, column quad), bias from an LDS copy
+// of the whole vector -- instead of crossing LDS to become (row, 8-column) items.  No LDS traffic and no barrier between
+// the last chunk of a tile and the first of the next: with K = 256 a tile is only four chunks long, and the staged epilogue
+// (16 LDS accesses per thread, two barriers, the matrix pipe idle meanwhile) was a fifth of it.
+// SPEC: waves 0-3 request and stage every operand chunk (8 + 8 pieces per thread), waves 4-7 store every finished tile (8 items
+// per thread).  Loads and stores of a wave share ONE in-order counter: with every wave doing both, the wait
+// for the first chunk requested after a tile's stores is also a wait for those stores -- a write round trip per tile, and
+// hipcc even emits it for the chunk requested BEFORE the stores (one static s_waitcnt vmcnt(0) serves all chunks).  With the
+// roles split no wave ever has a store older than a load it waits for.
+template <bool CONV = false, bool DIRECT = false, bool SPEC = false>
 __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanesParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage];
+    static_assert(!(CONV && DIRECT), "the plane epilogue needs the (row, 8-column) items");
+    static_assert(!(SPEC && DIRECT), "SPEC keeps the staged epilogue: only then can the storing waves be chosen");
+    constexpr int NLT = SPEC ? 256 : kDnThreads;   // threads that request / stage operand pieces
+    constexpr int PJ = 2048 / NLT;                 // pieces per loader thread and operand: 128 rows x 16 pieces
+    constexpr int RJ = NLT / 16;                   // rows between a thread's consecutive pieces
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + (DIRECT ? 8192 : 0)];
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);
+    if constexpr (DIRECT) {
+        for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
@@ -58,14 +77,19 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
         __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
     // CONV: input pixel (b, oh * stride - 1, ow * stride - 1) and tap validity of this thread's four rows of the tile whose
     // chunks are being requested (recomputed when the request stream moves on to the next tile)
-    int rbase[4] = {0, 0, 0, 0};
-    uint32_t rmask[4] = {0u, 0u, 0u, 0u};
+    const bool loader = !SPEC || wave < 4, storer = !SPEC || wave >= 4;
+    const int ltid = tid & (NLT - 1);  // loader / storer index inside its group
+    int rbase[PJ];
+    uint32_t rmask[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) rbase[j] = 0, rmask[j] = 0u;
     auto row_info = [&](int m0) __attribute__((always_inline)) {
         if constexpr (CONV) {
+            if (!loader) return;
             const int hw = p.Ho * p.Wo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m0 + (tid >> 4) + 32 * j;
+            for (int j = 0; j < PJ; ++j) {
+                const int m = m0 + (ltid >> 4) + RJ * j;
                 uint32_t mk = 0;
                 int base = 0;
                 if (m < p.M) {
@@ -92,11 +116,12 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
         m0 = tm * kDnBM;
     };
     // this thread's four pieces of each operand chunk: piece idx = tid + 512 j -> row idx >> 4, position idx & 15
-    auto issue = [&](pl_u32x4 (&ra)[4], pl_u32x4 (&rb)[4], int m0, int tn, int kc) __attribute__((always_inline)) {
-        const char *wsrc = reinterpret_cast<const char *>(p.w) + ((size_t)tn * NK + kc) * (kDnBN * 256) + tid * 16;
+    auto issue = [&](pl_u32x4 (&ra)[PJ], pl_u32x4 (&rb)[PJ], int m0, int tn, int kc) __attribute__((always_inline)) {
+        if (!loader) return;
+        const char *wsrc = reinterpret_cast<const char *>(p.w) + ((size_t)tn * NK + kc) * (kDnBN * 256) + ltid * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = tid + kDnThreads * j;
+        for (int j = 0; j < PJ; ++j) {
+            const int idx = ltid + NLT * j;
             const int m = m0 + (idx >> 4);
             uint32_t off;
             if constexpr (CONV) {
@@ -107,16 +132,17 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
                 off = m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
             }
             ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
-            rb[j] = *reinterpret_cast<const pl_u32x4 *>(wsrc + j * (kDnThreads * 16));
+            rb[j] = *reinterpret_cast<const pl_u32x4 *>(wsrc + j * (NLT * 16));
         }
     };
-    const int st_off = (tid >> 4) * kPlRowB + (tid & 15) * 16;  // 32 rows further per j
-    auto stage = [&](const pl_u32x4 (&ra)[4], const pl_u32x4 (&rb)[4], int buf) __attribute__((always_inline)) {
+    const int st_off = (ltid >> 4) * kPlRowB + (ltid & 15) * 16;  // RJ rows further per j
+    auto stage = [&](const pl_u32x4 (&ra)[PJ], const pl_u32x4 (&rb)[PJ], int buf) __attribute__((always_inline)) {
+        if (!loader) return;
         char *dst = smem + buf * kDnStage + st_off;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<pl_u32x4 *>(dst + j * 32 * kPlRowB) = ra[j];
-            *reinterpret_cast<pl_u32x4 *>(dst + kDnABytes + j * 32 * kPlRowB) = rb[j];
+        for (int j = 0; j < PJ; ++j) {
+            *reinterpret_cast<pl_u32x4 *>(dst + j * RJ * kPlRowB) = ra[j];
+            *reinterpret_cast<pl_u32x4 *>(dst + kDnABytes + j * RJ * kPlRowB) = rb[j];
         }
     };
     auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
     int m0, tn;
     tile_mn(v, m0, tn);
     row_info(m0);
-    pl_u32x4 ra[4], rb[4];
+    pl_u32x4 ra[PJ], rb[PJ];
     issue(ra, rb, m0, tn, 0);
     stage(ra, rb, 0);
     // the chunk after the first: same tile if NK > 1, else the next tile's
@@ -197,6 +223,26 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
             lds_barrier();
             ++g;
         }
+        if constexpr (DIRECT) {
+            const int cb0 = wn * 32 + 4 * kh;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = m0 + wm * 64 + i * 32 + frow;
+                const uint32_t rowoff = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + cb0) * 4) : kPlOob;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + tn * kDnBN + cb0 + 8 * q);
+                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+                }
+            }
+            v += G;
+            if (v >= p.tiles) break;
+            tile_mn(v, m0, tn);
+            continue;
+        }
         // ---- epilogue through the stage the tile's last chunk occupied ((g - 1) & 1; the next chunk is in the other one)
         char *stg = smem + ((g - 1) & 1) * kDnStage;
         constexpr int kRowE = 528;  // 128 columns x 4 B + 16 B pad: 16-byte accesses of consecutive rows land on different banks
@@ -213,9 +259,10 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
                 *reinterpret_cast<f32x4 *>(stg + (wm * 64 + i * 32 + frow) * kRowE + (cb0 + 8 * q) * 4) = val;
             }
         lds_barrier();
+        if (storer)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = tid + kDnThreads * j;
+        for (int j = 0; j < PJ; ++j) {
+            const int idx = ltid + NLT * j;
             const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
             const int m = m0 + r;
             if constexpr (CONV) {

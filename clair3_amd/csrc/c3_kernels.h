@@ -202,6 +202,7 @@ struct Lstm2Params {
     float *hout;       // [B][T][2H]; column = dir*H + unit
     int B, T;
     int64_t ld_gx;
+    unsigned long long *trace = nullptr;  // OPT bit 3 (C3HIP_LSTM_TRACE): shader-clock stamps of workgroup (0, 0), [wave][step][4]
 };
 
 // F16: h_{t-1} W_hh^T on v_mfma_f32_16x16x32_f16 with both operands as two fp16 pieces (fp16x3, c3_gemm.h SPLIT mode 2):
@@ -209,7 +210,7 @@ struct Lstm2Params {
 // fragments), the cell phase stores h as two fp16 planes, and a block's 40 fp32 matrix instructions of 32 cycles become
 // 15 of 16.
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-template <int H, bool F16 = false>
+template <int H, bool F16 = false, int OPT = 0>
 __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p) {
     constexpr int NB = H / 32;        // gate-column blocks per wave (8 waves)
     constexpr int NQ = H / 16;        // k groups of 16
@@ -309,9 +310,18 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
             *hb(buf, row, k) = h;
         }
     };
+    constexpr bool TRACE = (OPT & 8) != 0;
+    auto stamp = [&](int step, int k) __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (p.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) p.trace[(wave * 64 + step) * 4 + k] = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     for (int step = 0; step < p.T; ++step) {
         const int t = dir ? p.T - 1 - step : step;
         const int cur = step & 1;
+        stamp(step, 0);
         if (step == 0) {  // h_{-1} = 0: the pre-activations are the x-projection alone
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[b] = xn[b];
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        stamp(step, 1);
         // gate pre-activations (x-projection + recurrent part) -> LDS, then the next step's x-projection into the
         // freed accumulators
 #pragma unroll
@@ -379,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
 #pragma unroll
             for (int v = 0; v < 4; ++v) gwr[v * LDG + b * 16] = acc[b][v];
         __syncthreads();
+        stamp(step, 2);
         // cell: c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')   (rows i, f, g, o)
         const uint32_t ho = hobase + (uint32_t)(t * 2 * H * 4);
 #pragma unroll
@@ -406,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
             put_h(cur ^ 1, crow, cu0 + 32 * r, h);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrsrc, ho + 128 * r, 0, 0);
         }
+        stamp(step, 3);
         lds_barrier();
     }
 }

@@ -30,6 +30,7 @@ struct LstmFusedParams {
     int B, T, C;
     void *hplanes = nullptr;  // F16: write h as plane activations instead ([B*T][2H/64 slabs][hi 64 | lo 64] fp16, c3_conv3.h):
                               // the two pieces the recurrence forms anyway, and what dense_planes_kernel (c3_dense.h) reads
+    unsigned long long *trace = nullptr;  // OPT bit 3 (C3HIP_LSTM_TRACE): shader-clock stamps of workgroup (0, 0), [wave][step][4]
 };
 
 constexpr int kFusedKS = 5;  // k-steps of 4 covering C <= 20 input channels
@@ -37,7 +38,13 @@ constexpr int kFusedKS = 5;  // k-steps of 4 covering C <= 20 input channels
 // F16: the recurrent product h_{t-1} W_hh^T on v_mfma_f32_16x16x32_f16, both operands as two fp16 pieces (fp16x3, see
 // lstm_recurrent_kernel_v2): fragment slot q of a gate holds piece q & 1 of k-step q >> 1, h lives in two fp16 planes.
 // The 18-channel input projection stays on its 20 fp32 matrix instructions.
-template <typename TX, bool F16 = false>
+// OPT bit 0: the counts of step t + 1 stay as loaded (raw 16-bit pairs) until the top of step t + 1 and are widened there.
+// Widening them where they are requested -- what a single load_x16() does -- puts a wait for four just-issued loads between
+// the projection and the recurrent matrix instructions of EVERY step (hipcc keeps the conversion next to the loads): one
+// exposed L2 round trip per step on the critical path of a latency-bound kernel.
+// OPT bit 1: h leaves as planes, known at compile time (see `planes` below).
+// OPT bit 3: phase trace (debug).
+template <typename TX, bool F16 = false, int OPT = 0>
 __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p) {
     constexpr int H = 128, NW = 8, NQ = 8, LDH = H + 4;
     constexpr int LDH16 = 2 * H + 16;  // bytes per row of an fp16 h plane: 16 rows fall on 16 different 16-byte bank slots
@@ -129,12 +136,38 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         }
     };
     u32x4p xn16 = {0u, 0u, 0u, 0u};
+    constexpr bool DEFER = F16P && (OPT & 1);
+    uint32_t xraw[4] = {0u, 0u, 0u, 0u};
+    auto load_raw = [&](int t) __attribute__((always_inline)) {
+        const int so = t * p.C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xraw[j] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, xo2[j], so, 0);
+    };
+    auto widen_raw = [&](u32x4p &xa) __attribute__((always_inline)) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = __builtin_amdgcn_perm(0x48484848u, xraw[j] ^ 0x8080u, 0x04010400u);
+            xa[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, w) + h2{(_Float16)-9.0f, (_Float16)-9.0f});
+        }
+    };
+    constexpr bool TRACE = (OPT & 8) != 0;
+    auto stamp = [&](int step, int k) __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (p.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) p.trace[(wave * 64 + step) * 4 + k] = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     const int h_col = dir * H + wave * 16 + col;
     float c[4] = {0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t hrsrc =
         __builtin_amdgcn_make_buffer_rsrc(p.hout, 0, (uint32_t)((int64_t)p.B * p.T * 2 * H * 4), 0x00020000);
     uint32_t ho[4];  // byte offset of hout[window 4s+v][0][h_col]; windows beyond B are out of range (store dropped)
-    const bool planes = F16 && p.hplanes != nullptr;  // same bytes per (window, step): 2H x 4
+    // OPT bit 1: the caller guarantees hplanes != nullptr.  With `planes` a run-time value the plane store sits in a branch, and
+    // hipcc then waits for the step's four count loads with vmcnt(3..0) -- which, loads and stores sharing one in-order
+    // counter, also waits for the 16-byte store issued just before them: a full HBM write round trip on every step.
+    const bool planes = (F16 && (OPT & 2)) ? true : (F16 && p.hplanes != nullptr);  // same bytes per (window, step): 2H x 4
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(planes ? p.hplanes : (void *)p.hout, 0,
                                                                             (uint32_t)((int64_t)p.B * p.T * 2 * H * 4), 0x00020000);
 #pragma unroll
@@ -156,7 +189,8 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         __builtin_amdgcn_raw_buffer_store_b128(d, prsrc, cp_off + (uint32_t)(t * 2 * H * 4), 0, 0);
     };
     float xn[kFusedKS];
-    if constexpr (F16P) load_x16(dir ? p.T - 1 : 0, xn16);
+    if constexpr (DEFER) load_raw(dir ? p.T - 1 : 0);
+    else if constexpr (F16P) load_x16(dir ? p.T - 1 : 0, xn16);
     else load_x(dir ? p.T - 1 : 0, xn);
     __syncthreads();
 
@@ -169,14 +203,19 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         f32x4v acc[4];
         // gates = bias + x_t W_ih^T   (clair3/model.py:131-132: x.float() then LSTM1); the bias is the C operand of the
         // first MFMA (a resident 4-register vector per gate) instead of 16 register moves per step
+        stamp(step, 0);
         if constexpr (F16P) {
+            if constexpr (DEFER) widen_raw(xn16);
             const f16x8v xh = __builtin_bit_cast(f16x8v, xn16);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wp16[g][1]), biasv[g], 0, 0, 0);
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wp16[g][0]), acc[g], 0, 0, 0);
             }
-            if (step + 1 < p.T) load_x16(dir ? t - 1 : t + 1, xn16);
+            if (step + 1 < p.T) {
+                if constexpr (DEFER) load_raw(dir ? t - 1 : t + 1);
+                else load_x16(dir ? t - 1 : t + 1, xn16);
+            }
         } else {
 #pragma unroll
         for (int ks = 0; ks < kFusedKS; ++ks)
@@ -213,6 +252,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
                         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wres[g * NQ + q][e], acc[g], 0, 0, 0);
             }
         }
+        stamp(step, 1);
 #pragma unroll
         for (int v = 0; v < 4; v += 2) {  // two cells per packed instruction
             f32x2g cc = {c[v], c[v + 1]};
@@ -233,7 +273,9 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[e]), hrsrc, ho[v + e] + (uint32_t)(t * 2 * H * 4), 0, 0);
             }
         }
+        stamp(step, 2);
         lds_barrier();
+        stamp(step, 3);
         if constexpr (F16)
             if (planes) copy_planes(cur ^ 1, t);  // the tile this step wrote; the next step writes the other buffer
     }

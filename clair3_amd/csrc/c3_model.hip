@@ -154,6 +154,10 @@ struct c3_model {
     float *l1_wih = nullptr, *l1_bias = nullptr;  // LSTM1 input projection as MFMA fragments (fused kernel)
     float *l1_wih16 = nullptr;                    // the same as two fp16 pieces of 128 W_ih for the F16 kernel (int8 windows)
     bool lstm1_fused = true;                // env C3HIP_LSTM1_FUSED=0 selects GEMM + recurrence
+    int lstm_opt = 1;                       // env C3HIP_LSTM_OPT: bit 0 = LSTM1 (int8 windows, h1 as planes) widens the counts of step t + 1 at the
+                                            // top of step t + 1 and stores its plane piece unconditionally (c3_lstm_fused.h OPT 3)
+    int lstm_trace_left = 0, lstm2_trace_left = 0;  // debug, env C3HIP_LSTM_TRACE=n: the n-th LSTM launches record a phase trace
+    unsigned long long *lstm_trace_dev = nullptr;
     // full alignment
     float *conv_w[9] = {};
     float *conv_b[9] = {};
@@ -199,6 +203,9 @@ struct c3_model {
     float *proj2_pw = nullptr;               // LSTM2 projection weights as dense_planes_kernel chunks (c3_dense.h); env C3HIP_PROJ2_PLANES
     float proj2_pwscale = 1.f;
     bool proj2_planes = true;
+    int dense_mode = 1;                      // dense_planes_kernel (c3_dense.h): 1 = the projection's fp32 tile leaves straight from the accumulators
+                                             // (DIRECT; the stride-2 convs keep the staged plane epilogue), 0 = staged everywhere, 2 = loading and
+                                             // storing waves split (SPEC; measured slower: proj2 102 vs 93 us, conv3 41.8 vs 37.5); env C3HIP_DENSE_MODE
     float *proj2_w3 = nullptr;               // LSTM2 projection weights as bf16 pieces for the tiled SPLIT GEMM; env C3HIP_PROJ2_SPLIT
     bool proj2_split = true;
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
@@ -958,7 +965,8 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             dp.Hin = hh[l], dp.Win = ww[l], dp.Cin = cin, dp.Ho = hh[l + 1], dp.Wo = ww[l + 1], dp.stride = 2, dp.range_flag = m->range_flag;
             ps.mfma(2.0 * ((M + kDnBM - 1) / kDnBM * kDnBM) * (double)Cout * 9.0 * cin * 3, true);
             const int grid = std::min(dp.tiles, m->wg_slots / 2);  // one 512-thread workgroup (136 KB of LDS) per CU
-            hipLaunchKernelGGL(dense_planes_kernel<true>, dim3(grid), dim3(kDnThreads), 0, s, dp);
+            if (m->dense_mode == 2) hipLaunchKernelGGL((dense_planes_kernel<true, false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+            else hipLaunchKernelGGL(dense_planes_kernel<true>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             HIP_TRY(hipGetLastError());
         } else if (kConvStride[l] == 2) {
             ps.mfma(2.0 * ((M + 127) / 128 * 128) * (double)Cout * 9.0 * cin * 3, true);
@@ -1143,6 +1151,33 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
     return run_tail(m, s, m->spp, m->K4, n, y, "fa.l4", "fa.tail");
 }
 
+// debug (C3HIP_LSTM_TRACE): shader-clock stamps of workgroup (0, 0), every wave, four phase boundaries per step
+static hipError_t lstm_trace_begin(c3_model *m) {
+    constexpr size_t bytes = 8 * 64 * 4 * sizeof(unsigned long long);
+    if (!m->lstm_trace_dev) {
+        const hipError_t e = hipMalloc((void **)&m->lstm_trace_dev, bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipMemset(m->lstm_trace_dev, 0, bytes);
+}
+static hipError_t lstm_trace_print(c3_model *m, hipStream_t s, const char *name, int T, const char *legend) {
+    static unsigned long long h[8 * 64 * 4];
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(h, m->lstm_trace_dev, sizeof(h), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    fprintf(stderr, "%s trace (workgroup 0, shader cycles; %s)\n", name, legend);
+    for (int w = 0; w < 8; ++w) {
+        for (int st = 8; st < 12 && st + 1 < T; ++st) {
+            const unsigned long long *a = h + (w * 64 + st) * 4, *b = a + 4;
+            fprintf(stderr, "  wave %d step %2d: %6llu %6llu %6llu %6llu | step %6llu | top vs wave 0: %+lld\n", w, st, a[1] - a[0], a[2] - a[1],
+                    a[3] - a[2], b[0] - a[3], b[0] - a[0], (long long)(a[0] - h[st * 4]));
+        }
+    }
+    fprintf(stderr, "  whole launch, wave 0: %llu cycles for %d steps\n", h[(T - 1) * 4 + 3] - h[0], T);
+    return hipSuccess;
+}
+
 template <typename T>
 static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float *y, const int32_t *starts = nullptr) {
     const int Tn = m->positions;
@@ -1165,7 +1200,22 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         if (m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16)) {
             lp.whh = m->whh16[0];
             if (h1_planes) lp.hplanes = m->h1;  // h1 leaves as fp16 piece planes for dense_planes_kernel
-            hipLaunchKernelGGL((lstm1_fused_kernel<T, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+            const dim3 grid((unsigned)((n + 15) / 16), 2);
+            bool launched = false;
+            if constexpr (sizeof(T) == 1) {
+                if (m->lstm_trace_left > 0 && --m->lstm_trace_left == 0) {  // debug (C3HIP_LSTM_TRACE): this launch is traced
+                    HIP_TRY(lstm_trace_begin(m));
+                    lp.trace = m->lstm_trace_dev;
+                    if ((m->lstm_opt & 1) && h1_planes) hipLaunchKernelGGL((lstm1_fused_kernel<T, true, 11>), grid, dim3(512), 0, s, lp);
+                    else hipLaunchKernelGGL((lstm1_fused_kernel<T, true, 8>), grid, dim3(512), 0, s, lp);
+                    HIP_TRY(lstm_trace_print(m, s, "lstm1", Tn, "top -> matrix instructions issued -> cell + h written -> barrier -> next top"));
+                    launched = true;
+                } else if ((m->lstm_opt & 1) && h1_planes) {
+                    hipLaunchKernelGGL((lstm1_fused_kernel<T, true, 3>), grid, dim3(512), 0, s, lp);
+                    launched = true;
+                }
+            }
+            if (!launched) hipLaunchKernelGGL((lstm1_fused_kernel<T, true>), grid, dim3(512), 0, s, lp);
         } else {
             hipLaunchKernelGGL(lstm1_fused_kernel<T>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
         }
@@ -1192,7 +1242,9 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             dp.a = m->h1, dp.w = m->proj2_pw, dp.bias = m->proj_b[1], dp.c = m->gx2, dp.post_scale = 1.f / m->proj2_pwscale;
             dp.M = M, dp.N = 1280, dp.K = 256, dp.tiles_n = 1280 / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
             const int grid = std::min(dp.tiles, m->wg_slots / 2);
-            hipLaunchKernelGGL(dense_planes_kernel<false>, dim3(grid), dim3(kDnThreads), 0, s, dp);
+            if (m->dense_mode == 2) hipLaunchKernelGGL((dense_planes_kernel<false, false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+            else if (m->dense_mode == 1) hipLaunchKernelGGL((dense_planes_kernel<false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+            else hipLaunchKernelGGL(dense_planes_kernel<false>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             HIP_TRY(hipGetLastError());
         } else if (p2f16) {
             DenseLoaderParams lp{m->h1, 256};
@@ -1235,6 +1287,12 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
             if (m->f16_ok && m->lstm2_f16 && m->whh16[1]) {
                 lp.whh = m->whh16[1];
+                if (m->lstm2_trace_left > 0 && --m->lstm2_trace_left == 0) {
+                    HIP_TRY(lstm_trace_begin(m));
+                    lp.trace = m->lstm_trace_dev;
+                    hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true, 8>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+                    HIP_TRY(lstm_trace_print(m, s, "lstm2", Tn, "top -> matrix instructions issued -> gates exchanged -> cell + h written -> barrier -> next top"));
+                } else
                 hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
             } else {
                 hipLaunchKernelGGL(lstm_recurrent_kernel_v2<160>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
@@ -1362,6 +1420,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_PROJ2_SPLIT")) m->proj2_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_PROJ2_PLANES")) m->proj2_planes = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_PROJ2_STREAM")) m->proj2_stream = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_DENSE_MODE")) m->dense_mode = atoi(e);
     if (const char *e = getenv("C3HIP_TAIL_MFMA")) m->tail_mfma = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_DIRECT")) m->conv1_direct = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_WINOGRAD_PMASK")) m->wino_p_mask = (unsigned)strtoul(e, nullptr, 0);
@@ -1376,6 +1435,8 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_LSTM1_F16")) m->lstm1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_F16")) m->conv1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_LSTM_OPT")) m->lstm_opt = atoi(e);
+    if (const char *e = getenv("C3HIP_LSTM_TRACE")) m->lstm_trace_left = m->lstm2_trace_left = atoi(e);
     if (const char *e = getenv("C3HIP_FA_PLANES")) m->fa_planes = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV_S2_PLANES")) m->conv_s2_planes = atoi(e) != 0;
     if (hipMalloc((void **)&m->zeros, 256) != hipSuccess || hipMemset(m->zeros, 0, 256) != hipSuccess) {
@@ -1837,6 +1898,7 @@ int c3_model_destroy(c3_model *m) {
         if (p) (void)hipFree(p);
     if (m->decode_dev) (void)hipFree(m->decode_dev);
     if (m->range_flag) (void)hipFree(m->range_flag);
+    if (m->lstm_trace_dev) (void)hipFree(m->lstm_trace_dev);
     if (m->pin_flag) (void)hipHostFree(m->pin_flag);
     for (int l = 0; l < 9; ++l) {
         if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
