@@ -69,20 +69,26 @@ def build_model(kind, channels, indel, device):
     return m, sd
 
 
-def host_leg(model, x_host, steps, warmup):
+def host_leg(model, x_host, steps, warmup, slots=None):
     """K steps host to host: pageable numpy windows -> rows in host memory, ring of HOST_SLOTS submits in flight on ONE
-    handle (c3_predict_submit / c3_predict_wait).  Returns (seconds, last rows)."""
+    handle (c3_predict_submit / c3_predict_wait) -- or, with a list of handles, batch i on handle i % len with `slots` submits
+    in flight on each (what clair3_amd.worker.predict_batches does with a list).  Returns (seconds, last rows)."""
+    models = list(model) if isinstance(model, (list, tuple)) else [model]
+    slots = slots or HOST_SLOTS
     tickets = []
     y = None
 
     def run(k):
         nonlocal y
         for i in range(k):
-            if len(tickets) == HOST_SLOTS:
-                y = model.wait(tickets.pop(0))
-            tickets.append(model.submit(x_host, slot=i % HOST_SLOTS))
+            if len(tickets) == slots * len(models):
+                mi, t = tickets.pop(0)
+                y = mi.wait(t)
+            mi = models[i % len(models)]
+            tickets.append((mi, mi.submit(x_host, slot=(i // len(models)) % slots)))
         while tickets:
-            y = model.wait(tickets.pop(0))
+            mi, t = tickets.pop(0)
+            y = mi.wait(t)
 
     run(warmup)
     t0 = time.perf_counter()
@@ -214,6 +220,22 @@ def run_workload(name, args, rank, world, local):
             hl["batch_1000"] = {"value": bref * k / el, "ms_per_step": 1e3 * el / k, "steps": k,
                                 "device_resident_one_in_flight": bref * k / el_dev,
                                 "frac_of_device_resident": el_dev / el}
+            # the reference loop's own call: ONE blocking _torch_predict per batch (predict._hip_predict -> c3_predict, which cuts
+            # the batch into chunks that travel through the ring)
+            for _ in range(3):
+                y = model.predict_numpy(xb)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                y = model.predict_numpy(xb)
+            el_sync = time.perf_counter() - t0
+            hl["batch_1000"]["sync_call"] = {"value": bref * k / el_sync, "ms_per_call": 1e3 * el_sync / k,
+                                             "frac_of_device_resident": el_dev / el_sync,
+                                             "path": "model.predict_numpy = _hip_predict = c3_predict: one blocking call per batch"}
+            # every handle of the device-resident headline fed from the host: batch i on handle i % S, two submits in flight each
+            if len(models) > 1:
+                el3, y = host_leg(models, xb, k, 3, slots=2)
+                hl["batch_1000"]["all_handles"] = {"value": bref * k / el3, "ms_per_step": 1e3 * el3 / k, "handles": len(models),
+                                                   "slots_in_flight_per_handle": 2}
             # zero-copy variant: the source buffer page-locked once (c3_host_register), no staging copy
             try:
                 from clair3_amd import _lib

@@ -34,6 +34,7 @@ struct DensePlanesParams {
     // CONV: 3x3 / pad 1 / stride `stride` convolution as an implicit GEMM, M = B * Ho * Wo output pixels, K = 9 * Cin
     int Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0, stride = 1;
     uint32_t *range_flag = nullptr;
+    long long *trace = nullptr;  // TR (debug, C3HIP_DENSE_TRACE): {tag, shader clock} pairs of workgroup 0, waves 0 and 4, [2][512][2]
 };
 
 // CONV = false: the LSTM2 projection above.  CONV = true: the two stride-2 convolutions of Clair3_F (conv3, conv5;
@@ -45,17 +46,11 @@ struct DensePlanesParams {
 // of the whole vector -- instead of crossing LDS to become (row, 8-column) items.  No LDS traffic and no barrier between
 // the last chunk of a tile and the first of the next: with K = 256 a tile is only four chunks long, and the staged epilogue
 // (16 LDS accesses per thread, two barriers, the matrix pipe idle meanwhile) was a fifth of it.
-// SPEC: waves 0-3 request and stage every operand chunk (8 + 8 pieces per thread), waves 4-7 store every finished tile (8 items
-// per thread).  Loads and stores of a wave share ONE in-order counter: with every wave doing both, the wait
-// for the first chunk requested after a tile's stores is also a wait for those stores -- a write round trip per tile, and
-// hipcc even emits it for the chunk requested BEFORE the stores (one static s_waitcnt vmcnt(0) serves all chunks).  With the
-// roles split no wave ever has a store older than a load it waits for.
-template <bool CONV = false, bool DIRECT = false, bool SPEC = false>
+template <bool CONV = false, bool DIRECT = false, bool TR = false>
 __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanesParams p) {
     static_assert(!(CONV && DIRECT), "the plane epilogue needs the (row, 8-column) items");
-    static_assert(!(SPEC && DIRECT), "SPEC keeps the staged epilogue: only then can the storing waves be chosen");
-    constexpr int NLT = SPEC ? 256 : kDnThreads;   // threads that request / stage operand pieces
-    constexpr int PJ = 2048 / NLT;                 // pieces per loader thread and operand: 128 rows x 16 pieces
+    constexpr int NLT = kDnThreads;                // threads that request / stage operand pieces
+    constexpr int PJ = 2048 / NLT;                 // pieces per thread and operand: 128 rows x 16 pieces
     constexpr int RJ = NLT / 16;                   // rows between a thread's consecutive pieces
     __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + (DIRECT ? 8192 : 0)];
     float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);
@@ -77,7 +72,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
         __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
     // CONV: input pixel (b, oh * stride - 1, ow * stride - 1) and tap validity of this thread's four rows of the tile whose
     // chunks are being requested (recomputed when the request stream moves on to the next tile)
-    const bool loader = !SPEC || wave < 4, storer = !SPEC || wave >= 4;
+    constexpr bool loader = true, storer = true;
     const int ltid = tid & (NLT - 1);  // loader / storer index inside its group
     int rbase[PJ];
     uint32_t rmask[PJ];
@@ -151,6 +146,18 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
     const int a_rd[2] = {(wm * 64 + frow) * kPlRowB + kh * 16, (wm * 64 + 32 + frow) * kPlRowB + kh * 16};
     const int b_rd = kDnABytes + (wn * 32 + frow) * kPlRowB + kh * 16;
 
+    int tr_n = 0;
+    auto trace = [&](int tag) __attribute__((always_inline)) {
+        if constexpr (TR) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (p.trace && blockIdx.x == 0 && (tid == 0 || tid == 256) && tr_n < 512) {
+                long long *tb = p.trace + ((tid ? 1 : 0) * 512 + tr_n) * 2;
+                tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
+                ++tr_n;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     int v = blockIdx.x;
     if (v >= p.tiles) return;
     int m0, tn;
@@ -184,7 +191,9 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
             // the chunk in registers -> the other stage (its readers passed the barrier that ended the previous chunk), then
             // the request for the chunk after it
             const bool have_next = vq < p.tiles;
+            trace(1);
             if (have_next) stage(ra, rb, (g + 1) & 1);
+            trace(2);
             if (have_next) {
                 if (++kq == NK) {
                     kq = 0, vq += G;
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
                 }
                 if (vq < p.tiles) issue(ra, rb, m0q, tnq, kq);
             }
+            trace(3);
             __builtin_amdgcn_sched_barrier(0);
             pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
             auto frags = [&](int ks, int st) __attribute__((always_inline)) {
@@ -220,9 +230,11 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
                 acc[1] = mma(acc[1], wh[st], xh[st][1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            trace(4);
             lds_barrier();
             ++g;
         }
+        trace(5);
         if constexpr (DIRECT) {
             const int cb0 = wn * 32 + 4 * kh;
 #pragma unroll
@@ -294,6 +306,576 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
         if (v >= p.tiles) break;
         tile_mn(v, m0, tn);
         lds_barrier();  // the staged tile has been read; the next chunk's stage() may overwrite it
+    }
+    if constexpr (CONV)
+        if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dense_planes_pipe_kernel -- the same tiles, operands and LDS layout with the chunk stream spread over the matrix stream.
+//
+// Phase trace of dense_planes_kernel on the LSTM2 projection (C3HIP_DENSE_TRACE; shader cycles per 64-channel chunk):
+// stage 800 -> request 1400 -> 24 matrix instructions + fragment reads 1400 -> barrier 900 = 4500 for 1536 cycles of
+// matrix work on the two waves of a SIMD.  Both operands stream, so a chunk is 64 KB through the vector memory pipe of a CU
+// (64 B / clk: 1024 cycles) and 64 KB through the LDS write path; issued back to back at the top of a chunk, the eight
+// loads of a thread fill the memory pipe's queue and the wave stalls in the ISSUE of its loads, then in its eight LDS
+// writes, before its first matrix instruction -- every wave at the same time.  Here piece j of the chunk held in registers
+// goes to LDS in k-step j of the current chunk and its register is re-requested right away (one LDS write and one load
+// per operand per six matrix instructions): the three pipes run side by side.
+// The tile's results leave at the top of the NEXT tile (stores of the first tile's predecessor are out-of-range offsets),
+// and a tile's first chunk is its own copy of the code: hipcc derives an s_waitcnt vmcnt(N) per static instruction from the
+// worst path into it, and loads and stores of a wave share one in-order counter -- one copy of the chunk code for all
+// chunks made the first wait after a tile's stores a wait for those stores as well.
+// ABL (tools/dense_probe.hip only; 0 in the product): 1 no operand loads, 2 no LDS staging writes, 4 no matrix instructions,
+// 8 no fragment reads, 16 no result stores, 32 no barriers.
+template <bool CONV = false, bool TR = false, int ABL = 0>
+__global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DensePlanesParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + (CONV ? 0 : 8192)];
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);
+    if constexpr (!CONV) {
+        for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
+    const int frow = lane & 31, kh = lane >> 5;
+    const int NK = p.K / 64;
+    const int G = gridDim.x;
+    const int rowb = CONV ? p.Cin * 4 : (p.K / 64) * 256;  // bytes per row (pixel) of A
+    const int nsin = CONV ? p.Cin / 64 : 1;
+
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(p.a), 0, CONV ? (uint32_t)((int64_t)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win * rowb) : (uint32_t)((int64_t)p.M * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t crsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, (uint32_t)((int64_t)p.N * p.K * 4), 0x00020000);
+    int rbase[4] = {0, 0, 0, 0};
+    uint32_t rmask[4] = {0u, 0u, 0u, 0u};
+    auto row_info = [&](int m0) __attribute__((always_inline)) {
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + (tid >> 4) + 32 * j;
+                uint32_t mk = 0;
+                int base = 0;
+                if (m < p.M) {
+                    const int b = m / hw, rem = m - b * hw;
+                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                    const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
+                    base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int ih = ih0 + t / 3, iw = iw0 + t % 3;
+                        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
+                    }
+                }
+                rbase[j] = base, rmask[j] = mk;
+            }
+        }
+    };
+    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
+        const int tile = xcd_tile_index(v, p.tiles);
+        const int tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+        m0 = tm * kDnBM;
+    };
+    // piece j of a chunk: row (tid >> 4) + 32 j of each operand, 16-byte position tid & 15
+    pl_u32x4 ra[4], rb[4];
+    // `on` = false: both loads still issue, at out-of-range offsets (they return zeros).  A conditional request would give
+    // hipcc paths with fewer loads in flight, and it sizes every s_waitcnt vmcnt(N) for the emptiest path into it: the wait
+    // for piece j then also waits for the pieces requested a few instructions earlier.
+    auto issue1 = [&](int j, int m0, int tn, int kc, bool on) __attribute__((always_inline)) {
+        const int idx = tid + kDnThreads * j;
+        const int m = m0 + (idx >> 4);
+        uint32_t off;
+        if constexpr (CONV) {
+            const int tap = kc / nsin, slab = kc - tap * nsin;
+            const int kh3 = tap / 3, kw3 = tap - 3 * kh3;
+            off = (on && ((rmask[j] >> tap) & 1u)) ? (uint32_t)(rbase[j] + (kh3 * p.Win + kw3) * rowb + slab * 256 + (idx & 15) * 16) : kPlOob;
+        } else {
+            off = on && m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
+        }
+        const uint32_t woff = on ? (uint32_t)((tn * NK + kc) * (kDnBN * 256) + idx * 16) : kPlOob;
+        if constexpr (ABL & 1) {
+            ra[j] = pl_u32x4{off, woff, 0x3c003c00u, 0x3c003c00u}, rb[j] = pl_u32x4{woff, off, 0x3c003c00u, 0x3c003c00u};  // keeps the address arithmetic alive
+        } else {
+            ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
+            rb[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
+        }
+    };
+    const int st_off = (tid >> 4) * kPlRowB + (tid & 15) * 16;  // 32 rows further per j
+    auto stage1 = [&](int j, int buf) __attribute__((always_inline)) {
+        char *dst = smem + buf * kDnStage + st_off + j * 32 * kPlRowB;
+        if constexpr (ABL & 2) {
+            if (ra[j][1] == 0x12345u && rb[j][2] == 0x54321u) *reinterpret_cast<pl_u32x4 *>(dst) = ra[j];  // never true: the registers stay live
+        } else {
+            *reinterpret_cast<pl_u32x4 *>(dst) = ra[j];
+            *reinterpret_cast<pl_u32x4 *>(dst + kDnABytes) = rb[j];
+        }
+    };
+    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
+        if constexpr (ABL & 4) {
+            c[0] += __uint_as_float(w[0] ^ x[0]), c[5] += __uint_as_float(w[3] ^ x[3]);
+            return c;
+        } else {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+        }
+    };
+    const int a_rd[2] = {(wm * 64 + frow) * kPlRowB + kh * 16, (wm * 64 + 32 + frow) * kPlRowB + kh * 16};
+    const int b_rd = kDnABytes + (wn * 32 + frow) * kPlRowB + kh * 16;
+
+    int tr_n = 0;
+    auto trace = [&](int tag) __attribute__((always_inline)) {
+        if constexpr (TR) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (p.trace && blockIdx.x == 0 && (tid == 0 || tid == 256) && tr_n < 512) {
+                long long *tb = p.trace + ((tid ? 1 : 0) * 512 + tr_n) * 2;
+                tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
+                ++tr_n;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int v = blockIdx.x;
+    if (v >= p.tiles) return;
+    int m0, tn;
+    tile_mn(v, m0, tn);
+    row_info(m0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue1(j, m0, tn, 0, true);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage1(j, 0);
+    int vq = v, m0q = m0, tnq = tn, kq = 1;  // (tile, chunk) of the chunk held in registers
+    if (kq == NK) {
+        kq = 0, vq = v + G;
+        if (vq < p.tiles) {
+            tile_mn(vq, m0q, tnq);
+            row_info(m0q);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue1(j, m0q, tnq, kq, vq < p.tiles);
+    lds_barrier();
+
+    int g = 0;  // chunks done: the current chunk sits in LDS stage g & 1
+    float omax = 0.f;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    // FIRST: the tile's first chunk -- the accumulators start from the constant 0 of its first matrix instructions
+    auto chunk = [&](auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const char *cur = smem + (g & 1) * kDnStage;
+        const bool have_next = vq < p.tiles;  // the registers hold a chunk: it goes to the other stage during this one
+        bool req = false;                     // ... and its registers are re-requested for the chunk after it
+        if (have_next) {
+            if (++kq == NK) {
+                kq = 0, vq += G;
+                if (vq < p.tiles) {
+                    tile_mn(vq, m0q, tnq);
+                    row_info(m0q);
+                }
+            }
+            req = vq < p.tiles;
+        }
+        pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
+        auto frags = [&](int ks, int st) __attribute__((always_inline)) {
+            if constexpr (ABL & 8) {
+                const pl_u32x4 f = {(uint32_t)(ks + g), (uint32_t)lane, 0x3c003c00u, 0x3c003c00u};
+                wh[st] = wl[st] = xh[st][0] = xh[st][1] = xl[st][0] = xl[st][1] = f;
+                return;
+            }
+            wh[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + ks * 32);
+            wl[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + 128 + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + ks * 32);
+                xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + 128 + ks * 32);
+            }
+        };
+        trace(1);
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int st = ks & 1;
+            if (ks < 3) frags(ks + 1, st ^ 1);
+            trace(2);
+            stage1(ks, (g + 1) & 1);
+            trace(3);  // zeros once the stream has ended: that stage is not read again before the epilogue rewrites it
+            issue1(ks, m0q, tnq, kq, req);
+            trace(4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (FIRST && ks == 0) {
+                f32x16 zero;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+                acc[0] = mma(zero, wh[st], xl[st][0]);
+                acc[1] = mma(zero, wh[st], xl[st][1]);
+            } else {
+                acc[0] = mma(acc[0], wh[st], xl[st][0]);
+                acc[1] = mma(acc[1], wh[st], xl[st][1]);
+            }
+            acc[0] = mma(acc[0], wl[st], xh[st][0]);
+            acc[1] = mma(acc[1], wl[st], xh[st][1]);
+            acc[0] = mma(acc[0], wh[st], xh[st][0]);
+            acc[1] = mma(acc[1], wh[st], xh[st][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            trace(5);
+        }
+        if constexpr (!(ABL & 32)) lds_barrier();
+        ++g;
+    };
+    // the finished tile (pm0, ptn): out-of-range offsets when there is none yet -- the same stores on every path
+    auto epilogue = [&](int pm0, int ptn, bool valid) __attribute__((always_inline)) {
+        const int cb0 = wn * 32 + 4 * kh;
+        if constexpr (!CONV) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = pm0 + wm * 64 + i * 32 + frow;
+                const uint32_t rowoff = valid && m < p.M ? (uint32_t)(((int64_t)m * p.N + ptn * kDnBN + cb0) * 4) : kPlOob;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + ptn * kDnBN + cb0 + 8 * q);
+                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    if constexpr (ABL & 16) {
+                        if (val[0] == 1234.5f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // through the stage the tile's last chunk occupied ((g - 1) & 1; the next chunk is in the other one)
+            char *stg = smem + ((g - 1) & 1) * kDnStage;
+            constexpr int kRowE = 528;  // 128 columns x 4 B + 16 B pad
+            static_assert(kDnBM * kRowE <= kDnStage, "staged tile must fit one stage");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + ptn * kDnBN + cb0 + 8 * q);
+                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    *reinterpret_cast<f32x4 *>(stg + (wm * 64 + i * 32 + frow) * kRowE + (cb0 + 8 * q) * 4) = val;
+                }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + kDnThreads * j;
+                const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
+                const int m = pm0 + r;
+                f32x4 a = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32);
+                f32x4 b = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32 + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = __int_as_float(max(__float_as_int(a[e]), 0));  // ReLU on the bit pattern
+                    b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
+                }
+                omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+                u32x2 pa[2], pb[2];
+                split2_f16(a, pa);
+                split2_f16(b, pb);
+                const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+                const int n = ptn * kDnBN + c8 * 8;  // channel: slab n >> 6, hi piece at 2 (n & 63), lo piece 128 bytes further
+                const uint32_t off = valid && m < p.M ? (uint32_t)m * (uint32_t)(p.N * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : kPlOob;
+                __builtin_amdgcn_raw_buffer_store_b128(hi, crsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, crsrc, off + 128, 0, 0);
+            }
+            lds_barrier();  // the staged tile has been read; the next chunk's stage1() may overwrite it
+        }
+    };
+    int pm0 = 0, ptn = 0;
+    bool have_prev = false;
+    for (;;) {
+        trace(8);
+        epilogue(pm0, ptn, have_prev);
+        trace(9);
+        if (v >= p.tiles) break;
+        chunk(std::true_type{});  // the copy behind the stores
+        for (int kc = 1; kc < NK; ++kc) chunk(std::false_type{});
+        pm0 = m0, ptn = tn, have_prev = true;
+        v += G;
+        if (v < p.tiles) tile_mn(v, m0, tn);
+    }
+    if constexpr (CONV)
+        if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dense_planes_ws_kernel -- the same tiles with the work split by wave ROLE: waves 0-7 multiply (2 x 4, 64 x 32 outputs each,
+// as above) and store the results, waves 8-11 do nothing but move operand chunks: global -> registers -> LDS.
+//
+// tools/dense_probe.hip on the LSTM2 projection (us): whole kernel 102; without its result stores 76; operand loads + LDS
+// staging alone 33 (676 MB out of L2 per launch: ~20 TB/s); fragment reads + matrix instructions add 42, the stores 27 -- the
+// parts ADD UP instead of overlapping.  With every wave doing everything, every wave sits in turn behind its own loads
+// (s_waitcnt before staging), behind the LDS write path and behind the matrix pipe, in lockstep with its seven siblings, and a
+// wave's stores and loads share one in-order counter.  With the roles split, a chunk lasts max(move, multiply): the movers
+// never wait for the matrix pipe, the multipliers never execute a load, and the only stores a wave ever waits for are none.
+// One barrier per chunk as before (movers fill stage (g + 1) & 1 while the multipliers read stage g & 1).
+constexpr int kWsThreads = 768, kWsMovers = 256;
+template <bool CONV = false, int ABL = 0>
+__global__ __launch_bounds__(kWsThreads) void dense_planes_ws_kernel(DensePlanesParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + 8192];
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);
+    for (int i = threadIdx.x; i < p.N && i < 2048; i += kWsThreads) bias_lds[i] = p.bias[i];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NK = p.K / 64;
+    const int G = gridDim.x;
+    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
+        const int tile = xcd_tile_index(v, p.tiles);
+        const int tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+        m0 = tm * kDnBM;
+    };
+    if (blockIdx.x >= p.tiles) return;
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------------------------------------ movers
+        const int ltid = tid - 512;
+        const int rowb = CONV ? p.Cin * 4 : (p.K / 64) * 256;  // bytes per row (pixel) of A
+        const int nsin = CONV ? p.Cin / 64 : 1;
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void *>(p.a), 0, CONV ? (uint32_t)((int64_t)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win * rowb) : (uint32_t)((int64_t)p.M * rowb), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, (uint32_t)((int64_t)p.N * p.K * 4), 0x00020000);
+        // piece j of a chunk: row (ltid >> 4) + 16 j of each operand, 16-byte position ltid & 15
+        int rbase[8];
+        uint32_t rmask[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rbase[j] = 0, rmask[j] = 0u;
+        auto row_info = [&](int m0) __attribute__((always_inline)) {
+            if constexpr (CONV) {
+                const int hw = p.Ho * p.Wo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int m = m0 + (ltid >> 4) + 16 * j;
+                    uint32_t mk = 0;
+                    int base = 0;
+                    if (m < p.M) {
+                        const int b = m / hw, rem = m - b * hw;
+                        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                        const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
+                        base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            const int ih = ih0 + t / 3, iw = iw0 + t % 3;
+                            if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
+                        }
+                    }
+                    rbase[j] = base, rmask[j] = mk;
+                }
+            }
+        };
+        pl_u32x4 ra[8], rb[8];
+        // `on` = false: the loads still issue, at out-of-range offsets (zeros): the same number of loads in flight on every
+        // path, so hipcc's s_waitcnt vmcnt(N) before each LDS write leaves the younger loads in flight
+        auto issue1 = [&](int j, int m0, int tn, int kc, bool on) __attribute__((always_inline)) {
+            const int idx = ltid + kWsMovers * j;
+            const int m = m0 + (idx >> 4);
+            uint32_t off;
+            if constexpr (CONV) {
+                const int tap = kc / nsin, slab = kc - tap * nsin;
+                const int kh3 = tap / 3, kw3 = tap - 3 * kh3;
+                off = (on && ((rmask[j] >> tap) & 1u)) ? (uint32_t)(rbase[j] + (kh3 * p.Win + kw3) * rowb + slab * 256 + (idx & 15) * 16) : kPlOob;
+            } else {
+                off = on && m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
+            }
+            const uint32_t woff = on ? (uint32_t)((tn * NK + kc) * (kDnBN * 256) + idx * 16) : kPlOob;
+            if constexpr (!(ABL & 1)) {
+                ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
+                rb[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
+            } else {
+                ra[j] = pl_u32x4{off, woff, 0x3c003c00u, 0x3c003c00u}, rb[j] = pl_u32x4{woff, off, 0x3c003c00u, 0x3c003c00u};
+            }
+        };
+        const int st_off = (ltid >> 4) * kPlRowB + (ltid & 15) * 16;  // 16 rows further per j
+        auto stage1 = [&](int j, int buf) __attribute__((always_inline)) {
+            char *dst = smem + buf * kDnStage + st_off + j * 16 * kPlRowB;
+            if constexpr (!(ABL & 2)) {
+                *reinterpret_cast<pl_u32x4 *>(dst) = ra[j];
+                *reinterpret_cast<pl_u32x4 *>(dst + kDnABytes) = rb[j];
+            } else {
+                if (ra[j][1] == 0x12345u && rb[j][2] == 0x54321u) *reinterpret_cast<pl_u32x4 *>(dst) = ra[j];
+            }
+        };
+        int v = blockIdx.x;
+        int m0q, tnq;
+        tile_mn(v, m0q, tnq);
+        row_info(m0q);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue1(j, m0q, tnq, 0, true);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage1(j, 0);
+        int vq = v, kq = 1;  // (tile, chunk) of the chunk held in registers
+        if (kq == NK) {
+            kq = 0, vq = v + G;
+            if (vq < p.tiles) {
+                tile_mn(vq, m0q, tnq);
+                row_info(m0q);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue1(j, m0q, tnq, kq, vq < p.tiles);
+        lds_barrier();
+        int g = 0;
+        for (; v < p.tiles; v += G) {
+            for (int kc = 0; kc < NK; ++kc) {
+                bool req = false;
+                if (vq < p.tiles) {
+                    if (++kq == NK) {
+                        kq = 0, vq += G;
+                        if (vq < p.tiles) {
+                            tile_mn(vq, m0q, tnq);
+                            row_info(m0q);
+                        }
+                    }
+                    req = vq < p.tiles;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    stage1(j, (g + 1) & 1);  // zeros once the stream has ended: nobody reads them
+                    issue1(j, m0q, tnq, kq, req);
+                }
+                if constexpr (!(ABL & 32)) lds_barrier();
+                ++g;
+            }
+            if constexpr (CONV) {  // the multipliers' epilogue crosses LDS: its two barriers
+                lds_barrier();
+                lds_barrier();
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- multipliers
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
+    const int frow = lane & 31, kh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t crsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
+    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
+        if constexpr (ABL & 4) {
+            c[0] += __uint_as_float(w[0] ^ x[0]), c[5] += __uint_as_float(w[3] ^ x[3]);
+            return c;
+        } else {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+        }
+    };
+    const int a_rd[2] = {(wm * 64 + frow) * kPlRowB + kh * 16, (wm * 64 + 32 + frow) * kPlRowB + kh * 16};
+    const int b_rd = kDnABytes + (wn * 32 + frow) * kPlRowB + kh * 16;
+    const int cb0 = wn * 32 + 4 * kh;
+    lds_barrier();
+    int g = 0;
+    float omax = 0.f;
+    for (int v = blockIdx.x; v < p.tiles; v += G) {
+        int m0, tn;
+        tile_mn(v, m0, tn);
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int kc = 0; kc < NK; ++kc) {
+            const char *cur = smem + (g & 1) * kDnStage;
+            pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
+            auto frags = [&](int ks, int st) __attribute__((always_inline)) {
+                if constexpr (ABL & 8) {
+                    const pl_u32x4 f = {(uint32_t)(ks + g), (uint32_t)lane, 0x3c003c00u, 0x3c003c00u};
+                    wh[st] = wl[st] = xh[st][0] = xh[st][1] = xl[st][0] = xl[st][1] = f;
+                    return;
+                }
+                wh[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + ks * 32);
+                wl[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + 128 + ks * 32);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + ks * 32);
+                    xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + 128 + ks * 32);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int st = ks & 1;
+                if (ks < 3) frags(ks + 1, st ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = mma(acc[0], wh[st], xl[st][0]);
+                acc[1] = mma(acc[1], wh[st], xl[st][1]);
+                acc[0] = mma(acc[0], wl[st], xh[st][0]);
+                acc[1] = mma(acc[1], wl[st], xh[st][1]);
+                acc[0] = mma(acc[0], wh[st], xh[st][0]);
+                acc[1] = mma(acc[1], wh[st], xh[st][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!(ABL & 32)) lds_barrier();
+            ++g;
+        }
+        if constexpr (!CONV) {
+            // fp32 tile straight from the accumulators: a lane owns 4 consecutive columns of a row (weights are the first operand)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = m0 + wm * 64 + i * 32 + frow;
+                const uint32_t rowoff = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + cb0) * 4) : kPlOob;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + tn * kDnBN + cb0 + 8 * q);
+                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    if constexpr (ABL & 16) {
+                        if (val[0] == 1234.5f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // plane epilogue through the stage the tile's last chunk occupied ((g - 1) & 1; the movers are filling the other one and
+            // start on this one only behind the second barrier below)
+            char *stg = smem + ((g - 1) & 1) * kDnStage;
+            constexpr int kRowE = 528;  // 128 columns x 4 B + 16 B pad
+            static_assert(kDnBM * kRowE <= kDnStage, "staged tile must fit one stage");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + tn * kDnBN + cb0 + 8 * q);
+                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    *reinterpret_cast<f32x4 *>(stg + (wm * 64 + i * 32 + frow) * kRowE + (cb0 + 8 * q) * 4) = val;
+                }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + 512 * j;
+                const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
+                const int m = m0 + r;
+                f32x4 a = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32);
+                f32x4 b = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32 + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = __int_as_float(max(__float_as_int(a[e]), 0));  // ReLU on the bit pattern
+                    b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
+                }
+                omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+                u32x2 pa[2], pb[2];
+                split2_f16(a, pa);
+                split2_f16(b, pb);
+                const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+                const int n = tn * kDnBN + c8 * 8;  // channel: slab n >> 6, hi piece at 2 (n & 63), lo piece 128 bytes further
+                const uint32_t off = m < p.M ? (uint32_t)m * (uint32_t)(p.N * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : kPlOob;
+                __builtin_amdgcn_raw_buffer_store_b128(hi, crsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, crsrc, off + 128, 0, 0);
+            }
+            lds_barrier();  // the staged tile has been read: the movers may fill this stage
+        }
     }
     if constexpr (CONV)
         if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN

@@ -203,9 +203,10 @@ struct c3_model {
     float *proj2_pw = nullptr;               // LSTM2 projection weights as dense_planes_kernel chunks (c3_dense.h); env C3HIP_PROJ2_PLANES
     float proj2_pwscale = 1.f;
     bool proj2_planes = true;
-    int dense_mode = 1;                      // dense_planes_kernel (c3_dense.h): 1 = the projection's fp32 tile leaves straight from the accumulators
-                                             // (DIRECT; the stride-2 convs keep the staged plane epilogue), 0 = staged everywhere, 2 = loading and
-                                             // storing waves split (SPEC; measured slower: proj2 102 vs 93 us, conv3 41.8 vs 37.5); env C3HIP_DENSE_MODE
+    int dense_mode = 3;                      // dense kernels (c3_dense.h): 3 = dense_planes_pipe_kernel (chunk stream spread over the matrix stream;
+                                             // default), 4 = dense_planes_ws_kernel (8 multiplying + 4 moving waves: the kernels themselves 5-8 %
+                                             // faster, the step as a whole 2.5 % slower -- DESIGN.md 3.8), 1 / 0 = round-2 kernel with the direct /
+                                             // staged fp32 epilogue; env C3HIP_DENSE_MODE
     float *proj2_w3 = nullptr;               // LSTM2 projection weights as bf16 pieces for the tiled SPLIT GEMM; env C3HIP_PROJ2_SPLIT
     bool proj2_split = true;
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
@@ -965,7 +966,8 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             dp.Hin = hh[l], dp.Win = ww[l], dp.Cin = cin, dp.Ho = hh[l + 1], dp.Wo = ww[l + 1], dp.stride = 2, dp.range_flag = m->range_flag;
             ps.mfma(2.0 * ((M + kDnBM - 1) / kDnBM * kDnBM) * (double)Cout * 9.0 * cin * 3, true);
             const int grid = std::min(dp.tiles, m->wg_slots / 2);  // one 512-thread workgroup (136 KB of LDS) per CU
-            if (m->dense_mode == 2) hipLaunchKernelGGL((dense_planes_kernel<true, false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+            if (m->dense_mode == 4) hipLaunchKernelGGL(dense_planes_ws_kernel<true>, dim3(grid), dim3(kWsThreads), 0, s, dp);
+            else if (m->dense_mode == 3) hipLaunchKernelGGL(dense_planes_pipe_kernel<true>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             else hipLaunchKernelGGL(dense_planes_kernel<true>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             HIP_TRY(hipGetLastError());
         } else if (kConvStride[l] == 2) {
@@ -1242,7 +1244,29 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             dp.a = m->h1, dp.w = m->proj2_pw, dp.bias = m->proj_b[1], dp.c = m->gx2, dp.post_scale = 1.f / m->proj2_pwscale;
             dp.M = M, dp.N = 1280, dp.K = 256, dp.tiles_n = 1280 / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
             const int grid = std::min(dp.tiles, m->wg_slots / 2);
-            if (m->dense_mode == 2) hipLaunchKernelGGL((dense_planes_kernel<false, false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+            static int dtrace_left = getenv("C3HIP_DENSE_TRACE") ? atoi(getenv("C3HIP_DENSE_TRACE")) : 0;  // debug: that launch is traced
+            if (dtrace_left > 0 && --dtrace_left == 0) {
+                static long long *tdev = nullptr;
+                static long long th[2 * 512 * 2];
+                if (!tdev) HIP_TRY(hipMalloc((void **)&tdev, sizeof(th)));
+                HIP_TRY(hipMemset(tdev, 0, sizeof(th)));
+                dp.trace = tdev;
+                if (m->dense_mode == 3) hipLaunchKernelGGL((dense_planes_pipe_kernel<false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+                else if (m->dense_mode == 1) hipLaunchKernelGGL((dense_planes_kernel<false, true, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+                else hipLaunchKernelGGL((dense_planes_kernel<false, false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(th, tdev, sizeof(th), hipMemcpyDeviceToHost));
+                fprintf(stderr, "dense trace (proj2, workgroup 0, shader cycles since the first stamp; tags: 1 chunk top, 2 staged, 3 requested, 4 matrix instructions issued, 5 tile done)\n");
+                for (int w = 0; w < 2; ++w) {
+                    fprintf(stderr, "  wave %d:", w * 4);
+                    for (int i = 0; i < 300 && th[(w * 512 + i) * 2]; ++i)
+                        fprintf(stderr, "%s%lld:%lld", th[(w * 512 + i) * 2] == 1 ? "\n    " : " ", th[(w * 512 + i) * 2], th[(w * 512 + i) * 2 + 1] - th[1]);
+                    fprintf(stderr, "\n");
+                }
+                dp.trace = nullptr;
+            } else
+            if (m->dense_mode == 4) hipLaunchKernelGGL(dense_planes_ws_kernel<false>, dim3(grid), dim3(kWsThreads), 0, s, dp);
+            else if (m->dense_mode == 3) hipLaunchKernelGGL(dense_planes_pipe_kernel<false>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             else if (m->dense_mode == 1) hipLaunchKernelGGL((dense_planes_kernel<false, true>), dim3(grid), dim3(kDnThreads), 0, s, dp);
             else hipLaunchKernelGGL(dense_planes_kernel<false>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             HIP_TRY(hipGetLastError());
@@ -1292,8 +1316,9 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
                     lp.trace = m->lstm_trace_dev;
                     hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true, 8>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
                     HIP_TRY(lstm_trace_print(m, s, "lstm2", Tn, "top -> matrix instructions issued -> gates exchanged -> cell + h written -> barrier -> next top"));
-                } else
-                hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+                } else {
+                    hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
+                }
             } else {
                 hipLaunchKernelGGL(lstm_recurrent_kernel_v2<160>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
             }
@@ -1654,9 +1679,79 @@ int c3_predict_wait(c3_model *m, int slot) {
     return 0;
 }
 
+// The synchronous call of the reference loop (_torch_predict: H2D, forward, D2H one after the other,
+// clair3/CallVariantsFromCffi.py:48-52).  A batch well beyond one chunk (256 full-alignment / 4096 pileup windows; env
+// C3HIP_PREDICT_CHUNK) is cut into chunks that travel through the submit / wait ring: the staging copy and H2D transfer of chunk
+// i + 1 and the D2H transfer of chunk i - 1 run under the kernels of chunk i, so the caller's ONE blocking call costs little more
+// than the kernels of the whole batch.  Rows do not depend on the cut (a window's row is independent of the batch it travels in).
+static int64_t predict_chunk(const c3_model *m) {
+    static const int64_t env = getenv("C3HIP_PREDICT_CHUNK") ? atoll(getenv("C3HIP_PREDICT_CHUNK")) : -1;
+    if (env >= 0) return env;  // 0: never cut
+    return m->kind == C3_KIND_PILEUP ? 4096 : 256;
+}
+
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host) {
-    TRY(c3_predict_submit(m, x_host, x_dtype, batch, y_host, 0));
-    return c3_predict_wait(m, 0);
+    if (!m) return fail("null model");
+    const int64_t chunk = predict_chunk(m);
+    if (chunk <= 0 || batch < 2 * chunk) {
+        TRY(c3_predict_submit(m, x_host, x_dtype, batch, y_host, 0));
+        return c3_predict_wait(m, 0);
+    }
+    constexpr int kRing = 3;
+    const int64_t wbytes = c3_model_window_bytes(m, x_dtype);
+    // A blocking call cannot hide its staging copy behind a previous batch, and that copy (pageable -> pinned, ~16 GB/s with the
+    // staging pool) is as long as the kernels of a full-alignment batch.  So the caller's pages are page-locked for the duration of
+    // the call (~0.1 ms per 24 MB, hipHostRegister) and the DMA engine reads them directly; if the range cannot be registered
+    // (e.g. a read-only mapping) the chunks go through the staging buffer as before.
+    static const bool want_reg = !getenv("C3HIP_PREDICT_REGISTER") || atoi(getenv("C3HIP_PREDICT_REGISTER")) != 0;
+    const size_t xbytes = (size_t)(batch * wbytes);
+    void *reg_base = nullptr;
+    if (want_reg && xbytes >= ((size_t)4 << 20) && !is_registered(x_host, xbytes)) {
+        const uintptr_t lo = (uintptr_t)x_host & ~(uintptr_t)4095, hi = ((uintptr_t)x_host + xbytes + 4095) & ~(uintptr_t)4095;
+        (void)hipSetDevice(m->device);
+        if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+            reg_base = (void *)lo;
+            std::lock_guard<std::mutex> lk(g_registered_mu);
+            g_registered.push_back({(const char *)lo, (size_t)(hi - lo)});
+        } else {
+            (void)hipGetLastError();  // not fatal: staged copy
+        }
+    }
+    int64_t n_sub = 0, n_done = 0;  // chunks submitted / waited for
+    int rc = 0;
+    // chunk sizes grow (chunk / 2, chunk, 2 chunk, 4 chunk, 4 chunk, ...): the kernels start after a SHORT first transfer, the
+    // later, longer transfers hide under ever longer kernel runs, and big chunks fill the chip better than small ones; a tail
+    // shorter than half the next size joins the last chunk
+    int64_t next = std::max<int64_t>(chunk / 2, 1);
+    for (int64_t off = 0; off < batch && rc == 0; ++n_sub) {
+        int64_t take = std::min(next, batch - off);
+        if (batch - off - take < next / 2 || batch - off - take < chunk / 2) take = batch - off;
+        take = std::min(take, max_microbatch(m));
+        if (n_sub - n_done == kRing) rc = c3_predict_wait(m, (int)(n_done++ % kRing));
+        if (rc == 0)
+            rc = c3_predict_submit(m, (const char *)x_host + off * wbytes, x_dtype, take, y_host + off * m->row, (int)(n_sub % kRing));
+        if (rc != 0) break;
+        off += take;
+        next = std::min(2 * next, 4 * chunk);
+    }
+    const std::string first_error = rc != 0 ? g_err : std::string();
+    for (; n_done < n_sub; ++n_done) {  // drain, also after an error: no slot stays busy behind a failed call
+        const int r = c3_predict_wait(m, (int)(n_done % kRing));
+        if (rc == 0) rc = r;
+    }
+    if (reg_base) {
+        {
+            std::lock_guard<std::mutex> lk(g_registered_mu);
+            for (size_t i = 0; i < g_registered.size(); ++i)
+                if (g_registered[i].p == (const char *)reg_base) {
+                    g_registered.erase(g_registered.begin() + i);
+                    break;
+                }
+        }
+        (void)hipHostUnregister(reg_base);
+    }
+    if (!first_error.empty()) g_err = first_error;
+    return rc;
 }
 
 int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, int64_t n_cols, const int32_t *starts_host,

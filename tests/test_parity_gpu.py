@@ -541,21 +541,23 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=23)
     x_p = syn.make_pileup_windows(70, seed=24)
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
-    fa_sets = [{"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0"},
+    fa_sets = [{"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "4"},  # stride-2 convs on the round-2 / the role-split dense kernel
+               {"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0"},
                {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0x48"},  # stride-2 convs of the plane path on the tiled GEMM
                {"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
                {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"},
                {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
                {"C3HIP_SPLIT_KIND": "1"}, {"C3HIP_WINOGRAD_F16MASK": "0"}, {"C3HIP_WINOGRAD_F16MASK": "0x24"}]
     for i, env in enumerate(fa_sets):
-        if i >= 3:
+        if i >= 5:
             env = dict(env, C3HIP_FA_PLANES="0")  # switches of the fp32-activation kernels
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f, what=f"FA {env}")
         for k in env:
             monkeypatch.delenv(k)
-    for env in [{"C3HIP_PROJ2_PLANES": "0"}, {"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
+    for env in [{"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "1"}, {"C3HIP_DENSE_MODE": "4"}, {"C3HIP_LSTM_OPT": "0"},
+                {"C3HIP_PROJ2_PLANES": "0"}, {"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
                 {"C3HIP_PROJ2_SPLIT": "0"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"},
                 {"C3HIP_LSTM1_F16": "0"}, {"C3HIP_LSTM2_F16": "0"},
                 {"C3HIP_LSTM1_F16": "0", "C3HIP_LSTM2_F16": "0", "C3HIP_PROJ2_SPLIT": "0", "C3HIP_L4_SPLIT": "0"}]:
@@ -564,3 +566,46 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
         util.assert_rows_match(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p, what=f"pileup {env}")
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_dense_kernel_forms_are_bit_identical(monkeypatch, oracle_mod):
+    """c3_dense.h holds four forms of the same contraction (round-2 kernel with staged / direct epilogue, chunk stream spread over
+    the matrix stream = default, role-split waves): same chunk order, same matrix instructions, same epilogue arithmetic -- the
+    rows must be EQUAL, also when a workgroup walks several tiles (600 pileup windows: 1550 projection tiles on 256 workgroups;
+    96 full-alignment windows: 156 + 90 stride-2 tiles) and on ragged last tiles"""
+    sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=61)
+    x_p = syn.make_pileup_windows(600 + 7, seed=62)
+    sd_f = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=63)
+    x_f = syn.make_fa_windows(96 + 3, seed=64)
+    y_p = make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p)
+    y_f = make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f)
+    util.assert_rows_match(y_p[:40], oracle_mod.pileup_forward(sd_p, x_p[:40], False), what="pileup, default dense kernel")
+    util.assert_rows_match(y_f[-24:], oracle_mod.fa_forward(sd_f, x_f[-24:], True), what="full alignment, default dense kernel")
+    for mode in ("0", "1", "4"):
+        monkeypatch.setenv("C3HIP_DENSE_MODE", mode)
+        assert np.array_equal(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p), f"pileup rows differ with C3HIP_DENSE_MODE={mode}"
+        assert np.array_equal(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f), f"full-alignment rows differ with C3HIP_DENSE_MODE={mode}"
+        monkeypatch.delenv("C3HIP_DENSE_MODE")
+
+
+def test_blocking_call_cut_into_chunks_gives_the_same_rows(oracle_mod):
+    """c3_predict (= _hip_predict, the reference loop's one blocking call per batch) sends a batch of 2+ chunks (256
+    full-alignment / 4096 pileup windows) through the submit / wait ring in growing pieces, from the caller's pages page-locked for
+    the call: the rows equal those of the same windows predicted in single-chunk calls, ragged tails included"""
+    sd_f = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=71)
+    x_f = syn.make_fa_windows(2 * 256 + 256 + 131, seed=72)  # pieces of 128, 256, 515
+    m = make_model(syn.FULL_ALIGNMENT, 8, True, sd_f)
+    y = m.predict_numpy(x_f)
+    parts = [m.predict_numpy(x_f[lo:lo + 300]) for lo in range(0, len(x_f), 300)]
+    assert np.array_equal(y, np.concatenate(parts))
+    util.assert_rows_match(y[-16:], oracle_mod.fa_forward(sd_f, x_f[-16:], True), what="last rows of a cut batch")
+    sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=73)
+    x_p = syn.make_pileup_windows(2 * 4096 + 4096 + 777, seed=74)
+    mp = make_model(syn.PILEUP, 18, False, sd_p)
+    yp = mp.predict_numpy(x_p)
+    parts = [mp.predict_numpy(x_p[lo:lo + 4000]) for lo in range(0, len(x_p), 4000)]
+    assert np.array_equal(yp, np.concatenate(parts))
+    # a read-only source (np.load(..., mmap_mode="r") slices in the worker) cannot always be page-locked: the staged path takes over
+    x_ro = x_f[:600].copy()
+    x_ro.setflags(write=False)
+    assert np.array_equal(m.predict_numpy(x_ro), y[:600])

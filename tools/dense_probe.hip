@@ -1,0 +1,86 @@
+// dense_probe.hip -- where the time of dense_planes_pipe_kernel goes on the LSTM2 projection shape (M = 33 * 1024, N = 1280,
+// K = 256): the kernel with parts switched off (ABL bits, c3_dense.h) and the round-2 kernel next to it.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/dense_probe.hip -o tools/bin/dense_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <string>
+static std::string g_err;
+static int fail(const char *, ...) { return -1; }
+#include "c3_dense.h"
+using namespace c3;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <class F>
+static float time_us(F launch, int reps) {
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) launch();
+    hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return 1e3f * ms / reps;
+}
+
+int main(int argc, char **argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 1024;
+    const int M = 33 * B, N = 1280, K = 256;
+    std::vector<uint16_t> ha((size_t)M * K * 2), hw((size_t)N * K * 2);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    // fp16 values in roughly (-1, 1): sign, exponent 8..14, random mantissa (hi and lo pieces alike: power realism)
+    for (auto &x : ha) { const uint32_t r = rnd(); x = (uint16_t)(((r >> 31) << 15) | ((8 + (r >> 8) % 7) << 10) | (r & 0x3ff)); }
+    for (auto &x : hw) { const uint32_t r = rnd(); x = (uint16_t)(((r >> 31) << 15) | ((6 + (r >> 8) % 7) << 10) | (r & 0x3ff)); }
+    void *da, *dw;
+    float *dc, *dbias;
+    CK(hipMalloc(&da, ha.size() * 2));
+    CK(hipMalloc(&dw, hw.size() * 2));
+    CK(hipMalloc((void **)&dc, (size_t)M * N * 4));
+    CK(hipMalloc((void **)&dbias, N * 4));
+    CK(hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(dbias, 0, N * 4));
+    DensePlanesParams dp;
+    dp.a = da, dp.w = dw, dp.bias = dbias, dp.c = dc, dp.post_scale = 1.f / 256.f;
+    dp.M = M, dp.N = N, dp.K = K, dp.tiles_n = N / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
+    const int grid = dp.tiles < 256 ? dp.tiles : 256;
+    const double gflop = 2.0 * M * N * K * 3 * 1e-9;
+    printf("proj2 shape M=%d N=%d K=%d: %d tiles on %d workgroups, %.1f GFLOP executed (three piece products)\n", M, N, K, dp.tiles, grid, gflop);
+    auto report = [&](const char *name, float us) { printf("  %-58s %7.1f us  %6.0f TF executed\n", name, us, gflop / us * 1e-3); };
+    report("round-2 kernel, staged epilogue", time_us([&] { hipLaunchKernelGGL(dense_planes_kernel<false>, dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20));
+    report("round-2 kernel, direct epilogue", time_us([&] { hipLaunchKernelGGL((dense_planes_kernel<false, true>), dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20));
+#define RUN(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_pipe_kernel<false, false, abl>), dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20))
+    RUN(0, "pipe kernel");
+    RUN(16, "  - result stores");
+    RUN(1, "  - operand loads");
+    RUN(2, "  - LDS staging writes");
+    RUN(3, "  - loads - staging");
+    RUN(8, "  - fragment reads");
+    RUN(4, "  - matrix instructions");
+    RUN(12, "  - fragment reads - matrix instructions");
+    RUN(19, "  - loads - staging - stores");
+    RUN(27, "  - loads - staging - stores - fragment reads (matrix only)");
+    RUN(59, "  matrix instructions only, no barriers");
+    RUN(23, "  fragment reads + barriers only");
+    RUN(28, "  loads + staging + barriers only");
+    RUN(15, "  stores + barriers only");
+#define RUNW(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_ws_kernel<false, abl>), dim3(grid), dim3(kWsThreads), 0, 0, dp); }, 20))
+    RUNW(0, "role-split kernel (8 multiplying + 4 moving waves)");
+    RUNW(16, "  - result stores");
+    RUNW(1, "  - operand loads");
+    RUNW(2, "  - LDS staging writes");
+    RUNW(3, "  - loads - staging");
+    RUNW(8, "  - fragment reads");
+    RUNW(4, "  - matrix instructions");
+    RUNW(12, "  - fragment reads - matrix instructions (move + store)");
+    RUNW(28, "  move only");
+    RUNW(19, "  multiply only (fragment reads + matrix instructions)");
+    RUNW(27, "  matrix instructions + barriers only");
+    CK(hipDeviceSynchronize());
+    return 0;
+}

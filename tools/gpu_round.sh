@@ -98,14 +98,15 @@ h=d['host_inclusive']
 print('  device one-in-flight %.0f | host B=256 %.0f (%.2f) | host B=1000 %.0f of %.0f (%.2f) | registered %s' % (d['one_batch_in_flight']['value'], h['value'], h['frac_of_device_resident_one_in_flight'], h['batch_1000']['value'], h['batch_1000']['device_resident_one_in_flight'], h['batch_1000']['frac_of_device_resident'], h.get('batch_1000_registered_source')))
 "; done ;;
     cprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w tools/conv_probe.hip -o /tmp/conv_probe && timeout 300 /tmp/conv_probe > gpurun_out/conv_probe.txt 2>&1; echo "cprobe rc=$?"; cat gpurun_out/conv_probe.txt ;;
-    r3ab) pyb() { python -c "
+    dmab) pyb() { python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('  value %.0f windows/s  %.4f ms/step (one in flight %.0f)' % (d['value'], d['ms_per_step'], d['one_batch_in_flight']['value']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
+print('  value %.0f windows/s  %.4f ms/step' % (d['value'], d['ms_per_step']), ' '.join('%s=%.1f' % (k, v['avg_us']) for k,v in d['kernels'].items()))
 "; }
-          for cfg in "0 0" "1 0" "1 1" "1 2"; do set -- $cfg; echo "== pileup C3HIP_LSTM_OPT=$1 C3HIP_DENSE_MODE=$2"; C3HIP_LSTM_OPT=$1 C3HIP_DENSE_MODE=$2 timeout 600 python bench.py --gpus 1 --workload pileup --no-cpu-baseline --no-host-leg --streams 1 --steps 100 --warmup 5 2> gpurun_out/r3ab.err | pyb; done
-          for dm in 0 2; do echo "== full_alignment C3HIP_DENSE_MODE=$dm"; C3HIP_DENSE_MODE=$dm timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --no-host-leg --streams 1 --steps 100 --warmup 5 2> gpurun_out/r3ab.err | pyb; done
-          echo "== LSTM traces"; C3HIP_LSTM_TRACE=4 timeout 600 python bench.py --gpus 1 --workload pileup --no-cpu-baseline --no-host-leg --streams 1 --steps 10 --warmup 2 2>&1 >/dev/null | grep -A40 "trace (workgroup" | cut -c1-160 ;;
+          for dm in ${DENSE_MODES:-3 4 3 4}; do echo "== pileup C3HIP_DENSE_MODE=$dm"; C3HIP_DENSE_MODE=$dm timeout 600 python bench.py --gpus 1 --workload pileup --no-cpu-baseline --no-host-leg --streams 1 --steps 100 --warmup 5 2> gpurun_out/dmab.err | pyb; done
+          for dm in ${DENSE_MODES:-3 4 3 4}; do echo "== full_alignment C3HIP_DENSE_MODE=$dm"; C3HIP_DENSE_MODE=$dm timeout 600 python bench.py --gpus 1 --workload full_alignment --no-cpu-baseline --no-host-leg --streams 1 --steps 100 --warmup 5 2> gpurun_out/dmab.err | pyb; done ;;
+    traces) C3HIP_LSTM_TRACE=4 C3HIP_DENSE_TRACE=4 timeout 600 python bench.py --gpus 1 --workload pileup --no-cpu-baseline --no-host-leg --streams 1 --steps 10 --warmup 2 2>&1 >/dev/null | grep -A40 "trace (" | cut -c1-400 ;;
+    dprobe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/dense_probe.hip -o /tmp/dense_probe && timeout 300 /tmp/dense_probe > gpurun_out/dense_probe.txt 2>&1; echo "dprobe rc=$?"; cat gpurun_out/dense_probe.txt ;;
     info)  (rocminfo | grep -E "Name|Compute Unit|Max Clock|Wavefront" | head -40; lscpu | head -20; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null) > gpurun_out/info.txt 2>&1 ;;
   esac
 done
