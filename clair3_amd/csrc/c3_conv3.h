@@ -61,6 +61,12 @@ struct PlaneConvParams {
     float post_scale;     // the weights are packed times a power of two (pick_wscale); undone here, exactly
     int M, H, W;
     int tiles;            // ceil(M / 256) * (C / 64)
+    // SRC8 (first residual block of Clair3_F, 8-channel windows): conv1 (clair3/model.py:316-317,391) is computed in here
+    // from the int8 windows instead of being read as plane activations
+    const int8_t *x8 = nullptr;      // [B][Hin][Win][8] windows
+    const uint32_t *c1w = nullptr;   // conv1_i8_f16_kernel's weight fragments (c3_conv1.h): [5 k-steps][2 column blocks][2 pieces][64 lanes][16 B]
+    const float *c1b = nullptr;      // conv1 bias [64] (BatchNorm folded)
+    int Hin = 0, Win = 0;
 };
 
 // split four fp32 values into their fp16 pieces and store them behind `off` (hi plane) / `off + 128` (lo plane)
@@ -82,14 +88,29 @@ __device__ __forceinline__ f32x4 load_planes4(const __amdgpu_buffer_rsrc_t rsrc,
 // ABL: ablation switches of tools/conv_probe.hip (0 in the product): 1 no weight loads, 2 no halo loads after the first tile,
 // 4 no epilogue, 8 no matrix instructions, 64 shader-clock trace of two
 // workgroups (wave 0) at phase boundaries into p.res ([2][256] x {tag, clock}).
-template <int C, bool RES, int ABL = 0>
+// SRC8 (C = 64 only; the first residual block behind the 8-channel conv1): conv1's output never exists in HBM.
+//   1  the INPUT halo rows are computed here from the int8 windows (conv1 + BatchNorm + ReLU, split into the two fp16 pieces,
+//      written straight into the LDS halo tile): 292 rows x 64 channels = 10 groups of 32 pixels over the 8 waves, 20 matrix
+//      instructions of 32 cycles per group against conv1_i8_f16_kernel's weight fragments (kept in LDS), taps requested
+//      during the previous tile's last chunk;
+//   2  the RESIDUAL (= conv1's output at the tile's own pixels) is computed in the accumulators' own layout -- conv1 with the
+//      weights as first operand leaves a lane the same 4 consecutive channels of the same pixel as this kernel -- and is the
+//      value the accumulators start from (times 1 / post_scale, a power of two), 10 matrix instructions per 32 x 32 block.
+// conv1 costs 7 MFLOP per window against 56 for each of these layers; what it saves is its own launch (16 us, store-bound) and
+// 150 MB of HBM traffic per 256 windows (its output written once and read twice).
+template <int C, bool RES, int ABL = 0, int SRC8 = 0>
 __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConvParams p) {
+    static_assert(SRC8 == 0 || C == 64, "conv1 feeds the 64-channel block only");
+    static_assert(SRC8 != 2 || RES, "SRC8 = 2 replaces the residual read");
     constexpr int NS = C / 64;     // input slabs = output column tiles
     constexpr int PIXB = 4 * C;    // bytes per pixel
     constexpr int NCH = 9 * NS;    // weight chunks per tile
-    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes];
+    constexpr int kC1WBytes = 5 * 2 * 2 * 64 * 16;
+    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes + (SRC8 ? kC1WBytes + 256 : 0)];
     char *const halo = smem;
     char *const bbuf = smem + kPlHaloBytes;
+    char *const c1w_lds = smem + kPlHaloBytes + 3 * kPlBBytes;
+    float *const c1b_lds = reinterpret_cast<float *>(c1w_lds + kC1WBytes);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,9 +147,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         }
     };
     auto halo_write = [&](const pl_u32x4 (&h)[kPlHaloLoads]) __attribute__((always_inline)) {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));  // the ten LDS addresses are recomputed here, not carried (and spilled) across the tile loop
 #pragma unroll
         for (int j = 0; j < kPlHaloLoads; ++j) {
-            const int idx = tid + kPlThreads * j;
+            const int idx = tid_ + kPlThreads * j;
             const int row = idx >> 4, pos = idx & 15;
             if (row < T) *reinterpret_cast<pl_u32x4 *>(halo + row * kPlRowB + pos * 16) = h[j];
         }
@@ -152,6 +175,101 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     const int b_rd = (wn * 32 + frow) * kPlRowB + kh * 16;
     const int cb0 = wn * 32 + 4 * kh;  // first of this lane's output channels inside the 64-channel slab tn
 
+    // ---- conv1 inside this kernel (SRC8).  Lane (pixel m = lane & 31 of a 32-pixel group, tap half kh): k-step t holds taps
+    // 2 t / 2 t + 1 in the two lane halves, 8 channels each (c3_conv1.h: the int8 bytes b become exact fp16 values b / 128 with
+    // one v_perm_b32 + one v_pk_add_f16 per pair; the weights are two fp16 pieces of 1.28 W').
+    typedef uint32_t c1u2 __attribute__((ext_vector_type(2)));
+    const int c1_rowB = p.Win * 8;
+    const __amdgpu_buffer_rsrc_t x8rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.x8)) - (SRC8 ? c1_rowB + 8 : 0), 0,
+        SRC8 ? (uint32_t)((int64_t)(p.M / (p.H * p.W)) * p.Hin * c1_rowB + c1_rowB + 8) : 0u, 0x00020000);
+    auto c1_request = [&](int pix, c1u2 (&d)[5]) __attribute__((always_inline)) {
+        // the per-lane tap geometry is recomputed here every time: left to itself hipcc keeps it (15 registers) alive across the
+        // whole tile loop, and the 248-register main loop then spills the halo registers
+        int kh_ = kh;
+        asm volatile("" : "+v"(kh_));
+        const bool valid = (unsigned)pix < (unsigned)p.M;
+        const int b = pix / HW, r = pix - b * HW;
+        const int oy = r / W, ox = r - oy * W;
+        const uint32_t base = (uint32_t)(((b * p.Hin + 2 * oy) * p.Win + 2 * ox) * 8);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int tap = 2 * t + kh_;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            const bool ok = valid && tap < 9 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            d[t] = __builtin_bit_cast(c1u2, __builtin_amdgcn_raw_buffer_load_b64(x8rsrc, ok ? base + (uint32_t)(ky * c1_rowB + kx * 8) : 0x80000000u, 0, 0));
+        }
+    };
+    auto c1_widen = [&](c1u2 d) __attribute__((always_inline)) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        pl_u32x4 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t x = d[h] ^ 0x80808080u;
+            const uint32_t p01 = __builtin_amdgcn_perm(0x48484848u, x, 0x04010400u);  // [x.b0, 0x48, x.b1, 0x48]
+            const uint32_t p23 = __builtin_amdgcn_perm(0x48484848u, x, 0x04030402u);
+            const h2 nine = {(_Float16)-9.0f, (_Float16)-9.0f};
+            o[2 * h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, p01) + nine);
+            o[2 * h + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, p23) + nine);
+        }
+        return o;
+    };
+    // conv1 of one 32-pixel group for column block cb (32 output channels): acc = sum over 5 k-steps, two weight pieces each
+    auto c1_block = [&](const c1u2 (&d)[5], int cb) __attribute__((always_inline)) {
+        f32x16 c;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const pl_u32x4 a = c1_widen(d[t]);
+            const pl_u32x4 w1 = *reinterpret_cast<const pl_u32x4 *>(c1w_lds + (((t * 2 + cb) * 2 + 1) * 64 + lane) * 16);
+            const pl_u32x4 w0 = *reinterpret_cast<const pl_u32x4 *>(c1w_lds + (((t * 2 + cb) * 2 + 0) * 64 + lane) * 16);
+            c = mma(c, w1, a);
+            c = mma(c, w0, a);
+        }
+        return c;
+    };
+    float omax = 0.f;
+    // SRC8 = 1: halo rows 32 g .. 32 g + 31 (pixel m_lo + row) for g = wave and wave + 8
+    c1u2 c1d[2][5];
+    auto c1_halo_request = [&](int mbase) __attribute__((always_inline)) {
+        const int m_lo = mbase - W - 1;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) c1_request(m_lo + 32 * (wave + 8 * gi) + frow, c1d[gi]);  // groups >= 10: rows beyond T, dropped below
+    };
+    auto c1_halo_write = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int row = 32 * (wave + 8 * gi) + frow;
+            if (32 * (wave + 8 * gi) >= T) continue;  // wave-uniform
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const f32x16 c = c1_block(c1d[gi], cb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(c1b_lds + 32 * cb + 8 * q + 4 * kh);
+                    f32x4 val;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __int_as_float(max(__float_as_int(c[4 * q + e] + b4[e]), 0));
+                    omax = fmaxf(omax, fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3])));
+                    u32x2 pc[2];
+                    split2_f16(val, pc);
+                    if (row < T) {
+                        char *dst = halo + row * kPlRowB + (32 * cb + 8 * q + 4 * kh) * 2;
+                        *reinterpret_cast<u32x2 *>(dst) = pc[0];
+                        *reinterpret_cast<u32x2 *>(dst + 128) = pc[1];
+                    }
+                }
+            }
+        }
+    };
+    // SRC8 = 2: the residual of this wave's two 32 x 32 blocks (pixels m0 + lrow[i], channels 32 wn .. 32 wn + 31)
+    auto c1_res_request = [&](int mbase) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) c1_request(mbase + lrow[i], c1d[i]);
+    };
+
     int tr_n = 0;
     auto trace = [&](int tag) __attribute__((always_inline)) {
         if constexpr (ABL & 64) {
@@ -171,15 +289,26 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     // and no matrix instruction ever waits for an LDS read issued right in front of it.  (With two buffers and the barrier at
     // the chunk boundary the compiler's schedule exposed two LDS round trips plus the barrier per chunk: 2400 cycles per chunk
     // for 1536 cycles of matrix work on the two waves of a SIMD.)
-    pl_u32x4 hreg[kPlHaloLoads];
+    pl_u32x4 hreg[SRC8 == 1 ? 1 : kPlHaloLoads];
     pl_u32x4 rb[3][NBP];
-    halo_issue(hreg, m0, 0);
+    if constexpr (SRC8) {
+        for (int i = tid; i < kC1WBytes / 16; i += kPlThreads)
+            *reinterpret_cast<pl_u32x4 *>(c1w_lds + i * 16) = *reinterpret_cast<const pl_u32x4 *>(reinterpret_cast<const char *>(p.c1w) + i * 16);
+        if (tid < 64) c1b_lds[tid] = p.c1b[tid];
+    }
+    if constexpr (SRC8 == 1) c1_halo_request(m0);
+    else halo_issue(hreg, m0, 0);
     b_issue(rb[0], 0);
     b_issue(rb[1], 1);
     b_issue(rb[2], 2);
     if (tid < 16) *reinterpret_cast<pl_u32x4 *>(halo + T * kPlRowB + tid * 16) = pl_u32x4{0u, 0u, 0u, 0u};
     trace(2);
-    halo_write(hreg);
+    if constexpr (SRC8 == 1) {
+        lds_barrier();  // conv1's weight fragments and bias are in LDS
+        c1_halo_write();
+    } else {
+        halo_write(hreg);
+    }
     b_write(rb[0], 0);
     b_write(rb[1], 1);
     lds_barrier();
@@ -208,8 +337,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         }
     };
 
-    float omax = 0.f;
     for (;;) {
+        // SRC8 = 2: this tile's residual taps, requested first thing: the tap-mask arithmetic below runs while they arrive.  (Held
+        // any longer -- requested under the previous tile's epilogue, next to its 40 halo registers -- they pushed the kernel
+        // into scratch, with spill stores waiting on just-issued loads: 70 instead of 53 us.)
+        if constexpr (SRC8 == 2) c1_res_request(m0);
         // tap validity of this lane's two output pixels: bit t set when tap t = (dh + 1) * 3 + (dw + 1) lies inside the window
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -231,10 +363,26 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         const int m0n = more ? (xcd_tile_index(vn, p.tiles) / NS) * kPlBM : 0;
 
         f32x16 acc[2];
+        if constexpr (SRC8 == 2) {
+            // the accumulators start from the residual: relu(conv1 + bias) / post_scale, same (pixel, channel) per element
+            const float inv_post = 1.f / p.post_scale;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                const f32x16 c = c1_block(c1d[i], wn);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(c1b_lds + 32 * wn + 8 * q + 4 * kh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][4 * q + e] = __int_as_float(max(__float_as_int(c[4 * q + e] + b4[e]), 0)) * inv_post;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        }
         // first fragments of the tile's first chunk (the halo rows and LDS buffer 0 are in place behind a barrier)
         set_asrc(0);
         frags(0, 0, 0);
@@ -250,7 +398,10 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             if constexpr (!(ABL & 1)) b_issue(rb[tap % 3], cc + 3 < NCH ? cc + 3 : cc + 3 - NCH);  // set tap % 3 went to LDS two chunks ago
             const bool sw = tap == 8 && (!last || more);
             if (tap == 8) {
-                if constexpr (!(ABL & 2))
+                // NS = 1 (C = 64): the only switch is the one to the next tile, and its halo rows are requested AFTER the tap loop
+                // (below) -- they have the whole epilogue to arrive, and the 40 registers they land in are not held under the
+                // last chunk's matrix phase, where the kernel's register demand peaks
+                if constexpr (NS > 1 && !(ABL & 2))
                     if (sw) halo_issue(hreg, last ? m0n : m0, last ? 0 : slab + 1);
             }
             __builtin_amdgcn_sched_barrier(0);  // the global loads stay ahead of the matrix phase they fly under
@@ -289,6 +440,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
                     if constexpr (!(ABL & 1)) b_write(rb[(tap + 2) % 3], (tap + 2) % 3);
                 }
             }
+            if constexpr (NS > 1)
             if (tap == 8 && !last) {  // slab switch inside the tile
                 lds_barrier();        // every wave has finished reading the old slab
                 if constexpr (!(ABL & 2)) halo_write(hreg);
@@ -303,6 +455,13 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         // (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the wave's 32.  The tile crosses LDS once (the halo region is free now:
         // 256 rows x 272 B of fp32) so that every global access of the epilogue is a full 16 bytes of 8 consecutive
         // channels, 8 lanes per 128-byte plane row: (pixel, channel group) items, residual added, ReLU, split, two stores.
+        if constexpr (NS == 1) {
+            if constexpr (SRC8 == 1) {
+                if (more) c1_halo_request(m0n);
+            } else if constexpr (!(ABL & 2)) {
+                if (more) halo_issue(hreg, m0n, 0);
+            }
+        }
         lds_barrier();  // all waves are done with the halo rows
         trace(30);
         if constexpr (ABL & 4) {
@@ -317,7 +476,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             const int idx = tid + kPlThreads * j;
             const int m = m0 + (idx >> 3);
             ioff[j] = m < p.M ? (uint32_t)m * (uint32_t)PIXB + (uint32_t)(tn * 256 + (idx & 7) * 16) : kPlOob;
-            if constexpr (RES) {
+            if constexpr (RES && SRC8 != 2) {
                 rh[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[j], 0, 0));
                 rl[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[j] + 128, 0, 0));
             }
@@ -341,7 +500,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             const uint32_t off = ioff[j];
             f32x4 a = *reinterpret_cast<const f32x4 *>(halo + pr * kPlRowB + g * 32);
             f32x4 b = *reinterpret_cast<const f32x4 *>(halo + pr * kPlRowB + g * 32 + 16);
-            if constexpr (RES) {
+            if constexpr (RES && SRC8 != 2) {
                 const f16x8 h8 = __builtin_bit_cast(f16x8, rh[j]), l8 = __builtin_bit_cast(f16x8, rl[j]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -366,7 +525,8 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         trace(32);
         if (!more) break;
         lds_barrier();  // the staged tile has been read back
-        if constexpr (!(ABL & 2)) halo_write(hreg);
+        if constexpr (SRC8 == 1) c1_halo_write();
+        else if constexpr (!(ABL & 2)) halo_write(hreg);
         lds_barrier();
         trace(33);
         v = vn, m0 = m0n;

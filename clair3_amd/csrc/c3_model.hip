@@ -191,6 +191,7 @@ struct c3_model {
     bool f16_ok = true;             // cleared by c3_predict_wait when a batch came back non-finite: every layer then runs its fp32-MFMA form
     float *conv1_wfrag16 = nullptr; // conv1_i8_f16_kernel: [5][2][2 pieces][64][8 fp16]
     bool conv1_f16 = true;          // conv1 on fp16 matrix instructions (int8 inputs exact, weights as two pieces); env C3HIP_CONV1_F16
+    bool conv1_fused = true;        // 8-channel conv1 computed inside res1a / res1b (c3_conv3.h SRC8): no conv1 launch, no conv1 planes; env C3HIP_CONV1_FUSED
     unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
     int wg_slots = 512;             // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
     unsigned wino_n64_mask = 0x1b6; // layers using the 32-tile x 64-cout workgroup shape; env C3HIP_WINOGRAD_N64MASK
@@ -941,8 +942,15 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
     for (int l = 0; l < 9; ++l) {
         const int Cout = kConvCout[l];
         const int M = (int)(n * hh[l + 1] * ww[l + 1]);
-        const double flops = 2.0 * M * Cout * 9.0 * cin;
-        const double bytes = (l == 0 ? 1.0 : 4.0) * n * hh[l] * ww[l] * cin + 4.0 * M * Cout * (l % 3 == 2 ? 2 : 1) + 4.0 * Cout * 9.0 * cin;
+        const bool fuse1 = m->conv1_fused && m->C == 8 && !m->keep && ww[1] <= kPlMaxW;  // conv1 inside the first residual block (c3_conv3.h SRC8)
+        if (l == 0 && fuse1) {  // no launch, no conv1 planes: res1a computes its input rows, res1b its residual, from the windows
+            cin = Cout;
+            continue;
+        }
+        double flops = 2.0 * M * Cout * 9.0 * cin;
+        double bytes = (l == 0 ? 1.0 : 4.0) * n * hh[l] * ww[l] * cin + 4.0 * M * Cout * (l % 3 == 2 ? 2 : 1) + 4.0 * Cout * 9.0 * cin;
+        if (fuse1 && l == 1) flops += 2.0 * M * 64.0 * 9.0 * m->C, bytes += 1.0 * n * hh[0] * ww[0] * m->C - 4.0 * M * 64;  // conv1's algorithmic work rides here
+        if (fuse1 && l == 2) bytes += 1.0 * n * hh[0] * ww[0] * m->C - 4.0 * M * 64;  // residual from the windows, not from conv1 planes
         ProfScope ps(m, s, kFaLayerTag[l], flops, bytes);
         if (l == 0 && cin == 8) {
             ps.mfma(2.0 * ((M + 31) / 32 * 32) * 64.0 * 80.0 * 2, true);
@@ -989,14 +997,24 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             cp.M = M, cp.H = hh[l], cp.W = ww[l];
             const int tiles_m = (M + kPlBM - 1) / kPlBM;
             cp.tiles = tiles_m * (Cout / 64);
-            ps.mfma(2.0 * tiles_m * kPlBM * (double)Cout * 9.0 * cin * 3, true);
+            const bool src8 = fuse1 && (l == 1 || l == 2);
+            if (src8) {
+                cp.x8 = x, cp.c1w = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.c1b = m->conv_b[0], cp.Hin = hh[0], cp.Win = ww[0];
+                if (l == 1) cp.x = nullptr;
+                else cp.res = nullptr;
+            }
+            // SRC8: + conv1 for 320 halo rows (res1a) / the tile's 256 pixels (res1b), two piece products of K = 80
+            ps.mfma(2.0 * tiles_m * kPlBM * (double)Cout * 9.0 * cin * 3 + (src8 ? 2.0 * tiles_m * (l == 1 ? 320 : 256) * 64.0 * 80.0 * 2 : 0.0), true);
             // persistent: one workgroup per tile when they all fit (2 per CU), else wg_slots rounded down so that a
             // workgroup's tiles share their column tile (c3_conv3.h)
             int g = cp.tiles;
             const int cus = m->wg_slots / 2, unit = 8 * (Cout / 64);  // one 512-thread workgroup (114 KB of LDS) per CU
             if (g > cus) g = std::max(unit, cus / unit * unit);
             const dim3 grid(g), block(kPlThreads);
-            if (Cout == 64) {
+            if (Cout == 64 && src8) {
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true, 0, 2>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false, 0, 1>), grid, block, 0, s, cp);
+            } else if (Cout == 64) {
                 if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true>), grid, block, 0, s, cp);
                 else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false>), grid, block, 0, s, cp);
             } else if (Cout == 128) {
@@ -1459,6 +1477,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_LSTM2_F16")) m->lstm2_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_F16")) m->lstm1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_F16")) m->conv1_f16 = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_CONV1_FUSED")) m->conv1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM_OPT")) m->lstm_opt = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM_TRACE")) m->lstm_trace_left = m->lstm2_trace_left = atoi(e);

@@ -541,7 +541,8 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=23)
     x_p = syn.make_pileup_windows(70, seed=24)
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
-    fa_sets = [{"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "4"},  # stride-2 convs on the round-2 / the role-split dense kernel
+    fa_sets = [{"C3HIP_CONV1_FUSED": "0"},  # conv1 as its own launch, its planes read by res1a / res1b
+               {"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "4"},  # stride-2 convs on the round-2 / the role-split dense kernel
                {"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0"},
                {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0x48"},  # stride-2 convs of the plane path on the tiled GEMM
                {"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
@@ -549,7 +550,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
                {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
                {"C3HIP_SPLIT_KIND": "1"}, {"C3HIP_WINOGRAD_F16MASK": "0"}, {"C3HIP_WINOGRAD_F16MASK": "0x24"}]
     for i, env in enumerate(fa_sets):
-        if i >= 5:
+        if i >= 6:
             env = dict(env, C3HIP_FA_PLANES="0")  # switches of the fp32-activation kernels
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -609,3 +610,20 @@ def test_blocking_call_cut_into_chunks_gives_the_same_rows(oracle_mod):
     x_ro = x_f[:600].copy()
     x_ro.setflags(write=False)
     assert np.array_equal(m.predict_numpy(x_ro), y[:600])
+
+
+def test_conv1_inside_the_first_residual_block(monkeypatch, oracle_mod):
+    """8-channel windows: conv1 is computed inside res1a (its input halo rows) and res1b (its residual) from the int8 windows
+    (c3_conv3.h SRC8) instead of being launched, written and read back.  Several tiles per workgroup (330 windows: 987 stage-1
+    tiles on 256 workgroups), a ragged last tile, windows at both ends of the batch; against the oracle and against the unfused
+    launches (the residual is the full fp32 conv1 value instead of its two fp16 pieces: ~1e-7 apart, labels identical)"""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=81)
+    x = syn.make_fa_windows(330, seed=82)
+    y = make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)
+    sel = np.r_[0:12, 159:171, 318:330]
+    util.assert_rows_match(y[sel], oracle_mod.fa_forward(sd, x[sel], True), what="conv1 inside res1a / res1b")
+    monkeypatch.setenv("C3HIP_CONV1_FUSED", "0")
+    y0 = make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)
+    monkeypatch.delenv("C3HIP_CONV1_FUSED")
+    assert np.abs(y - y0).max() < 2e-6
+    assert (y[:, :21].argmax(1) == y0[:, :21].argmax(1)).all() and (y[:, 21:24].argmax(1) == y0[:, 21:24].argmax(1)).all()
