@@ -63,6 +63,7 @@ struct PlaneConvParams {
     int tiles;            // ceil(M / 256) * (C / 64)
     // SRC8 (first residual block of Clair3_F, 8-channel windows): conv1 (clair3/model.py:316-317,391) is computed in here
     // from the int8 windows instead of being read as plane activations
+    float *spp = nullptr;            // SPPF: PyramidPolling output [B][14 bins][C] (clair3/model.py:250-279), written instead of `out`
     const int8_t *x8 = nullptr;      // [B][Hin][Win][8] windows
     const uint32_t *c1w = nullptr;   // conv1_i8_f16_kernel's weight fragments (c3_conv1.h): [5 k-steps][2 column blocks][2 pieces][64 lanes][16 B]
     const float *c1b = nullptr;      // conv1 bias [64] (BatchNorm folded)
@@ -98,7 +99,13 @@ __device__ __forceinline__ f32x4 load_planes4(const __amdgpu_buffer_rsrc_t rsrc,
 //      value the accumulators start from (times 1 / post_scale, a power of two), 10 matrix instructions per 32 x 32 block.
 // conv1 costs 7 MFLOP per window against 56 for each of these layers; what it saves is its own launch (16 us, store-bound) and
 // 150 MB of HBM traffic per 256 windows (its output written once and read twice).
-template <int C, bool RES, int ABL = 0, int SRC8 = 0>
+// SPPF (last convolution of the network, 12 x 5 windows): PyramidPolling (clair3/model.py:245-279: 3x3, 2x2 and 1x1 max-pooling
+// bins over the 12 x 5 window, W padded on the right) is this kernel's epilogue.  Tiles are aligned to WINDOWS for that -- a tile
+// starts every 4 windows = 240 pixels and its last 16 rows are computed and dropped (the same 94 % the 240 tiles of 256
+// workgroups use today; 256 windows = 64 x 4 tiles = one per CU) -- so every bin of a window lies inside one tile: the ReLU'd
+// fp32 tile goes back into LDS, thread (window, channel, level) takes the maxima of its bins over 60 LDS values and stores
+// them.  No plane output (its only reader was the pooling kernel), no pooling launch, no atomics.
+template <int C, bool RES, int ABL = 0, int SRC8 = 0, bool SPPF = false>
 __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConvParams p) {
     static_assert(SRC8 == 0 || C == 64, "conv1 feeds the 64-channel block only");
     static_assert(SRC8 != 2 || RES, "SRC8 = 2 replaces the residual read");
@@ -123,10 +130,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     // PERSISTENT: workgroup w walks the tiles of virtual blocks w, w + G, w + 2G, ... (XCD-aware order).  The host launches
     // either one workgroup per tile or G with (G / 8) % NS == 0, so the column tile tn -- and with it the weight stream --
     // is the same for every tile of a workgroup: the weight pipeline simply keeps running across tile boundaries.
+    const int tile_stride = SPPF ? (kPlBM / HW) * HW : kPlBM;  // SPPF: whole windows per tile (4 x 60 pixels)
     int v = blockIdx.x;
     int tile = xcd_tile_index(v, p.tiles);
     const int tn = tile % NS;
-    int m0 = (tile / NS) * kPlBM;
+    int m0 = (tile / NS) * tile_stride;
 
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x), 0, (uint32_t)((int64_t)p.M * PIXB), 0x00020000);
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         }
         const int vn = v + G;
         const bool more = vn < p.tiles;
-        const int m0n = more ? (xcd_tile_index(vn, p.tiles) / NS) * kPlBM : 0;
+        const int m0n = more ? (xcd_tile_index(vn, p.tiles) / NS) * tile_stride : 0;
 
         f32x16 acc[2];
         if constexpr (SRC8 == 2) {
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         for (int j = 0; j < 4; ++j) {
             const int idx = tid + kPlThreads * j;
             const int m = m0 + (idx >> 3);
-            ioff[j] = m < p.M ? (uint32_t)m * (uint32_t)PIXB + (uint32_t)(tn * 256 + (idx & 7) * 16) : kPlOob;
+            ioff[j] = m < p.M && (idx >> 3) < tile_stride ? (uint32_t)m * (uint32_t)PIXB + (uint32_t)(tn * 256 + (idx & 7) * 16) : kPlOob;
             if constexpr (RES && SRC8 != 2) {
                 rh[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[j], 0, 0));
                 rl[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[j] + 128, 0, 0));
@@ -514,12 +522,49 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
                 b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
             }
             omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+            if constexpr (SPPF) {  // the finished values go back to their place in the LDS tile for the pooling pass
+                *reinterpret_cast<f32x4 *>(halo + pr * kPlRowB + g * 32) = a;
+                *reinterpret_cast<f32x4 *>(halo + pr * kPlRowB + g * 32 + 16) = b;
+                continue;
+            }
             u32x2 pa[2], pb[2];
             split2_f16(a, pa);
             split2_f16(b, pb);
             const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
             __builtin_amdgcn_raw_buffer_store_b128(hi, orsrc, off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(lo, orsrc, off + 128, 0, 0);
+        }
+        if constexpr (SPPF) {
+            // thread (channel c = tid & 63, window w = (tid >> 6) & 3 of the tile, level half = tid >> 8): half 0 takes the nine
+            // 3x3 bins (rows 4 apart, column pairs {0,1} {2,3} {4,pad}), half 1 the four 2x2 bins (rows 6 apart, columns {0,1,2}
+            // {3,4,pad}) and the 1x1 bin.  The padded bins include F.pad's zero in their maximum: values are >= 0 after the ReLU
+            // anyway.  A wave reads 64 consecutive channels of one pixel per instruction: conflict-free.
+            lds_barrier();
+            const int sc = tid & 63, sw = (tid >> 6) & 3, half = tid >> 8;
+            const int wb = m0 / HW + sw;  // window index
+            const float *src = reinterpret_cast<const float *>(halo + (sw * HW) * kPlRowB) + sc;
+            constexpr int RS = kPlRowB / 4;  // floats between consecutive pixels
+            float mx[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) mx[k] = 0.f;
+            if (half == 0) {
+#pragma unroll
+                for (int h = 0; h < 12; ++h)
+#pragma unroll
+                    for (int w = 0; w < 5; ++w) mx[(h / 4) * 3 + w / 2] = fmaxf(mx[(h / 4) * 3 + w / 2], src[(h * 5 + w) * RS]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 12; ++h)
+#pragma unroll
+                    for (int w = 0; w < 5; ++w) mx[(h / 6) * 2 + w / 3] = fmaxf(mx[(h / 6) * 2 + w / 3], src[(h * 5 + w) * RS]);
+                mx[4] = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+            }
+            if (wb * HW < p.M) {
+                float *dst = p.spp + ((int64_t)wb * 14 + (half ? 9 : 0)) * C + tn * 64 + sc;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (k < (half ? 5 : 9)) dst[(int64_t)k * C] = mx[k];
+            }
         }
         }
         trace(32);

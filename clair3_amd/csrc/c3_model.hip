@@ -191,6 +191,7 @@ struct c3_model {
     bool f16_ok = true;             // cleared by c3_predict_wait when a batch came back non-finite: every layer then runs its fp32-MFMA form
     float *conv1_wfrag16 = nullptr; // conv1_i8_f16_kernel: [5][2][2 pieces][64][8 fp16]
     bool conv1_f16 = true;          // conv1 on fp16 matrix instructions (int8 inputs exact, weights as two pieces); env C3HIP_CONV1_F16
+    bool spp_fused = true;          // PyramidPolling as the epilogue of res3b (c3_conv3.h SPPF; 12 x 5 windows); env C3HIP_SPP_FUSED
     bool conv1_fused = true;        // 8-channel conv1 computed inside res1a / res1b (c3_conv3.h SRC8): no conv1 launch, no conv1 planes; env C3HIP_CONV1_FUSED
     unsigned wino_p_mask = 0x1b6;   // layers using the persistent 32x64 kernel (c3_wino_p.h); env C3HIP_WINOGRAD_PMASK
     int wg_slots = 512;             // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
@@ -285,7 +286,7 @@ static int launch_gemm(hipStream_t s, const typename Loader::Params &lp, const f
 // order by the tail kernel, so a window's probabilities are bit-identical whatever batch it travels in.
 static int l4_splits(const c3_model *m) {
     const int nk = m->K4 / kBK;
-    const int want = m->kind == C3_KIND_PILEUP ? 15 : 28;
+    const int want = m->kind == C3_KIND_PILEUP ? 15 : 28;  // measured against 22 / 30 / 33 (pileup) and 14 / 56 (full alignment), 128 x 128 tiles too
     int best = 1;
     for (int s = 1; s <= nk && s <= want; ++s)
         if (nk % s == 0) best = s;
@@ -998,13 +999,20 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             const int tiles_m = (M + kPlBM - 1) / kPlBM;
             cp.tiles = tiles_m * (Cout / 64);
             const bool src8 = fuse1 && (l == 1 || l == 2);
+            // PyramidPolling as the epilogue of the last convolution (c3_conv3.h SPPF): 12 x 5 windows, four whole windows per tile
+            const bool sppf = l == 8 && m->spp_fused && !m->keep && hh[9] == 12 && ww[9] == 5 && 14 * 256 == m->K4;
+            if (sppf) {
+                cp.spp = m->spp;
+                cp.tiles = (int)((n + 3) / 4) * (Cout / 64);
+            }
             if (src8) {
                 cp.x8 = x, cp.c1w = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.c1b = m->conv_b[0], cp.Hin = hh[0], cp.Win = ww[0];
                 if (l == 1) cp.x = nullptr;
                 else cp.res = nullptr;
             }
             // SRC8: + conv1 for 320 halo rows (res1a) / the tile's 256 pixels (res1b), two piece products of K = 80
-            ps.mfma(2.0 * tiles_m * kPlBM * (double)Cout * 9.0 * cin * 3 + (src8 ? 2.0 * tiles_m * (l == 1 ? 320 : 256) * 64.0 * 80.0 * 2 : 0.0), true);
+            const double tiles_x = sppf ? (double)((n + 3) / 4) : (double)tiles_m;  // pixel tiles the launch really runs
+            ps.mfma(2.0 * tiles_x * kPlBM * (double)Cout * 9.0 * cin * 3 + (src8 ? 2.0 * tiles_m * (l == 1 ? 320 : 256) * 64.0 * 80.0 * 2 : 0.0), true);
             // persistent: one workgroup per tile when they all fit (2 per CU), else wg_slots rounded down so that a
             // workgroup's tiles share their column tile (c3_conv3.h)
             int g = cp.tiles;
@@ -1021,14 +1029,15 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
                 if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<128, true>), grid, block, 0, s, cp);
                 else hipLaunchKernelGGL((conv3x3_planes_kernel<128, false>), grid, block, 0, s, cp);
             } else {
-                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<256, true>), grid, block, 0, s, cp);
+                if (sppf) hipLaunchKernelGGL((conv3x3_planes_kernel<256, true, 0, 0, true>), grid, block, 0, s, cp);
+                else if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<256, true>), grid, block, 0, s, cp);
                 else hipLaunchKernelGGL((conv3x3_planes_kernel<256, false>), grid, block, 0, s, cp);
             }
             HIP_TRY(hipGetLastError());
         }
         cin = Cout;
     }
-    {
+    if (!(m->spp_fused && !m->keep && hh[9] == 12 && ww[9] == 5 && 14 * 256 == m->K4)) {
         ProfScope ps(m, s, "fa.spp", 0.0, 4.0 * n * (hh[9] * ww[9] * 256.0 + m->K4));
         if (hh[9] == 12 && ww[9] == 5) {
             if (14 * 256 != m->K4) return fail("unsupported geometry: L4 expects %d inputs", m->K4);
@@ -1478,6 +1487,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_LSTM1_F16")) m->lstm1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_F16")) m->conv1_f16 = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_CONV1_FUSED")) m->conv1_fused = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_SPP_FUSED")) m->spp_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM_OPT")) m->lstm_opt = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM_TRACE")) m->lstm_trace_left = m->lstm2_trace_left = atoi(e);

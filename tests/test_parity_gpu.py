@@ -542,6 +542,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
     x_p = syn.make_pileup_windows(70, seed=24)
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
     fa_sets = [{"C3HIP_CONV1_FUSED": "0"},  # conv1 as its own launch, its planes read by res1a / res1b
+               {"C3HIP_SPP_FUSED": "0"},  # res3b writes its planes, pyramid pooling as its own launch
                {"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "4"},  # stride-2 convs on the round-2 / the role-split dense kernel
                {"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0"},
                {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0x48"},  # stride-2 convs of the plane path on the tiled GEMM
@@ -550,7 +551,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
                {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
                {"C3HIP_SPLIT_KIND": "1"}, {"C3HIP_WINOGRAD_F16MASK": "0"}, {"C3HIP_WINOGRAD_F16MASK": "0x24"}]
     for i, env in enumerate(fa_sets):
-        if i >= 6:
+        if i >= 7:
             env = dict(env, C3HIP_FA_PLANES="0")  # switches of the fp32-activation kernels
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -627,3 +628,19 @@ def test_conv1_inside_the_first_residual_block(monkeypatch, oracle_mod):
     monkeypatch.delenv("C3HIP_CONV1_FUSED")
     assert np.abs(y - y0).max() < 2e-6
     assert (y[:, :21].argmax(1) == y0[:, :21].argmax(1)).all() and (y[:, 21:24].argmax(1) == y0[:, 21:24].argmax(1)).all()
+
+
+def test_pyramid_pooling_inside_the_last_convolution(monkeypatch, oracle_mod):
+    """12 x 5 windows: res3b runs on window-aligned tiles (four whole windows each) and pools its own output (c3_conv3.h SPPF).  Batches
+    that are not a multiple of four windows, more tiles than workgroups (1100 windows: 1100 tiles on 256 workgroups), against the
+    oracle and against the separate pooling launch (which pools the two fp16 pieces instead of the fp32 value: ~1e-7 apart)"""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=91)
+    for n in (1, 3, 6, 1100):
+        x = syn.make_fa_windows(n, seed=92 + n)
+        y = make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)
+        sel = np.unique(np.r_[0:min(n, 8), max(0, n - 8):n])
+        util.assert_rows_match(y[sel], oracle_mod.fa_forward(sd, x[sel], True), what=f"pooling inside res3b, {n} windows")
+        monkeypatch.setenv("C3HIP_SPP_FUSED", "0")
+        y0 = make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)
+        monkeypatch.delenv("C3HIP_SPP_FUSED")
+        assert np.abs(y - y0).max() < 2e-6

@@ -22,7 +22,8 @@ def main(tag):
     f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch/c3_counter_collection.csv"))
     w = agg(os.path.join(ROOT, "gpurun_out/pmc_write/c3_counter_collection.csv"))
     conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("gemm_mfma_kernel<c3::PlaneConv" in k) or ("wino_conv_kernel" in k) or \
-        ("conv1_i8" in k) or ("conv3x3_planes_kernel" in k) or ("dense_planes_kernel<true>" in k)
+        ("conv1_i8" in k) or ("conv3x3_planes_kernel" in k) or ("dense_planes_kernel<true" in k) or \
+        ("dense_planes_pipe_kernel<true" in k) or ("dense_planes_ws_kernel<true" in k)
     tot_f = tot_w = n = 0
     per = {}
     all_f = all_w = 0.0
@@ -51,12 +52,13 @@ def main(tag):
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around "
                   "`bench.py --gpus 1 --steps 5 --warmup 2 --workload full_alignment` (B=256)",
         "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B",
-        "kernel_family": "the 9 convolution launches of one full-alignment step (direct implicit-GEMM + Winograd kernels)",
+        "kernel_family": "the convolution launches of one full-alignment step (8 with conv1 computed inside res1a / res1b, else 9)",
+        "launches_per_step": n / steps if steps else None,
         "launches": n,
         "hbm_bytes_per_launch": (2 * tot_f + tot_w) * 1024 / n,
         "fetch_bytes_per_launch_corrected": 2 * tot_f * 1024 / n,
         "write_bytes_per_launch": tot_w * 1024 / n,
-        "algorithmic_bytes_per_launch": sum(B * (a + b + c) for a, b, c in shapes) / 9,
+        "unfused_layer_bytes_per_step": sum(B * (a + b + c) for a, b, c in shapes),  # every layer reading its inputs and writing its output once
         "steps": steps,
         "hbm_bytes_per_step": (2 * all_f + all_w) * 1024 / steps if steps else None,
         "per_kernel": per,
