@@ -43,6 +43,11 @@ constexpr int kFusedKS = 5;  // k-steps of 4 covering C <= 20 input channels
 // the projection and the recurrent matrix instructions of EVERY step (hipcc keeps the conversion next to the loads): one
 // exposed L2 round trip per step on the critical path of a latency-bound kernel.
 // OPT bit 1: h leaves as planes, known at compile time (see `planes` below).
+// OPT bit 2: HALF tiles -- a workgroup takes 8 windows instead of 16, on rows {0,1, 4,5, 8,9, 12,13} of the 16-row matrix tile
+//            (a lane's accumulator elements 0 and 1; rows 2,3 mod 4 stay zero and are never evaluated).  The matrix phase of a
+//            step costs the same, but its cell phase -- vector-unit bound and as long as half the matrix phase -- halves, and a batch
+//            of 1024 windows becomes 256 workgroups instead of 128: the recurrences are latency-bound chains and half of the
+//            chip was idle.  The host picks it when the full tiles would leave CUs empty.
 // OPT bit 3: phase trace (debug).
 template <typename TX, bool F16 = false, int OPT = 0>
 __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p) {
@@ -56,7 +61,10 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane >> 4, col = lane & 15;
     const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * 16;
+    constexpr bool HALF = F16 && (OPT & 4);
+    const int b0 = blockIdx.x * (HALF ? 8 : 16);
+    // window of matrix row r: r itself, or (HALF) 2 (r >> 2) + (r & 1) for the rows with bit 1 clear
+    auto row_window = [&](int r) { return HALF ? ((r & 2) ? p.B : b0 + 2 * (r >> 2) + (r & 1)) : b0 + r; };
 
     for (int i = tid; i < 16 * LDH; i += NW * 64) (&hbuf[0][0][0])[i] = 0.f;
     if constexpr (F16)
@@ -81,7 +89,8 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
     // A operand of the projection: lane (window = lane&15, s) supplies x[window][t][4*ks + s].  Buffer loads: one
     // loop-invariant vector offset per k-step (out of range beyond C channels: the load returns the 0 the padding needs),
     // the time step is the scalar offset -- no per-step address arithmetic.
-    int xb = b0 + col;
+    int xb = row_window(col);
+    const bool xvalid = xb < p.B;  // (rows beyond the batch used to re-read the last window; their results were never stored)
     if (xb >= p.B) xb = p.B - 1;
     const int64_t xrow = p.starts ? (int64_t)p.starts[xb] * p.C : (int64_t)xb * p.T * p.C;
     // region mode: the host has checked starts[b] + T <= n_cols, the descriptor only has to end below the redirect offset
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 8 * s + 2 * j;  // channels k, k + 1 (C is even: 18)
-            xo2[j] = k < p.C ? (uint32_t)(xrow + k) : 0x80000000u;
+            xo2[j] = k < p.C && (xvalid || !HALF) ? (uint32_t)(xrow + k) : 0x80000000u;
         }
     }
     auto load_x16 = [&](int t, u32x4p &xa) __attribute__((always_inline)) {
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
                                                                             (uint32_t)((int64_t)p.B * p.T * 2 * H * 4), 0x00020000);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const int b = b0 + 4 * s + v;
+        const int b = row_window(4 * s + v);
         ho[v] = b < p.B ? (uint32_t)((((int64_t)b * p.T) * (2 * H) + h_col) * 4) : 0x80000000u;
     }
     // planes: the step's h tile (16 windows x H units, two pieces) already sits in LDS in plane order; one step later -- behind
@@ -180,8 +189,8 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
     // 8-unit group) -> 8 lanes per 128-byte plane row, instead of eight scattered 2-byte stores per thread and step
     static_assert(!F16 || H == 128, "the plane copy assumes 512 threads = 2 pieces x 16 windows x 16 groups of 8 units");
     const int cp_p = tid >> 8, cp_r = (tid >> 4) & 15, cp_c = tid & 15;
-    const uint32_t cp_off = planes && b0 + cp_r < p.B
-                                ? (uint32_t)(((int64_t)(b0 + cp_r) * p.T) * (2 * H) * 4 + (dir * 2 + (cp_c >> 3)) * 256 + cp_p * 128 + (cp_c & 7) * 16)
+    const uint32_t cp_off = planes && row_window(cp_r) < p.B
+                                ? (uint32_t)(((int64_t)row_window(cp_r) * p.T) * (2 * H) * 4 + (dir * 2 + (cp_c >> 3)) * 256 + cp_p * 128 + (cp_c & 7) * 16)
                                 : 0x80000000u;
     auto copy_planes = [&](int buf, int t) __attribute__((always_inline)) {
         typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         }
         stamp(step, 1);
 #pragma unroll
-        for (int v = 0; v < 4; v += 2) {  // two cells per packed instruction
+        for (int v = 0; v < (HALF ? 2 : 4); v += 2) {  // two cells per packed instruction
             f32x2g cc = {c[v], c[v + 1]};
             const f32x2g h = pk_lstm_cell(f32x2g{acc[0][v], acc[0][v + 1]}, f32x2g{acc[1][v], acc[1][v + 1]},
                                           f32x2g{acc[2][v], acc[2][v + 1]}, f32x2g{acc[3][v], acc[3][v + 1]}, cc);

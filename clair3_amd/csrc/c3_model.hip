@@ -155,7 +155,9 @@ struct c3_model {
     float *l1_wih16 = nullptr;                    // the same as two fp16 pieces of 128 W_ih for the F16 kernel (int8 windows)
     bool lstm1_fused = true;                // env C3HIP_LSTM1_FUSED=0 selects GEMM + recurrence
     int lstm_opt = 1;                       // env C3HIP_LSTM_OPT: bit 0 = LSTM1 (int8 windows, h1 as planes) widens the counts of step t + 1 at the
-                                            // top of step t + 1 and stores its plane piece unconditionally (c3_lstm_fused.h OPT 3)
+                                            // top of step t + 1 and stores its plane piece unconditionally (c3_lstm_fused.h OPT 3); bit 2 = half
+                                            // tiles (8 windows per workgroup) while full tiles leave CUs idle: LSTM1 57 -> 52 us and +2 % for ONE
+                                            // batch in flight, -5 % with three (twice the matrix work on a chip the others already fill): off
     int lstm_trace_left = 0, lstm2_trace_left = 0;  // debug, env C3HIP_LSTM_TRACE=n: the n-th LSTM launches record a phase trace
     unsigned long long *lstm_trace_dev = nullptr;
     // full alignment
@@ -1221,7 +1223,8 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
         {
             const bool f16 = m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16);
-            const double tiles = (double)((n + 15) / 16 * 16) * Tn * 2;  // (window, step, direction) rows of the 16-window tiles
+            const bool half = f16 && (m->lstm_opt & 4) && (m->lstm_opt & 1) && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 2;
+            const double tiles = (double)(half ? (n + 7) / 8 * 16 : (n + 15) / 16 * 16) * Tn * 2;  // (window, step, direction) rows of the 16-row tiles
             // recurrent part 512 x 128 as fp16x3 (or fp32); input part: int8 windows 512 x 32 against two weight pieces, else 512 x 20 fp32
             ps.mfma(f16 ? tiles * 2.0 * 512 * (128 * 3 + (sizeof(T) == 1 ? 32 * 2 : 0)) : tiles * 2.0 * 512 * (128 + 20), f16);
         }
@@ -1229,9 +1232,17 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         if (m->f16_ok && m->lstm1_f16 && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16)) {
             lp.whh = m->whh16[0];
             if (h1_planes) lp.hplanes = m->h1;  // h1 leaves as fp16 piece planes for dense_planes_kernel
-            const dim3 grid((unsigned)((n + 15) / 16), 2);
+            dim3 grid((unsigned)((n + 15) / 16), 2);
             bool launched = false;
+            // half tiles (8 windows per workgroup) while the full tiles would leave CUs idle: c3_lstm_fused.h OPT bit 2
+            const bool half1 = (m->lstm_opt & 4) && (m->lstm_opt & 1) && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 2 &&
+                               !(m->lstm_trace_left > 0);
             if constexpr (sizeof(T) == 1) {
+                if (half1) {
+                    grid = dim3((unsigned)((n + 7) / 8), 2);
+                    hipLaunchKernelGGL((lstm1_fused_kernel<T, true, 7>), grid, dim3(512), 0, s, lp);
+                    launched = true;
+                } else
                 if (m->lstm_trace_left > 0 && --m->lstm_trace_left == 0) {  // debug (C3HIP_LSTM_TRACE): this launch is traced
                     HIP_TRY(lstm_trace_begin(m));
                     lp.trace = m->lstm_trace_dev;

@@ -559,6 +559,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
         for k in env:
             monkeypatch.delenv(k)
     for env in [{"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "1"}, {"C3HIP_DENSE_MODE": "4"}, {"C3HIP_LSTM_OPT": "0"},
+                {"C3HIP_LSTM_OPT": "5"},  # LSTM1 on half tiles (8 windows per workgroup)
                 {"C3HIP_PROJ2_PLANES": "0"}, {"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
                 {"C3HIP_PROJ2_SPLIT": "0"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"},
                 {"C3HIP_LSTM1_F16": "0"}, {"C3HIP_LSTM2_F16": "0"},
