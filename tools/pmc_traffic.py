@@ -33,8 +33,8 @@ def main(tag):
             continue
         all_f += sum(f[k]["FETCH_SIZE"])
         all_w += sum(w[k]["WRITE_SIZE"]) if k in w else 0.0
-        if "spp" in k:
-            steps = len(f[k]["FETCH_SIZE"])  # one pyramid-pooling launch per forward pass
+        if "fc_tail_mfma_kernel<256>" in k or "fc_tail_kernel<256>" in k:
+            steps = len(f[k]["FETCH_SIZE"])  # one tail launch per forward pass
     for k in f:
         if not conv(k):
             continue
