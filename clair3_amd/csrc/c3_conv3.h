@@ -113,10 +113,13 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     constexpr int PIXB = 4 * C;    // bytes per pixel
     constexpr int NCH = 9 * NS;    // weight chunks per tile
     constexpr int kC1WBytes = 5 * 2 * 2 * 64 * 16;
-    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes + (SRC8 ? kC1WBytes + 256 : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes + 256 + (SRC8 ? kC1WBytes + 256 : 0)];
     char *const halo = smem;
     char *const bbuf = smem + kPlHaloBytes;
-    char *const c1w_lds = smem + kPlHaloBytes + 3 * kPlBBytes;
+    // this workgroup's 64 bias values (it keeps its column tile): read from LDS in the epilogue.  As global loads there they were
+    // waited for at once -- and with them, the counter being in-order, the halo rows and residual pieces requested just before
+    float *const bias_lds = reinterpret_cast<float *>(smem + kPlHaloBytes + 3 * kPlBBytes);
+    char *const c1w_lds = smem + kPlHaloBytes + 3 * kPlBBytes + 256;
     float *const c1b_lds = reinterpret_cast<float *>(c1w_lds + kC1WBytes);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     // for 1536 cycles of matrix work on the two waves of a SIMD.)
     pl_u32x4 hreg[SRC8 == 1 ? 1 : kPlHaloLoads];
     pl_u32x4 rb[3][NBP];
+    if (tid < 64) bias_lds[tid] = p.bias[tn * 64 + tid];  // visible behind the prologue's barrier
     if constexpr (SRC8) {
         for (int i = tid; i < kC1WBytes / 16; i += kPlThreads)
             *reinterpret_cast<pl_u32x4 *>(c1w_lds + i * 16) = *reinterpret_cast<const pl_u32x4 *>(reinterpret_cast<const char *>(p.c1w) + i * 16);
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + tn * 64 + cb0 + 8 * q);
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + cb0 + 8 * q);
                 f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);

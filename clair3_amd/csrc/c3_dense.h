@@ -330,11 +330,9 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
 // 8 no fragment reads, 16 no result stores, 32 no barriers.
 template <bool CONV = false, bool TR = false, int ABL = 0>
 __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DensePlanesParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + (CONV ? 0 : 8192)];
-    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);
-    if constexpr (!CONV) {
-        for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
-    }
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + 8192];
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);  // the whole bias vector (N <= 2048): no global load in an epilogue
+    for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
@@ -559,7 +557,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DenseP
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + ptn * kDnBN + cb0 + 8 * q);
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + ptn * kDnBN + cb0 + 8 * q);
                     f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
