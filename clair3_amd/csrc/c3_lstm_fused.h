@@ -198,8 +198,20 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         __builtin_amdgcn_raw_buffer_store_b128(d, prsrc, cp_off + (uint32_t)(t * 2 * H * 4), 0, 0);
     };
     float xn[kFusedKS];
+    // OPT bit 0 for the fp32 projection (int32 windows): the same deferral -- raw integers until the top of their step
+    constexpr bool DEFER32 = !F16P && (OPT & 1);
+    int xr32[kFusedKS];
+    auto load_raw32 = [&](int t) __attribute__((always_inline)) {
+        const int so = t * p.C * (int)sizeof(TX);
+#pragma unroll
+        for (int ks = 0; ks < kFusedKS; ++ks) {
+            if constexpr (sizeof(TX) == 1) xr32[ks] = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(xrsrc, xo[ks], so, 0);
+            else xr32[ks] = (int)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, xo[ks], so, 0);
+        }
+    };
     if constexpr (DEFER) load_raw(dir ? p.T - 1 : 0);
     else if constexpr (F16P) load_x16(dir ? p.T - 1 : 0, xn16);
+    else if constexpr (DEFER32) load_raw32(dir ? p.T - 1 : 0);
     else load_x(dir ? p.T - 1 : 0, xn);
     __syncthreads();
 
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
         const int cur = step & 1;
         float xa[kFusedKS];
 #pragma unroll
-        for (int ks = 0; ks < kFusedKS; ++ks) xa[ks] = xn[ks];
+        for (int ks = 0; ks < kFusedKS; ++ks) xa[ks] = DEFER32 ? (float)xr32[ks] : xn[ks];
         f32x4v acc[4];
         // gates = bias + x_t W_ih^T   (clair3/model.py:131-132: x.float() then LSTM1); the bias is the C operand of the
         // first MFMA (a resident 4-register vector per gate) instead of 16 register moves per step
@@ -232,7 +244,10 @@ __global__ __launch_bounds__(512) void lstm1_fused_kernel(LstmFusedParams<TX> p)
             for (int g = 0; g < 4; ++g)
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wih[g][ks], ks == 0 ? biasv[g] : acc[g], 0, 0, 0);
         // next step's counts: requested from inside the MFMA stream (a load costs ~60 cycles of issue outside it)
-        if (step + 1 < p.T) load_x(dir ? t - 1 : t + 1, xn);
+        if (step + 1 < p.T) {
+            if constexpr (DEFER32) load_raw32(dir ? t - 1 : t + 1);
+            else load_x(dir ? t - 1 : t + 1, xn);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (F16) {

@@ -1255,6 +1255,10 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
                     launched = true;
                 }
             }
+            if (!launched && sizeof(T) != 1 && (m->lstm_opt & 1) && h1_planes && !(m->lstm_trace_left > 0)) {
+                hipLaunchKernelGGL((lstm1_fused_kernel<T, true, 3>), grid, dim3(512), 0, s, lp);  // int32 windows: same deferral, fp32 projection
+                launched = true;
+            }
             if (!launched) hipLaunchKernelGGL((lstm1_fused_kernel<T, true>), grid, dim3(512), 0, s, lp);
         } else {
             hipLaunchKernelGGL(lstm1_fused_kernel<T>, dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
