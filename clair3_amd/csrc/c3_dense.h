@@ -13,6 +13,13 @@
 //  * the finished tile leaves through the LDS buffer its last chunk occupied: (row, 8-column) items, two 16-byte stores,
 //    16 lanes per 512-byte row segment (173 MB of fp32 per 1024 windows: the store shape matters, c3_conv3.h).
 // LDS rows are 272 B apart (conflict-free ds_read_b128 of 16 consecutive rows, immediate (piece, k-step) offsets).
+//
+// Three kernels share the tile shape, the operand layouts and the LDS stages:
+//   dense_planes_kernel       the first form, described above (whole chunk staged and re-requested at the top of a chunk); kept
+//                             for A/B (C3HIP_DENSE_MODE=0 staged / 1 direct fp32 epilogue) and for its phase trace;
+//   dense_planes_pipe_kernel  the product (mode 3): the chunk stream spread piecewise over the matrix stream, waits sized by hand;
+//   dense_planes_ws_kernel    8 multiplying + 4 moving waves (mode 4): faster alone, slower for the step.
+// tools/dense_probe.hip times all three on the projection shape with parts switched off (the ABL template bits).
 #pragma once
 #include "c3_conv3.h"
 
