@@ -886,4 +886,184 @@ __global__ __launch_bounds__(kWsThreads) void dense_planes_ws_kernel(DensePlanes
         if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// dense_planes_big_kernel -- C[M][N] = A W^T + b on 256 x 256 tiles, for the LSTM2 projection (CONV = false only).
+//
+// The ablations of the 128 x 128 kernels (tools/dense_probe.hip) say their parts add up and two of the three
+// parts are traffic: 64 KB from L2 and through the LDS write path plus 192 KB of fragment reads per 1536 cycles of matrix work.
+// A 256 x 256 tile halves all of it per matrix instruction: a wave owns 128 x 64 outputs = 4 x 2 blocks of 32 x 32, so a k-step
+// reads 8 + 4 fragments for 24 matrix instructions (0.5 per instruction instead of 1.0), and a chunk stages 512 operand rows
+// for 2 x the products.  To fit two LDS stages the chunk is 32 channels (rows of 64 B hi | 64 B lo, 144 B apart: 16 consecutive
+// rows still cover all banks once): 73.7 KB per stage.  Otherwise dense_planes_pipe_kernel: pieces staged and re-requested one
+// at a time inside the matrix stream (one per 32 x 32 row block = per six matrix instructions), unconditional requests, results
+// stored at the top of the next tile, a tile's first chunk as its own copy of the code.  660 tiles for 1024 windows on 256
+// workgroups: three rounds, 86 % full.
+constexpr int kBgBM = 256, kBgBN = 256, kBgKC = 32, kBgRowB = 144;
+constexpr int kBgABytes = kBgBM * kBgRowB, kBgStage = (kBgBM + kBgBN) * kBgRowB;  // 73 728 B per stage
+
+struct DenseBigParams {
+    const void *a;      // plane activations [M][K/64][hi 64 | lo 64] fp16
+    const void *w;      // [N/256][K/32][256 rows][8 pieces of 16 B]: pieces 0-3 = hi of k 8g..8g+7 of the 32-channel chunk, 4-7 = lo; times 2^s
+    const float *bias;  // [N]
+    float *c;           // [M][N] fp32
+    float post_scale;   // 2^-s
+    int M, N, K;
+    int tiles_n, tiles;  // N / 256, ceil(M / 256) * tiles_n
+};
+
+__global__ __launch_bounds__(kDnThreads, 2) void dense_planes_big_kernel(DenseBigParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kBgStage + 8192];
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kBgStage);
+    for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 128 x 64 outputs each
+    const int frow = lane & 31, kh = lane >> 5;
+    const int NK = p.K / kBgKC;
+    const int G = gridDim.x;
+    const int rowb = (p.K / 64) * 256;  // bytes per row of A
+
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.a), 0, (uint32_t)((int64_t)p.M * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, (uint32_t)((int64_t)p.N * p.K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
+    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
+        const int tile = xcd_tile_index(v, p.tiles);
+        const int tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+        m0 = tm * kBgBM;
+    };
+    // piece j (0..3) of each operand: row (tid >> 3) + 64 j, 16-byte group g = tid & 7 (0-3 hi, 4-7 lo) of the 32-channel chunk
+    pl_u32x4 ra[4], rb[4];
+    const int pg = tid & 7;
+    const uint32_t a_in_row = pg < 4 ? (uint32_t)(pg * 16) : (uint32_t)(128 + (pg - 4) * 16);  // + slab * 256 + half * 64
+    auto issue1 = [&](int j, int m0, int tn, int kc, bool on) __attribute__((always_inline)) {
+        const int row = (tid >> 3) + 64 * j;
+        const int m = m0 + row;
+        const uint32_t off = on && m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)((kc >> 1) * 256 + (kc & 1) * 64) + a_in_row : kPlOob;
+        const uint32_t woff = on ? (uint32_t)(((tn * NK + kc) * kBgBN + row) * 128 + pg * 16) : kPlOob;
+        ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
+        rb[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
+    };
+    const int st_off = (tid >> 3) * kBgRowB + pg * 16;  // 64 rows further per j
+    auto stage1 = [&](int j, int buf, bool b_operand) __attribute__((always_inline)) {
+        char *dst = smem + buf * kBgStage + st_off + j * 64 * kBgRowB + (b_operand ? kBgABytes : 0);
+        *reinterpret_cast<pl_u32x4 *>(dst) = b_operand ? rb[j] : ra[j];
+    };
+    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+    };
+    // fragment of k-step ks: hi piece 2 ks + kh at byte (2 ks + kh) * 16 of the row, lo piece 64 bytes further
+    const int a_rd = (wm * 128 + frow) * kBgRowB + kh * 16;              // + i * 32 rows
+    const int b_rd = kBgABytes + (wn * 64 + frow) * kBgRowB + kh * 16;   // + j * 32 rows
+
+    int v = blockIdx.x;
+    if (v >= p.tiles) return;
+    int m0, tn;
+    tile_mn(v, m0, tn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue1(j, m0, tn, 0, true);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage1(j, 0, false), stage1(j, 0, true);
+    int vq = v, m0q = m0, tnq = tn, kq = 1;  // (tile, chunk) of the chunk held in registers
+    if (kq == NK) {
+        kq = 0, vq = v + G;
+        if (vq < p.tiles) tile_mn(vq, m0q, tnq);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue1(j, m0q, tnq, kq, vq < p.tiles);
+    lds_barrier();
+
+    int g = 0;  // chunks done: the current chunk sits in LDS stage g & 1
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto chunk = [&](auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const char *cur = smem + (g & 1) * kBgStage;
+        bool req = false;
+        if (vq < p.tiles) {
+            if (++kq == NK) {
+                kq = 0, vq += G;
+                if (vq < p.tiles) tile_mn(vq, m0q, tnq);
+            }
+            req = vq < p.tiles;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            pl_u32x4 wh[2], wl[2], xh[2], xl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wh[j] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + j * 32 * kBgRowB + ks * 32);
+                wl[j] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + j * 32 * kBgRowB + 64 + ks * 32);
+            }
+            xh[0] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + ks * 32);
+            xl[0] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + 64 + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int st = i & 1;
+                if (i < 3) {
+                    xh[st ^ 1] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + (i + 1) * 32 * kBgRowB + ks * 32);
+                    xl[st ^ 1] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + (i + 1) * 32 * kBgRowB + 64 + ks * 32);
+                }
+                // slot (ks, i) of the chunk: one operand piece goes to the other stage and is requested again
+                {
+                    const int slot = ks * 4 + i, j = slot >> 1;
+                    if (slot & 1) stage1(j, (g + 1) & 1, true);
+                    else stage1(j, (g + 1) & 1, false);
+                    if (slot & 1) issue1(j, m0q, tnq, kq, req);  // both registers of piece j are free now
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c0 = acc[i][j];
+                    if (FIRST && ks == 0) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) c0[e] = 0.f;
+                    }
+                    c0 = mma(c0, wh[j], xl[st]);
+                    c0 = mma(c0, wl[j], xh[st]);
+                    acc[i][j] = mma(c0, wh[j], xh[st]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();
+        ++g;
+    };
+    auto epilogue = [&](int pm0, int ptn, bool valid) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = pm0 + wm * 128 + i * 32 + frow;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n0 = ptn * kBgBN + wn * 64 + j * 32 + 4 * kh;
+                const uint32_t rowoff = valid && m < p.M ? (uint32_t)(((int64_t)m * p.N + n0) * 4) : kPlOob;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + n0 + 8 * q);
+                    f32x4 val = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+                }
+            }
+        }
+    };
+    int pm0 = 0, ptn = 0;
+    bool have_prev = false;
+    for (;;) {
+        epilogue(pm0, ptn, have_prev);
+        if (v >= p.tiles) break;
+        chunk(std::true_type{});  // the copy behind the stores
+        for (int kc = 1; kc < NK; ++kc) chunk(std::false_type{});
+        pm0 = m0, ptn = tn, have_prev = true;
+        v += G;
+        if (v < p.tiles) tile_mn(v, m0, tn);
+    }
+}
+
 }  // namespace c3

@@ -584,7 +584,7 @@ def test_dense_kernel_forms_are_bit_identical(monkeypatch, oracle_mod):
     y_f = make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f)
     util.assert_rows_match(y_p[:40], oracle_mod.pileup_forward(sd_p, x_p[:40], False), what="pileup, default dense kernel")
     util.assert_rows_match(y_f[-24:], oracle_mod.fa_forward(sd_f, x_f[-24:], True), what="full alignment, default dense kernel")
-    for mode in ("0", "1", "4"):
+    for mode in ("0", "1", "4", "5"):
         monkeypatch.setenv("C3HIP_DENSE_MODE", mode)
         assert np.array_equal(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p), f"pileup rows differ with C3HIP_DENSE_MODE={mode}"
         assert np.array_equal(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f), f"full-alignment rows differ with C3HIP_DENSE_MODE={mode}"

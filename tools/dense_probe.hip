@@ -81,6 +81,13 @@ int main(int argc, char **argv) {
     RUNW(28, "  move only");
     RUNW(19, "  multiply only (fragment reads + matrix instructions)");
     RUNW(27, "  matrix instructions + barriers only");
+    {   // 256 x 256 tiles (weights in 32-channel chunks: any bytes do for timing)
+        DenseBigParams bp;
+        bp.a = da, bp.w = dw, bp.bias = dbias, bp.c = dc, bp.post_scale = 1.f / 256.f;
+        bp.M = M, bp.N = N, bp.K = K, bp.tiles_n = N / kBgBN, bp.tiles = ((M + kBgBM - 1) / kBgBM) * bp.tiles_n;
+        const int gb = bp.tiles < 256 ? bp.tiles : 256;
+        report("256 x 256 tile kernel", time_us([&] { hipLaunchKernelGGL(dense_planes_big_kernel, dim3(gb), dim3(kDnThreads), 0, 0, bp); }, 20));
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }
