@@ -4,6 +4,8 @@
   * size-independent properties at the full BASELINE.json sizes.
 Gate (BASELINE.json north_star): probabilities within 1e-4 (fp32), genotype/zygosity labels identical.
 """
+import time
+
 import numpy as np
 import pytest
 
@@ -645,3 +647,24 @@ def test_pyramid_pooling_inside_the_last_convolution(monkeypatch, oracle_mod):
         y0 = make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)
         monkeypatch.delenv("C3HIP_SPP_FUSED")
         assert np.abs(y - y0).max() < 2e-6
+
+
+def test_kernel_choice_beside_other_handles_gives_the_same_rows(oracle_mod):
+    """a pileup handle picks its LSTM1 tile size and its projection kernel by whether other handles of the process are feeding the
+    GPU (others_active()): rows computed beside a busy second handle (full LSTM1 tiles, 256 x 256 projection tiles)
+    equal the rows of the same windows computed alone (half tiles, 128 x 128) bit for bit"""
+    sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=101)
+    x = syn.make_pileup_windows(1024 + 5, seed=102)
+    m1 = make_model(syn.PILEUP, 18, False, sd)
+    m2 = make_model(syn.PILEUP, 18, False, sd)
+    time.sleep(0.01)
+    y_alone = m1.predict_numpy(x)
+    util.assert_rows_match(y_alone[:32], oracle_mod.pileup_forward(sd, x[:32], False), what="pileup, alone on the chip")
+    ys = []
+    for i in range(6):  # the two handles alternate without a pause: each sees the other's forward pass a few 100 us old
+        t2 = m2.submit(x, slot=i % 2)
+        t1 = m1.submit(x, slot=i % 2)
+        ys.append(m1.wait(t1))
+        m2.wait(t2)
+    for y in ys[1:]:
+        assert np.array_equal(y, y_alone)
