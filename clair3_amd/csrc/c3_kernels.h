@@ -221,6 +221,14 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
     constexpr int NP = 16 * H / 512;  // (window, unit) pairs per thread in the cell phase
     constexpr int WCOLS = NB * 16;    // gate columns owned by one wave
     static_assert(NP * 32 == H, "cell phase: thread (row = tid >> 5) covers units (tid & 31) + 32 r");
+    // OPT bit 2: HALF tiles -- 8 windows per workgroup on rows {0,1,4,5,8,9,12,13} of the 16-row matrix tile (elements v = 0, 1 of
+    // every lane's accumulators), the other rows stay zero.  The matrix phase is unchanged, the gate exchange and the x loads are
+    // half as long and the cell phase is a packed pair + one single (lanes 0-31) per thread instead of two pairs + a single: for
+    // batches whose full tiles leave half the CUs without a workgroup (1024 windows = 128 of them).
+    constexpr bool HALF = F16 && (OPT & 4) != 0;
+    constexpr int NW = HALF ? 8 : 16;   // windows per workgroup
+    constexpr int NV = HALF ? 2 : 4;    // accumulator elements (= windows) per lane in use
+    static_assert(!HALF || H == 160, "half tiles: 8 windows x 160 units over 512 threads as unit, unit + 64, unit + 128 (lanes 0-31)");
     // ONE LDS object, carved up by hand
     constexpr int OFF_H = 0;                                 // float hbuf[2][16][LDH]
     constexpr int LDH16 = 2 * H + 16;                        // F16: bytes per row of an fp16 h plane (see hb16)
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane >> 4, col = lane & 15;
     const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * 16;
+    const int b0 = blockIdx.x * NW;
 
     for (int i = tid; i < (F16 ? H_BYTES / 4 : 16 * LDH); i += 512) reinterpret_cast<float *>(smem + OFF_H)[i] = 0.f;
 
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
     uint32_t xo[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        int b = b0 + 4 * s + v;
+        int b = b0 + (HALF ? 2 : 4) * s + v;
         if (b >= p.B) b = p.B - 1;
         xo[v] = (uint32_t)(((int64_t)b * p.T * p.ld_gx + col) * 4);
     }
@@ -284,14 +292,20 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int v = 0; v < NV; ++v)
                 xn[b][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xo[v], so + b * 64, 0));
     };
+    if constexpr (HALF) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xn[b] = f32x4v{0.f, 0.f, 0.f, 0.f};  // elements 2, 3: rows without a window
+    }
 
     // cell phase: thread (row = tid >> 5, units (tid & 31) + 32 r): every LDS / output address is one base + immediates
-    const int crow = tid >> 5, cu0 = tid & 31;
+    // (HALF: window slot j = tid >> 6 on tile row 4 (j >> 1) + (j & 1), units (tid & 63), + 64 and, lanes 0-31, + 128)
+    const int cwin = HALF ? tid >> 6 : tid >> 5;
+    const int crow = HALF ? 4 * (cwin >> 1) + (cwin & 1) : cwin, cu0 = HALF ? tid & 63 : tid & 31;
     float *gbase = gb(crow, cu0);
-    uint32_t hobase = b0 + crow < p.B ? (uint32_t)((((int64_t)(b0 + crow) * p.T) * 2 * H + dir * H + cu0) * 4) : 0x80000000u;
+    uint32_t hobase = b0 + cwin < p.B ? (uint32_t)((((int64_t)(b0 + cwin) * p.T) * 2 * H + dir * H + cu0) * 4) : 0x80000000u;
     float *gwr = gb(4 * s, (wave * NB) * 16 + col);  // + v * LDG + b * 16
 
     float c[NP];
@@ -388,11 +402,36 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) gwr[v * LDG + b * 16] = acc[b][v];
+            for (int v = 0; v < NV; ++v) gwr[v * LDG + b * 16] = acc[b][v];
         __syncthreads();
         stamp(step, 2);
         // cell: c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')   (rows i, f, g, o)
         const uint32_t ho = hobase + (uint32_t)(t * 2 * H * 4);
+        if constexpr (HALF) {
+            {
+                const float *g0 = gbase, *g1 = g0 + 64;
+                f32x2g cc = {c[0], c[1]};
+                const f32x2g h = pk_lstm_cell(f32x2g{g0[0], g1[0]}, f32x2g{g0[H], g1[H]}, f32x2g{g0[2 * H], g1[2 * H]},
+                                              f32x2g{g0[3 * H], g1[3 * H]}, cc);
+                c[0] = cc[0], c[1] = cc[1];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    put_h(cur ^ 1, crow, cu0 + 64 * e, h[e]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[e]), hrsrc, ho + 256 * e, 0, 0);
+                }
+            }
+            if (cu0 < 32) {
+                const float *g = gbase + 128;
+                const float ig = fast_sigmoid(g[0]);
+                const float fg = fast_sigmoid(g[H]);
+                const float gg = fast_tanh(g[2 * H]);
+                const float og = fast_sigmoid(g[3 * H]);
+                c[2] = __builtin_fmaf(fg, c[2], ig * gg);  // the pair form's order, spelled out: left to contraction the two tile shapes compiled differently
+                const float h = og * fast_tanh(c[2]);
+                put_h(cur ^ 1, crow, cu0 + 128, h);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrsrc, ho + 512, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r + 1 < NP; r += 2) {  // units cu0 + 32 r and cu0 + 32 (r + 1) as one packed pair
             const float *g0 = gbase + 32 * r, *g1 = g0 + 32;
@@ -413,10 +452,11 @@ __global__ __launch_bounds__(512, 2) void lstm_recurrent_kernel_v2(Lstm2Params p
             const float fg = fast_sigmoid(g[H]);
             const float gg = fast_tanh(g[2 * H]);
             const float og = fast_sigmoid(g[3 * H]);
-            c[r] = fg * c[r] + ig * gg;
+            c[r] = __builtin_fmaf(fg, c[r], ig * gg);
             const float h = og * fast_tanh(c[r]);
             put_h(cur ^ 1, crow, cu0 + 32 * r, h);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), hrsrc, ho + 128 * r, 0, 0);
+        }
         }
         stamp(step, 3);
         lds_barrier();

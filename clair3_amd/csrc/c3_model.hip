@@ -160,6 +160,7 @@ struct c3_model {
                                             // tiles (8 windows per workgroup) while full tiles leave CUs idle: LSTM1 57 -> 52 us and +2 % for ONE
                                             // batch in flight, -5 % with three (twice the matrix work on a chip the others already fill): off
     bool concurrent = false;                // another handle of the process queued a forward pass in the last 2 ms (others_active)
+    int lstm2_half = 1;                     // env C3HIP_LSTM2_HALF=0: LSTM2 never takes half tiles (C3HIP_LSTM_OPT bit 4 pins them on)
     int adaptive = 1;                       // env C3HIP_ADAPTIVE=0: the kernel choices that depend on `concurrent` follow C3HIP_LSTM_OPT / C3HIP_DENSE_MODE alone
     int lstm_trace_left = 0, lstm2_trace_left = 0;  // debug, env C3HIP_LSTM_TRACE=n: the n-th LSTM launches record a phase trace
     unsigned long long *lstm_trace_dev = nullptr;
@@ -1375,9 +1376,14 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     }
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
+        // half tiles (8 windows per workgroup, c3_kernels.h OPT bit 2) while the full tiles would leave CUs without a workgroup and
+        // no other handle is there to use them
+        const bool half2 = m->lstm2_v2 && m->f16_ok && m->lstm2_f16 && m->whh16[1] && m->lstm2_half &&
+                           (m->adaptive ? !m->concurrent : (m->lstm_opt & 16) != 0) && 2 * ((n + 15) / 16) <= m->wg_slots / 4 &&
+                           !(m->lstm2_trace_left > 0);
         {
             const bool f16 = m->lstm2_v2 && m->f16_ok && m->lstm2_f16 && m->whh16[1];
-            ps.mfma((double)((n + 15) / 16 * 16) * Tn * 2 * 2.0 * 640 * 160 * (f16 ? 3 : 1), f16);
+            ps.mfma((double)(half2 ? (n + 7) / 8 * 16 : (n + 15) / 16 * 16) * Tn * 2 * 2.0 * 640 * 160 * (f16 ? 3 : 1), f16);
         }
         if (m->lstm2_v2) {
             Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
@@ -1388,6 +1394,8 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
                     lp.trace = m->lstm_trace_dev;
                     hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true, 8>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
                     HIP_TRY(lstm_trace_print(m, s, "lstm2", Tn, "top -> matrix instructions issued -> gates exchanged -> cell + h written -> barrier -> next top"));
+                } else if (half2) {
+                    hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true, 4>), dim3((unsigned)((n + 7) / 8), 2), dim3(512), 0, s, lp);
                 } else {
                     hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
                 }
@@ -1564,6 +1572,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_SPP_FUSED")) m->spp_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM1_FUSED")) m->lstm1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LSTM_OPT")) m->lstm_opt = atoi(e), m->adaptive = 0;
+    if (const char *e = getenv("C3HIP_LSTM2_HALF")) m->lstm2_half = atoi(e);
     if (getenv("C3HIP_DENSE_MODE")) m->adaptive = 0;
     if (const char *e = getenv("C3HIP_ADAPTIVE")) m->adaptive = atoi(e);
     if (const char *e = getenv("C3HIP_LSTM_TRACE")) m->lstm_trace_left = m->lstm2_trace_left = atoi(e);

@@ -562,6 +562,7 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
             monkeypatch.delenv(k)
     for env in [{"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "1"}, {"C3HIP_DENSE_MODE": "4"}, {"C3HIP_LSTM_OPT": "0"},
                 {"C3HIP_LSTM_OPT": "5"},  # LSTM1 on half tiles (8 windows per workgroup)
+                {"C3HIP_LSTM_OPT": "21"}, {"C3HIP_LSTM2_HALF": "0"},  # both recurrences on half tiles; LSTM2 never
                 {"C3HIP_PROJ2_PLANES": "0"}, {"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
                 {"C3HIP_PROJ2_SPLIT": "0"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"},
                 {"C3HIP_LSTM1_F16": "0"}, {"C3HIP_LSTM2_F16": "0"},
@@ -591,6 +592,22 @@ def test_dense_kernel_forms_are_bit_identical(monkeypatch, oracle_mod):
         assert np.array_equal(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p), f"pileup rows differ with C3HIP_DENSE_MODE={mode}"
         assert np.array_equal(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f), f"full-alignment rows differ with C3HIP_DENSE_MODE={mode}"
         monkeypatch.delenv("C3HIP_DENSE_MODE")
+
+
+def test_lstm_tile_shapes_are_bit_identical(monkeypatch, oracle_mod):
+    """both recurrences run 16 windows per workgroup or, while that leaves CUs without a workgroup, 8 (on rows {0,1,4,5,...} of the
+    matrix tile; c3_lstm_fused.h / c3_kernels.h OPT bit 2): same matrix instructions per window, same cell arithmetic per unit --
+    the rows must be EQUAL whichever shapes are pinned, ragged last tile included"""
+    sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=111)
+    x = syn.make_pileup_windows(200 + 3, seed=112)
+    monkeypatch.setenv("C3HIP_LSTM_OPT", "1")  # full tiles for both
+    y = make_model(syn.PILEUP, 18, False, sd).predict_numpy(x)
+    util.assert_rows_match(y[:32], oracle_mod.pileup_forward(sd, x[:32], False), what="pileup, full tiles")
+    for opt in ("5", "17", "21"):  # LSTM1 half, LSTM2 half, both
+        monkeypatch.setenv("C3HIP_LSTM_OPT", opt)
+        assert np.array_equal(make_model(syn.PILEUP, 18, False, sd).predict_numpy(x), y), f"rows differ with C3HIP_LSTM_OPT={opt}"
+    monkeypatch.delenv("C3HIP_LSTM_OPT")
+    assert np.array_equal(make_model(syn.PILEUP, 18, False, sd).predict_numpy(x), y), "rows differ with the run-time choice"
 
 
 def test_blocking_call_cut_into_chunks_gives_the_same_rows(oracle_mod):
