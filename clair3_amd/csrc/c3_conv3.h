@@ -105,14 +105,23 @@ __device__ __forceinline__ f32x4 load_planes4(const __amdgpu_buffer_rsrc_t rsrc,
 // workgroups use today; 256 windows = 64 x 4 tiles = one per CU) -- so every bin of a window lies inside one tile: the ReLU'd
 // fp32 tile goes back into LDS, thread (window, channel, level) takes the maxima of its bins over 60 LDS values and stores
 // them.  No plane output (its only reader was the pooling kernel), no pooling launch, no atomics.
-template <int C, bool RES, int ABL = 0, int SRC8 = 0, bool SPPF = false>
+// C1 (with SRC8): channels of the windows, 8 or 9 (--enable_dwell_time adds the dwell channel).  Nine-byte pixels have no aligned
+// 8-byte pieces, so the 9-channel form takes conv1's K as the three ROWS of the 3 x 3 patch: the three pixels of a row are 27
+// consecutive bytes of the window tensor, padded to 32 = two k-steps (weights of the pad bytes are zero), fetched as four
+// unaligned 8-byte pieces per row (gfx950 serves those at any byte offset -- tools/unaligned_probe.hip -- but zeroes every dword
+// that straddles the end of the buffer, and bytes in front of the tensor must not be touched at all: at the left / right edge
+// of the window the piece that mixes an outside pixel with inside ones is fetched one byte later / six bytes earlier and
+// shifted, which also clears the outside bytes).  6 k-steps instead of 5, otherwise the 8-channel scheme.
+template <int C, bool RES, int ABL = 0, int SRC8 = 0, bool SPPF = false, int C1 = 8>
 __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConvParams p) {
+    static_assert(C1 == 8 || C1 == 9, "conv1 inside this kernel: 8- or 9-channel windows");
+    constexpr int NT1 = C1 == 8 ? 5 : 6;  // conv1 k-steps of 16
     static_assert(SRC8 == 0 || C == 64, "conv1 feeds the 64-channel block only");
     static_assert(SRC8 != 2 || RES, "SRC8 = 2 replaces the residual read");
     constexpr int NS = C / 64;     // input slabs = output column tiles
     constexpr int PIXB = 4 * C;    // bytes per pixel
     constexpr int NCH = 9 * NS;    // weight chunks per tile
-    constexpr int kC1WBytes = 5 * 2 * 2 * 64 * 16;
+    constexpr int kC1WBytes = NT1 * 2 * 2 * 64 * 16;
     __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes + 256 + (SRC8 ? kC1WBytes + 256 : 0)];
     char *const halo = smem;
     char *const bbuf = smem + kPlHaloBytes;
@@ -147,9 +156,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 
     auto halo_issue = [&](pl_u32x4 (&h)[kPlHaloLoads], int mbase, int slab) __attribute__((always_inline)) {
         const int m_lo = mbase - W - 1;
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));  // the ten row numbers are recomputed here, not carried (and spilled: reloads that wait for the loads just issued) across the tile loop
 #pragma unroll
         for (int j = 0; j < kPlHaloLoads; ++j) {
-            const int idx = tid + kPlThreads * j;
+            const int idx = tid_ + kPlThreads * j;
             const int row = idx >> 4, pos = idx & 15;
             const int pix = m_lo + row;
             const bool ok = row < T && (unsigned)pix < (unsigned)p.M;
@@ -190,11 +201,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     // 2 t / 2 t + 1 in the two lane halves, 8 channels each (c3_conv1.h: the int8 bytes b become exact fp16 values b / 128 with
     // one v_perm_b32 + one v_pk_add_f16 per pair; the weights are two fp16 pieces of 1.28 W').
     typedef uint32_t c1u2 __attribute__((ext_vector_type(2)));
-    const int c1_rowB = p.Win * 8;
+    const int c1_rowB = p.Win * C1;
     const __amdgpu_buffer_rsrc_t x8rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.x8)) - (SRC8 ? c1_rowB + 8 : 0), 0,
-        SRC8 ? (uint32_t)((int64_t)(p.M / (p.H * p.W)) * p.Hin * c1_rowB + c1_rowB + 8) : 0u, 0x00020000);
-    auto c1_request = [&](int pix, c1u2 (&d)[5]) __attribute__((always_inline)) {
+        const_cast<char *>(reinterpret_cast<const char *>(p.x8)) - (SRC8 ? c1_rowB + C1 : 0), 0,
+        SRC8 ? (uint32_t)((int64_t)(p.M / (p.H * p.W)) * p.Hin * c1_rowB + c1_rowB + C1) : 0u, 0x00020000);
+    auto c1_request = [&](int pix, c1u2 (&d)[NT1]) __attribute__((always_inline)) {
         // the per-lane tap geometry is recomputed here every time: left to itself hipcc keeps it (15 registers) alive across the
         // whole tile loop, and the 248-register main loop then spills the halo registers
         int kh_ = kh;
@@ -202,7 +213,35 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         const bool valid = (unsigned)pix < (unsigned)p.M;
         const int b = pix / HW, r = pix - b * HW;
         const int oy = r / W, ox = r - oy * W;
-        const uint32_t base = (uint32_t)(((b * p.Hin + 2 * oy) * p.Win + 2 * ox) * 8);
+        const uint32_t base = (uint32_t)(((b * p.Hin + 2 * oy) * p.Win + 2 * ox) * C1);
+        if constexpr (C1 == 9) {
+            // k-step t = (row ky = t >> 1, half u = t & 1): lane half kh_ takes bytes 16 u + 8 kh_ .. + 7 of the row's 27 (+ 5)
+            const bool left_out = ox == 0, right_out = 2 * ox + 1 >= p.Win;  // pixel 0 / pixel 2 of the row lies outside the window
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int ky = t >> 1, u = t & 1;
+                const int iy = 2 * oy - 1 + ky;
+                bool ok = valid && (unsigned)iy < (unsigned)p.Hin;
+                uint32_t off = base + (uint32_t)(ky * c1_rowB + 16 * u) + (uint32_t)(8 * kh_);
+                int shl = 0, shr = 0;
+                if (u == 0) {  // bytes 0-7: pixel 0; bytes 8-15: last channel of pixel 0, then pixel 1
+                    if (left_out) {
+                        if (kh_) off += 1, shl = 8;
+                        else ok = false;
+                    }
+                } else if (kh_) {  // bytes 24-26: pixel 2, then pad: fetched as bytes 19-26 (the piece ends with the row's last byte)
+                    if (right_out) ok = false;
+                    else off -= 5, shr = 40;
+                } else {           // bytes 16-23: two channels of pixel 1, then pixel 2
+                    if (right_out) off -= 6, shr = 48;
+                }
+                const c1u2 raw = __builtin_bit_cast(c1u2, __builtin_amdgcn_raw_buffer_load_b64(x8rsrc, ok ? off : 0x80000000u, 0, 0));
+                uint64_t v = (uint64_t)raw[0] | ((uint64_t)raw[1] << 32);
+                v = (v << shl) >> shr;
+                d[t] = c1u2{(uint32_t)v, (uint32_t)(v >> 32)};
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
             const int tap = 2 * t + kh_;
@@ -227,12 +266,12 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         return o;
     };
     // conv1 of one 32-pixel group for column block cb (32 output channels): acc = sum over 5 k-steps, two weight pieces each
-    auto c1_block = [&](const c1u2 (&d)[5], int cb) __attribute__((always_inline)) {
+    auto c1_block = [&](const c1u2 (&d)[NT1], int cb) __attribute__((always_inline)) {
         f32x16 c;
 #pragma unroll
         for (int e = 0; e < 16; ++e) c[e] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
+        for (int t = 0; t < NT1; ++t) {
             const pl_u32x4 a = c1_widen(d[t]);
             const pl_u32x4 w1 = *reinterpret_cast<const pl_u32x4 *>(c1w_lds + (((t * 2 + cb) * 2 + 1) * 64 + lane) * 16);
             const pl_u32x4 w0 = *reinterpret_cast<const pl_u32x4 *>(c1w_lds + (((t * 2 + cb) * 2 + 0) * 64 + lane) * 16);
@@ -243,7 +282,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     };
     float omax = 0.f;
     // SRC8 = 1: halo rows 32 g .. 32 g + 31 (pixel m_lo + row) for g = wave and wave + 8
-    c1u2 c1d[2][5];
+    c1u2 c1d[2][NT1];
     auto c1_halo_request = [&](int mbase) __attribute__((always_inline)) {
         const int m_lo = mbase - W - 1;
 #pragma unroll

@@ -775,6 +775,30 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
             if (mx < 16384.f) TRY(upload(m, &m->conv1_wfrag16, pf16));
         }
     }
+    if (l == 0 && Cin == 9 && m->conv1_f16) {
+        // conv1 inside conv3x3_planes_kernel<.., C1 = 9> (c3_conv3.h): k-step t = (patch row ky = t >> 1, half u = t & 1); lane
+        // (n = lane & 31, kh = lane >> 5) holds the weights of bytes q = 16 u + 8 kh + j of the row's three 9-byte pixels
+        // (pixel q / 9, channel q % 9; q >= 27: padding, zero), times 1.28 (the kernel feeds x / 128), as two fp16 pieces
+        std::vector<float> pf16((size_t)6 * 2 * 2 * 64 * 4, 0.f);
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(pf16.data());
+        float mx = 0.f;
+        for (int t = 0; t < 6; ++t)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * cb + (lane & 31), q = 16 * (t & 1) + 8 * (lane >> 5) + j, ky = t >> 1;
+                        float v = 0.f;
+                        if (q < 27) {
+                            const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+                            v = (float)((double)w[(((size_t)co * Cin + q % 9) * 3 + ky) * 3 + q / 9] * scale * (128.0 / 100.0));
+                        }
+                        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                        memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 0) * 64 + lane) * 8 + j], &h0, 2);
+                        memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 1) * 64 + lane) * 8 + j], &h1, 2);
+                        mx = std::max(mx, std::fabs(v));
+                    }
+        if (mx < 16384.f) TRY(upload(m, &m->conv1_wfrag16, pf16));  // else: conv1 stays on the tiled GEMM
+    }
     if (kConvStride[l] == 1 && Cin == Cout && Cin % 64 == 0 && m->fa_planes && m->split_kind == 2) {
         // conv3x3_planes_kernel: chunk (column tile tn, input slab, tap) = 64 couts x 256 B; piece g < 8 = hi of channels
         // 64 slab + 8 g .. + 7, g >= 8 = lo of channels 8 (g - 8) ..; times a power of two (pick_wscale), undone by post_scale
@@ -968,7 +992,8 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
     for (int l = 0; l < 9; ++l) {
         const int Cout = kConvCout[l];
         const int M = (int)(n * hh[l + 1] * ww[l + 1]);
-        const bool fuse1 = m->conv1_fused && m->C == 8 && !m->keep && ww[1] <= kPlMaxW;  // conv1 inside the first residual block (c3_conv3.h SRC8)
+        // conv1 inside the first residual block (c3_conv3.h SRC8; 8-channel windows, or 9 with the dwell channel)
+        const bool fuse1 = m->conv1_fused && (m->C == 8 || m->C == 9) && m->conv1_wfrag16 && !m->keep && ww[1] <= kPlMaxW && ww[0] >= 3;
         if (l == 0 && fuse1) {  // no launch, no conv1 planes: res1a computes its input rows, res1b its residual, from the windows
             cin = Cout;
             continue;
@@ -1035,16 +1060,21 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
                 if (l == 1) cp.x = nullptr;
                 else cp.res = nullptr;
             }
-            // SRC8: + conv1 for 320 halo rows (res1a) / the tile's 256 pixels (res1b), two piece products of K = 80
+            // SRC8: + conv1 for 320 halo rows (res1a) / the tile's 256 pixels (res1b), two piece products of K = 80 (96 for 9 channels)
             const double tiles_x = sppf ? (double)((n + 3) / 4) : (double)tiles_m;  // pixel tiles the launch really runs
-            ps.mfma(2.0 * tiles_x * kPlBM * (double)Cout * 9.0 * cin * 3 + (src8 ? 2.0 * tiles_m * (l == 1 ? 320 : 256) * 64.0 * 80.0 * 2 : 0.0), true);
+            ps.mfma(2.0 * tiles_x * kPlBM * (double)Cout * 9.0 * cin * 3 +
+                        (src8 ? 2.0 * tiles_m * (l == 1 ? 320 : 256) * 64.0 * (m->C == 8 ? 80.0 : 96.0) * 2 : 0.0),
+                    true);
             // persistent: one workgroup per tile when they all fit (2 per CU), else wg_slots rounded down so that a
             // workgroup's tiles share their column tile (c3_conv3.h)
             int g = cp.tiles;
             const int cus = m->wg_slots / 2, unit = 8 * (Cout / 64);  // one 512-thread workgroup (114 KB of LDS) per CU
             if (g > cus) g = std::max(unit, cus / unit * unit);
             const dim3 grid(g), block(kPlThreads);
-            if (Cout == 64 && src8) {
+            if (Cout == 64 && src8 && m->C == 9) {
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true, 0, 2, false, 9>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false, 0, 1, false, 9>), grid, block, 0, s, cp);
+            } else if (Cout == 64 && src8) {
                 if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true, 0, 2>), grid, block, 0, s, cp);
                 else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false, 0, 1>), grid, block, 0, s, cp);
             } else if (Cout == 64) {

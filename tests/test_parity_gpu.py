@@ -633,21 +633,30 @@ def test_blocking_call_cut_into_chunks_gives_the_same_rows(oracle_mod):
     assert np.array_equal(m.predict_numpy(x_ro), y[:600])
 
 
-def test_conv1_inside_the_first_residual_block(monkeypatch, oracle_mod):
-    """8-channel windows: conv1 is computed inside res1a (its input halo rows) and res1b (its residual) from the int8 windows
-    (c3_conv3.h SRC8) instead of being launched, written and read back.  Several tiles per workgroup (330 windows: 987 stage-1
-    tiles on 256 workgroups), a ragged last tile, windows at both ends of the batch; against the oracle and against the unfused
-    launches (the residual is the full fp32 conv1 value instead of its two fp16 pieces: ~1e-7 apart, labels identical)"""
-    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=81)
-    x = syn.make_fa_windows(330, seed=82)
-    y = make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)
+@pytest.mark.parametrize("channels", [8, 9])
+def test_conv1_inside_the_first_residual_block(channels, monkeypatch, oracle_mod):
+    """8- and 9-channel (dwell) windows: conv1 is computed inside res1a (its input halo rows) and res1b (its residual) from the
+    int8 windows (c3_conv3.h SRC8) instead of being launched, written and read back.  Several tiles per workgroup (330 windows:
+    987 stage-1 tiles on 256 workgroups), a ragged last tile, windows at both ends of the batch (the 9-byte pixels are fetched as
+    unaligned pieces that must neither touch bytes in front of the first window nor lose bytes at the end of the last); against
+    the oracle and against the unfused launches (the residual is the full fp32 conv1 value instead of its two fp16 pieces: ~1e-7
+    apart, labels identical)"""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, channels, True, seed=81)
+    x = syn.make_fa_windows(330, seed=82, channels=channels)
+    y = make_model(syn.FULL_ALIGNMENT, channels, True, sd).predict_numpy(x)
     sel = np.r_[0:12, 159:171, 318:330]
     util.assert_rows_match(y[sel], oracle_mod.fa_forward(sd, x[sel], True), what="conv1 inside res1a / res1b")
     monkeypatch.setenv("C3HIP_CONV1_FUSED", "0")
-    y0 = make_model(syn.FULL_ALIGNMENT, 8, True, sd).predict_numpy(x)
+    y0 = make_model(syn.FULL_ALIGNMENT, channels, True, sd).predict_numpy(x)
     monkeypatch.delenv("C3HIP_CONV1_FUSED")
     assert np.abs(y - y0).max() < 2e-6
     assert (y[:, :21].argmax(1) == y0[:, :21].argmax(1)).all() and (y[:, 21:24].argmax(1) == y0[:, 21:24].argmax(1)).all()
+    # one window, and windows whose last row / last pixel end the tensor, in a batch of their own
+    # (uniform recipe: every byte of the window is non-zero, also the first and last rows the realistic recipe leaves empty)
+    xu = syn.make_fa_windows(3, seed=83, recipe="uniform", channels=channels)
+    for n in (1, 3):
+        util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, channels, True, sd).predict_numpy(xu[:n]), oracle_mod.fa_forward(sd, xu[:n], True),
+                               what=f"{n} uniform window(s), {channels} channels")
 
 
 def test_pyramid_pooling_inside_the_last_convolution(monkeypatch, oracle_mod):

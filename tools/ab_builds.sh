@@ -6,7 +6,7 @@ print('  one in flight %.0f (%.4f ms)  three %.0f | sum of kernels %.1f us |' % 
 "; }
 for rep in 1 2; do
 for lib in "$@"; do
-  for wl in full_alignment pileup; do
+  for wl in ${WLS:-full_alignment pileup}; do
     echo "== $wl $lib"
     C3HIP_LIB=$PWD/$lib timeout 600 python bench.py --gpus 1 --workload $wl --no-cpu-baseline --no-host-leg --steps 200 --warmup 10 2> gpurun_out/ab.err | pyb
   done
