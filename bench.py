@@ -266,7 +266,7 @@ def run_workload(name, args, rank, world, local):
                       for r in stats}
     if kind == syn.FULL_ALIGNMENT:
         dom = [r for r in stats if r["name"].startswith(("fa.conv", "fa.res", "fa.stage"))]
-        dom_name = ("3x3 convolution family of Clair3_F (conv1 -- for 8-channel windows computed inside fa.res1a / fa.res1b, its algorithmic "
+        dom_name = ("3x3 convolution family of Clair3_F (conv1 -- computed inside fa.res1a / fa.res1b, its algorithmic "
                     "FLOP counted once, in fa.res1a --, the two other stride-2 convs, six residual-block convs): the launches named "
                     "fa.conv* / fa.res* in `kernels`")
     else:
