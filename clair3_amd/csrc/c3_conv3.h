@@ -68,6 +68,7 @@ struct PlaneConvParams {
     const uint32_t *c1w = nullptr;   // conv1_i8_f16_kernel's weight fragments (c3_conv1.h): [5 k-steps][2 column blocks][2 pieces][64 lanes][16 B]
     const float *c1b = nullptr;      // conv1 bias [64] (BatchNorm folded)
     int Hin = 0, Win = 0;
+    uint32_t mg_hw = 0, mg_w = 0;    // fast_div magics of H * W and W (c3_gemm.h)
 };
 
 // split four fp32 values into their fp16 pieces and store them behind `off` (hi plane) / `off + 128` (lo plane)
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         int kh_ = kh;
         asm volatile("" : "+v"(kh_));
         const bool valid = (unsigned)pix < (unsigned)p.M;
-        const int b = pix / HW, r = pix - b * HW;
-        const int oy = r / W, ox = r - oy * W;
+        const int b = fast_div(pix, p.mg_hw), r = pix - b * HW;
+        const int oy = fast_div(r, p.mg_w), ox = r - oy * W;
         const uint32_t base = (uint32_t)(((b * p.Hin + 2 * oy) * p.Win + 2 * ox) * C1);
         if constexpr (C1 == 9) {
             // k-step t = (row ky = t >> 1, half u = t & 1): lane half kh_ takes bytes 16 u + 8 kh_ .. + 7 of the row's 27 (+ 5)
@@ -399,8 +400,8 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             const int m = m0 + lrow[i];
             uint32_t mk = 0;
             if (m < p.M) {
-                const int b = m / HW, rem = m - b * HW;
-                const int oh = rem / W, ow = rem - oh * W;
+                const int b = fast_div(m, p.mg_hw), rem = m - b * HW;
+                const int oh = fast_div(rem, p.mg_w), ow = rem - oh * W;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;

@@ -41,6 +41,7 @@ struct DensePlanesParams {
     // CONV: 3x3 / pad 1 / stride `stride` convolution as an implicit GEMM, M = B * Ho * Wo output pixels, K = 9 * Cin
     int Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0, stride = 1;
     uint32_t *range_flag = nullptr;
+    uint32_t mg_hw = 0, mg_w = 0;  // CONV: fast_div magics of Ho * Wo and Wo (c3_gemm.h)
     long long *trace = nullptr;  // TR (debug, C3HIP_DENSE_TRACE): {tag, shader clock} pairs of workgroup 0, waves 0 and 4, [2][512][2]
 };
 
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
                 uint32_t mk = 0;
                 int base = 0;
                 if (m < p.M) {
-                    const int b = m / hw, rem = m - b * hw;
-                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                    const int b = fast_div(m, p.mg_hw), rem = m - b * hw;
+                    const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
                     const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
                     base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
 #pragma unroll
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DenseP
                 uint32_t mk = 0;
                 int base = 0;
                 if (m < p.M) {
-                    const int b = m / hw, rem = m - b * hw;
-                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                    const int b = fast_div(m, p.mg_hw), rem = m - b * hw;
+                    const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
                     const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
                     base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
 #pragma unroll
@@ -665,8 +666,8 @@ __global__ __launch_bounds__(kWsThreads) void dense_planes_ws_kernel(DensePlanes
                     uint32_t mk = 0;
                     int base = 0;
                     if (m < p.M) {
-                        const int b = m / hw, rem = m - b * hw;
-                        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                        const int b = fast_div(m, p.mg_hw), rem = m - b * hw;
+                        const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
                         const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
                         base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
 #pragma unroll

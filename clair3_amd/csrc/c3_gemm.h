@@ -86,6 +86,11 @@ __device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
 // XCD-aware, bijective block -> tile map: block b runs on XCD b%8 (observed; speed only), so give every
 // XCD a contiguous range of tiles (n fastest): the N-tiles of one M-tile and neighbouring M-tiles, which
 // share A rows / convolution halos, then hit the same 4 MiB L2.
+// floor(n / d) as ONE multiply-high instead of the ~25 instructions of a 32-bit division (they sit in the per-tile address code
+// of the convolution kernels, whose vector instructions cost matrix-pipe time): magic = floor(2^32 / d) + 1, exact for
+// 0 <= n with n * d < 2^32 (the host checks that: div_magic in c3_model.hip); magic 0 stands for d = 1.
+__device__ __forceinline__ int fast_div(int n, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)n, magic) : n; }
+
 __device__ __forceinline__ int xcd_tile_index(int block, int n_tiles) {
     const int xcd = block & 7, slot = block >> 3;
     const int q = n_tiles >> 3, r = n_tiles & 7;

@@ -973,6 +973,13 @@ static int spp_bins(const c3_model *m, int H, int W, SppParams &sp) {
 }
 
 // ---- plane-activation pipeline (c3_conv3.h): the default whenever the handle is on the fp16x3 kernels ----
+// magic of fast_div (c3_gemm.h) for divisor d and dividends below n: 0 = "d is 1"; fails when n * d does not fit 32 bits
+static int div_magic(int d, int64_t n, uint32_t *magic) {
+    if (d <= 1) return *magic = 0u, 0;
+    if (n * d >= ((int64_t)1 << 32)) return fail("batch too large for the 32-bit pixel arithmetic of the convolution kernels");
+    return *magic = (uint32_t)((((uint64_t)1 << 32) / (uint64_t)d) + 1), 0;
+}
+
 static bool fa_planes_ok(const c3_model *m) {
     if (!m->fa_planes || !m->f16_ok || m->split_kind != 2) return false;
     int hh[10], ww[10];
@@ -1023,6 +1030,8 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             dp.a = m->act[l - 1], dp.w = m->pconv_w[l], dp.bias = m->conv_b[l], dp.c = m->act[l], dp.post_scale = 1.f / m->pconv_wscale[l];
             dp.M = M, dp.N = Cout, dp.K = 9 * cin, dp.tiles_n = Cout / kDnBN, dp.tiles = (M + kDnBM - 1) / kDnBM * dp.tiles_n;
             dp.Hin = hh[l], dp.Win = ww[l], dp.Cin = cin, dp.Ho = hh[l + 1], dp.Wo = ww[l + 1], dp.stride = 2, dp.range_flag = m->range_flag;
+            TRY(div_magic(hh[l + 1] * ww[l + 1], (int64_t)M + 2 * kDnBM, &dp.mg_hw));
+            TRY(div_magic(ww[l + 1], hh[l + 1] * ww[l + 1], &dp.mg_w));
             ps.mfma(2.0 * ((M + kDnBM - 1) / kDnBM * kDnBM) * (double)Cout * 9.0 * cin * 3, true);
             const int grid = std::min(dp.tiles, m->wg_slots / 2);  // one 512-thread workgroup (136 KB of LDS) per CU
             if (m->dense_mode == 4) hipLaunchKernelGGL(dense_planes_ws_kernel<true>, dim3(grid), dim3(kWsThreads), 0, s, dp);
@@ -1046,6 +1055,8 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             cp.x = m->act[l - 1], cp.w = m->pconv_w[l], cp.bias = m->conv_b[l], cp.res = res ? m->act[l - 2] : nullptr, cp.out = m->act[l];
             cp.range_flag = m->range_flag, cp.post_scale = 1.f / m->pconv_wscale[l];
             cp.M = M, cp.H = hh[l], cp.W = ww[l];
+            TRY(div_magic(hh[l] * ww[l], (int64_t)M + 2 * kPlBM, &cp.mg_hw));
+            TRY(div_magic(ww[l], hh[l] * ww[l], &cp.mg_w));
             const int tiles_m = (M + kPlBM - 1) / kPlBM;
             cp.tiles = tiles_m * (Cout / 64);
             const bool src8 = fuse1 && (l == 1 || l == 2);

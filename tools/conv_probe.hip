@@ -48,6 +48,7 @@ template <int C> static int shape(const char *name, int B, int H, int W, int slo
     PlaneConvParams cp;
     cp.x = x, cp.w = w, cp.bias = bias, cp.res = r, cp.out = y, cp.range_flag = flag, cp.post_scale = 1.f;
     cp.M = B * H * W, cp.H = H, cp.W = W;
+    cp.mg_hw = (uint32_t)((1ull << 32) / (uint64_t)(H * W) + 1), cp.mg_w = (uint32_t)((1ull << 32) / (uint64_t)W + 1);  // fast_div magics
     const int tiles_m = (cp.M + kPlBM - 1) / kPlBM;
     cp.tiles = tiles_m * (C / 64);
     const int unit = 8 * (C / 64);
