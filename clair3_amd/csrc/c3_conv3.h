@@ -402,11 +402,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             if (m < p.M) {
                 const int b = fast_div(m, p.mg_hw), rem = m - b * HW;
                 const int oh = fast_div(rem, p.mg_w), ow = rem - oh * W;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)W) mk |= 1u << t;
-                }
+                mk = tap_mask9(oh - 1, ow - 1, p.H, W);
             }
             mask[i] = mk;
         }

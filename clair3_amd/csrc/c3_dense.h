@@ -100,11 +100,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanes
                     const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
                     const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
                     base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int ih = ih0 + t / 3, iw = iw0 + t % 3;
-                        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
-                    }
+                    mk = tap_mask9(ih0, iw0, p.Hin, p.Win);
                 }
                 rbase[j] = base, rmask[j] = mk;
             }
@@ -371,11 +367,7 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DenseP
                     const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
                     const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
                     base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int ih = ih0 + t / 3, iw = iw0 + t % 3;
-                        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
-                    }
+                    mk = tap_mask9(ih0, iw0, p.Hin, p.Win);
                 }
                 rbase[j] = base, rmask[j] = mk;
             }
@@ -670,11 +662,7 @@ __global__ __launch_bounds__(kWsThreads) void dense_planes_ws_kernel(DensePlanes
                         const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
                         const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
                         base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
-#pragma unroll
-                        for (int t = 0; t < 9; ++t) {
-                            const int ih = ih0 + t / 3, iw = iw0 + t % 3;
-                            if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mk |= 1u << t;
-                        }
+                        mk = tap_mask9(ih0, iw0, p.Hin, p.Win);
                     }
                     rbase[j] = base, rmask[j] = mk;
                 }

@@ -91,6 +91,17 @@ __device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
 // 0 <= n with n * d < 2^32 (the host checks that: div_magic in c3_model.hip); magic 0 stands for d = 1.
 __device__ __forceinline__ int fast_div(int n, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)n, magic) : n; }
 
+// 9-bit validity mask of a 3 x 3 patch whose top-left tap is input pixel (ih0, iw0) of an H x W image: bit 3 r + c set when
+// (ih0 + r, iw0 + c) lies inside.  Three row tests and three column tests instead of nine (row, column) pairs.
+__device__ __forceinline__ uint32_t tap_mask9(int ih0, int iw0, int H, int W) {
+    uint32_t cb = 0, mk = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cb |= (unsigned)(iw0 + c) < (unsigned)W ? 1u << c : 0u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) mk |= (unsigned)(ih0 + r) < (unsigned)H ? cb << (3 * r) : 0u;
+    return mk;
+}
+
 __device__ __forceinline__ int xcd_tile_index(int block, int n_tiles) {
     const int xcd = block & 7, slot = block >> 3;
     const int q = n_tiles >> 3, r = n_tiles & 7;
