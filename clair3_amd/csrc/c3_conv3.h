@@ -37,6 +37,10 @@
 #include "c3_gemm.h"
 #include "c3_kernels.h"
 
+#ifndef C3_HALO_TAP
+#define C3_HALO_TAP 8
+#endif
+
 namespace c3 {
 
 typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
@@ -155,8 +159,12 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(RES ? p.res : p.out), 0, (uint32_t)((int64_t)p.M * PIXB), 0x00020000);
 
-    auto halo_issue = [&](pl_u32x4 (&h)[kPlHaloLoads], int mbase, int slab) __attribute__((always_inline)) {
+    // `on` = false: the ten loads are still issued, at an out-of-range offset (zeros, no traffic).  A request under `if (on)` would
+    // make hipcc size every later s_waitcnt vmcnt(N) for the path WITHOUT these loads -- and on the path with them the next wait
+    // for a weight chunk then also waits for all ten of them (one in-order counter)
+    auto halo_issue = [&](pl_u32x4 (&h)[kPlHaloLoads], int mbase, int slab, bool on = true) __attribute__((always_inline)) {
         const int m_lo = mbase - W - 1;
+        const uint32_t lim = on ? (uint32_t)p.M : 0u;  // (one scalar select: as a condition on every load `on` became control flow around each of them)
         int tid_ = tid;
         asm volatile("" : "+v"(tid_));  // the ten row numbers are recomputed here, not carried (and spilled: reloads that wait for the loads just issued) across the tile loop
 #pragma unroll
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             const int idx = tid_ + kPlThreads * j;
             const int row = idx >> 4, pos = idx & 15;
             const int pix = m_lo + row;
-            const bool ok = row < T && (unsigned)pix < (unsigned)p.M;
+            const bool ok = row < T && (unsigned)pix < lim;
             const uint32_t off = ok ? (uint32_t)pix * (uint32_t)PIXB + (uint32_t)(slab * 256 + pos * 16) : kPlOob;
             h[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
         }
@@ -444,13 +452,15 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             const int cc = slab * 9 + tap;
             const bool last = cc == NCH - 1;
             if constexpr (!(ABL & 1)) b_issue(rb[tap % 3], cc + 3 < NCH ? cc + 3 : cc + 3 - NCH);  // set tap % 3 went to LDS two chunks ago
-            const bool sw = tap == 8 && (!last || more);
-            if (tap == 8) {
+            constexpr int kHaloTap = C3_HALO_TAP;  // the tap under whose matrix phase the next slab's halo rows are requested
+            if (tap == kHaloTap) {
                 // NS = 1 (C = 64): the only switch is the one to the next tile, and its halo rows are requested AFTER the tap loop
                 // (below) -- they have the whole epilogue to arrive, and the 40 registers they land in are not held under the
                 // last chunk's matrix phase, where the kernel's register demand peaks
-                if constexpr (NS > 1 && !(ABL & 2))
-                    if (sw) halo_issue(hreg, last ? m0n : m0, last ? 0 : slab + 1);
+                if constexpr (NS > 1 && !(ABL & 2)) {
+                    const bool lastslab = slab == NS - 1;
+                    halo_issue(hreg, lastslab ? m0n : m0, lastslab ? 0 : slab + 1, !lastslab || more);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);  // the global loads stay ahead of the matrix phase they fly under
 #pragma unroll
@@ -505,9 +515,9 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         // channels, 8 lanes per 128-byte plane row: (pixel, channel group) items, residual added, ReLU, split, two stores.
         if constexpr (NS == 1) {
             if constexpr (SRC8 == 1) {
-                if (more) c1_halo_request(m0n);
+                c1_halo_request(more ? m0n : -0x40000000);  // (no next tile: every pixel out of range, the taps are requested at an out-of-range offset)
             } else if constexpr (!(ABL & 2)) {
-                if (more) halo_issue(hreg, m0n, 0);
+                halo_issue(hreg, m0n, 0, more);
             }
         }
         lds_barrier();  // all waves are done with the halo rows
