@@ -209,6 +209,7 @@ struct c3_model {
     float *l4_w3 = nullptr;                  // the same as three bf16 pieces (SPLIT path); env C3HIP_L4_SPLIT
     bool l4_split = true;
     float *proj2_pw = nullptr;               // LSTM2 projection weights as dense_planes_kernel chunks (c3_dense.h); env C3HIP_PROJ2_PLANES
+    float *proj2_pwr = nullptr;              // the same in the register-fragment order of dense_planes_wres_kernel (weights resident; C3HIP_DENSE_MODE=6)
     float *proj2_pw32 = nullptr;             // the same as 32-channel chunks of 256 rows for dense_planes_big_kernel (C3HIP_DENSE_MODE=5)
     float proj2_pwscale = 1.f;
     bool proj2_planes = true;
@@ -597,6 +598,24 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                                         memcpy(&b16[(((((size_t)tn * NK32 + kc) * kBgBN + r) * 8 + g) * 8) + j], &piece, 2);
                                     }
                     TRY(upload(m, &m->proj2_pw32, pb));
+                }
+                if (N % kWrBN == 0 && Kp == kWrK) {
+                    // dense_planes_wres_kernel: the weights of wave w of column tile tn in fragment order, [tn][w][k-step][piece][lane][8 fp16]:
+                    // lane (n = lane & 31, kh = lane >> 5) holds k = 16 ks + 8 kh .. + 7 of row 256 tn + 32 w + n; the same power of two
+                    std::vector<float> pr((size_t)N * 256);
+                    uint16_t *r16 = reinterpret_cast<uint16_t *>(pr.data());
+                    for (int tn = 0; tn < N / kWrBN; ++tn)
+                        for (int w = 0; w < 8; ++w)
+                            for (int ks = 0; ks < kWrKS; ++ks)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int j = 0; j < 8; ++j) {
+                                        const float v = pw[(size_t)(tn * kWrBN + 32 * w + (lane & 31)) * Kp + 16 * ks + 8 * (lane >> 5) + j] * sc;  // exact
+                                        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                        const size_t base = ((((size_t)tn * 8 + w) * kWrKS + ks) * 2) * 64 * 8;
+                                        memcpy(&r16[base + (size_t)lane * 8 + j], &h0, 2);
+                                        memcpy(&r16[base + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                                    }
+                    TRY(upload(m, &m->proj2_pwr, pr));
                 }
             }
         }
@@ -1373,6 +1392,20 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
                 }
                 dp.trace = nullptr;
             } else
+            if ((m->dense_mode == 6 || (m->adaptive && m->dense_mode == 3)) && m->proj2_pwr &&
+                (M + kWrBM - 1) / kWrBM >= 2 * 8 * std::max(1, m->wg_slots / 16 / (1280 / kWrBN))) {
+                // weights resident in registers (c3_dense.h): 8 XCDs x lanes x 5 column tiles of workgroups, each walking the row tiles of its lane
+                DenseWresParams wp;
+                wp.a = m->h1, wp.w = m->proj2_pwr, wp.bias = m->proj_b[1], wp.c = m->gx2, wp.post_scale = 1.f / m->proj2_pwscale;
+                wp.M = M, wp.N = 1280, wp.tiles_m = (M + kWrBM - 1) / kWrBM, wp.tiles_n = 1280 / kWrBN;
+                wp.lanes_per_xcd = std::max(1, m->wg_slots / 16 / wp.tiles_n);  // CUs per XCD / column tiles (32 / 5 = 6)
+                // beside other handles half as many, twice as long workgroups: 120 of them leave room for the 128 of an LSTM launch
+                // of another batch (three batches in flight: 5.46 M -> 5.59 M windows/s; alone 4.9 M -> 4.3 M, hence the choice)
+                if (m->adaptive && m->concurrent) wp.lanes_per_xcd = std::max(1, wp.lanes_per_xcd / 2);
+                static const int env_lanes = getenv("C3HIP_WRES_LANES") ? atoi(getenv("C3HIP_WRES_LANES")) : 0;  // A/B
+                if (env_lanes > 0) wp.lanes_per_xcd = env_lanes;
+                hipLaunchKernelGGL(dense_planes_wres_kernel<0>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
+            } else
             if ((m->dense_mode == 5 || (m->adaptive && m->dense_mode == 3 && m->concurrent)) && m->proj2_pw32) {
                 DenseBigParams bp;
                 bp.a = m->h1, bp.w = m->proj2_pw32, bp.bias = m->proj_b[1], bp.c = m->gx2, bp.post_scale = 1.f / m->proj2_pwscale;
@@ -2144,7 +2177,7 @@ int c3_model_destroy(c3_model *m) {
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
                    m->l4_w, m->l4_b, m->w5t, m->b5, m->wh, m->bh, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias,
-                   m->conv1_wfrag, m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3, m->proj2_pw, m->proj2_pw32};
+                   m->conv1_wfrag, m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_frag, m->l4_w3, m->proj2_w3, m->proj2_pw, m->proj2_pw32, m->proj2_pwr};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     if (m->decode_dev) (void)hipFree(m->decode_dev);

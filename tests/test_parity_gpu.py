@@ -587,7 +587,7 @@ def test_dense_kernel_forms_are_bit_identical(monkeypatch, oracle_mod):
     y_f = make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f)
     util.assert_rows_match(y_p[:40], oracle_mod.pileup_forward(sd_p, x_p[:40], False), what="pileup, default dense kernel")
     util.assert_rows_match(y_f[-24:], oracle_mod.fa_forward(sd_f, x_f[-24:], True), what="full alignment, default dense kernel")
-    for mode in ("0", "1", "4", "5"):
+    for mode in ("0", "1", "4", "5", "6"):
         monkeypatch.setenv("C3HIP_DENSE_MODE", mode)
         assert np.array_equal(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p), f"pileup rows differ with C3HIP_DENSE_MODE={mode}"
         assert np.array_equal(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f), f"full-alignment rows differ with C3HIP_DENSE_MODE={mode}"
@@ -676,9 +676,9 @@ def test_pyramid_pooling_inside_the_last_convolution(monkeypatch, oracle_mod):
 
 
 def test_kernel_choice_beside_other_handles_gives_the_same_rows(oracle_mod):
-    """a pileup handle picks its LSTM1 tile size and its projection kernel by whether other handles of the process are feeding the
-    GPU (others_active()): rows computed beside a busy second handle (full LSTM1 tiles, 256 x 256 projection tiles)
-    equal the rows of the same windows computed alone (half tiles, 128 x 128) bit for bit"""
+    """a pileup handle picks its LSTM tile sizes and the shape of its projection launch by whether other handles of the process are
+    feeding the GPU (others_active()): rows computed beside a busy second handle (full LSTM tiles, 120 workgroups
+    of the weights-resident projection) equal the rows of the same windows computed alone (half tiles, 240 workgroups) bit for bit"""
     sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=101)
     x = syn.make_pileup_windows(1024 + 5, seed=102)
     m1 = make_model(syn.PILEUP, 18, False, sd)

@@ -88,6 +88,30 @@ int main(int argc, char **argv) {
         const int gb = bp.tiles < 256 ? bp.tiles : 256;
         report("256 x 256 tile kernel", time_us([&] { hipLaunchKernelGGL(dense_planes_big_kernel, dim3(gb), dim3(kDnThreads), 0, 0, bp); }, 20));
     }
+    {   // weights resident in registers (fragment order: any bytes do for timing)
+        DenseWresParams wp;
+        wp.a = da, wp.w = dw, wp.bias = dbias, wp.c = dc, wp.post_scale = 1.f / 256.f;
+        wp.M = M, wp.N = N, wp.tiles_m = (M + kWrBM - 1) / kWrBM, wp.tiles_n = N / kWrBN, wp.lanes_per_xcd = 6;
+        const int gw = 8 * wp.lanes_per_xcd * wp.tiles_n;
+#define RUNR(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_wres_kernel<abl>), dim3(gw), dim3(kDnThreads), 0, 0, wp); }, 20))
+        RUNR(0, "weights-resident kernel (240 workgroups)");
+        RUNR(16, "  - result stores");
+        RUNR(1, "  - activation loads");
+        RUNR(2, "  - LDS staging writes");
+        RUNR(8, "  - fragment reads");
+        RUNR(4, "  - matrix instructions");
+        RUNR(32, "  - barriers");
+        RUNR(19, "  - loads - staging - stores");
+        RUNR(27, "  - loads - staging - stores - fragment reads (matrix + barriers)");
+        RUNR(59, "  matrix instructions only");
+        RUNR(15, "  stores + barriers only");
+        for (int l : {4, 5, 6}) {
+            wp.lanes_per_xcd = l;
+            char nm[64];
+            snprintf(nm, sizeof nm, "  full kernel, %d lanes per XCD (%d workgroups)", l, 8 * l * wp.tiles_n);
+            report(nm, time_us([&] { hipLaunchKernelGGL((dense_planes_wres_kernel<0>), dim3(8 * l * wp.tiles_n), dim3(kDnThreads), 0, 0, wp); }, 20));
+        }
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }
