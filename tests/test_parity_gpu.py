@@ -575,10 +575,11 @@ def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracl
 
 
 def test_dense_kernel_forms_are_bit_identical(monkeypatch, oracle_mod):
-    """c3_dense.h holds four forms of the same contraction (round-2 kernel with staged / direct epilogue, chunk stream spread over
-    the matrix stream = default, role-split waves): same chunk order, same matrix instructions, same epilogue arithmetic -- the
-    rows must be EQUAL, also when a workgroup walks several tiles (600 pileup windows: 1550 projection tiles on 256 workgroups;
-    96 full-alignment windows: 156 + 90 stride-2 tiles) and on ragged last tiles"""
+    """c3_dense.h holds six forms of the same contraction (round-2 kernel with staged / direct epilogue, chunk stream spread over
+    the matrix stream = the stride-2 convolutions' default, role-split waves, 256 x 256 tiles, weights resident in registers = the
+    projection's default): same chunk order, same matrix instructions per accumulator, same epilogue arithmetic -- the rows must
+    be EQUAL, also when a workgroup walks several tiles (607 pileup windows: 313 row tiles of 64 on 48 lanes, 1550 tiles of
+    128 x 128 on 256 workgroups; 96 full-alignment windows: 156 + 90 stride-2 tiles) and on ragged last tiles"""
     sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=61)
     x_p = syn.make_pileup_windows(600 + 7, seed=62)
     sd_f = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=63)
@@ -587,7 +588,7 @@ def test_dense_kernel_forms_are_bit_identical(monkeypatch, oracle_mod):
     y_f = make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f)
     util.assert_rows_match(y_p[:40], oracle_mod.pileup_forward(sd_p, x_p[:40], False), what="pileup, default dense kernel")
     util.assert_rows_match(y_f[-24:], oracle_mod.fa_forward(sd_f, x_f[-24:], True), what="full alignment, default dense kernel")
-    for mode in ("0", "1", "4", "5", "6"):
+    for mode in ("0", "1", "3", "4", "5", "6"):
         monkeypatch.setenv("C3HIP_DENSE_MODE", mode)
         assert np.array_equal(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p), f"pileup rows differ with C3HIP_DENSE_MODE={mode}"
         assert np.array_equal(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f), f"full-alignment rows differ with C3HIP_DENSE_MODE={mode}"
