@@ -18,13 +18,14 @@ for kind, ch, indel, mk in ((syn.PILEUP, 18, False, syn.make_pileup_windows), (s
     for _ in range(5):
         m.wait(m.submit(x, slot=0))
     ts, tw, n = 0.0, 0.0, 200
-    tickets = [m.submit(x, slot=0), m.submit(x, slot=1)]
+    slots = int(os.environ.get("SLOTS", "3"))
+    tickets = [m.submit(x, slot=k) for k in range(slots)]
     t0 = time.perf_counter()
     for i in range(n):
         a = time.perf_counter()
         m.wait(tickets.pop(0))
         b = time.perf_counter()
-        tickets.append(m.submit(x, slot=i % 2))
+        tickets.append(m.submit(x, slot=i % slots))
         c = time.perf_counter()
         tw += b - a
         ts += c - b
