@@ -213,10 +213,12 @@ struct c3_model {
     float *proj2_pw32 = nullptr;             // the same as 32-channel chunks of 256 rows for dense_planes_big_kernel (C3HIP_DENSE_MODE=5)
     float proj2_pwscale = 1.f;
     bool proj2_planes = true;
-    int dense_mode = 3;                      // dense kernels (c3_dense.h): 3 = dense_planes_pipe_kernel (chunk stream spread over the matrix stream;
-                                             // default), 4 = dense_planes_ws_kernel (8 multiplying + 4 moving waves: the kernels themselves 5-8 %
-                                             // faster, the step as a whole 2.5 % slower -- DESIGN.md 3.8), 1 / 0 = round-2 kernel with the direct /
-                                             // staged fp32 epilogue; env C3HIP_DENSE_MODE
+    int dense_mode = 3;                      // dense kernels (c3_dense.h): 3 = default: dense_planes_pipe_kernel (chunk stream spread over the matrix
+                                             // stream) for the stride-2 convolutions and, while `adaptive`, dense_planes_wres_kernel (weights resident
+                                             // in registers) for the LSTM2 projection; 6 = that kernel pinned, 5 = 256 x 256 tiles, 4 =
+                                             // dense_planes_ws_kernel (8 multiplying + 4 moving waves: the kernels themselves 5-8 % faster, the step
+                                             // as a whole 2.5 % slower -- DESIGN.md 3.8), 1 / 0 = round-2 kernel with the direct / staged fp32
+                                             // epilogue; env C3HIP_DENSE_MODE (setting it pins the projection to the pipe kernel for 3)
     float *proj2_w3 = nullptr;               // LSTM2 projection weights as bf16 pieces for the tiled SPLIT GEMM; env C3HIP_PROJ2_SPLIT
     bool proj2_split = true;
     float *w5t = nullptr, *b5 = nullptr, *wh = nullptr, *bh = nullptr;
