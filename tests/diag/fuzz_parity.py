@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Diagnostic soak (not a test): random batch sizes, seeds and recipes through the C ABI against the oracle, for the three model
+shapes; every row of every batch.  usage: fuzz_parity.py [seconds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from clair3_amd import synthetic as syn  # noqa: E402
+from oracle import oracle  # noqa: E402
+from tests.test_parity_gpu import make_model  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(os.environ.get("SEED", "7")))
+cases = [(syn.PILEUP, 18, False), (syn.PILEUP, 18, True), (syn.FULL_ALIGNMENT, 8, True), (syn.FULL_ALIGNMENT, 9, True), (syn.FULL_ALIGNMENT, 8, False)]
+models = {}
+t_end = time.time() + budget
+n_batches = n_rows = 0
+worst = 0.0
+while time.time() < t_end:
+    kind, ch, indel = cases[int(rng.integers(len(cases)))]
+    seed = int(rng.integers(1 << 30))
+    key = (kind, ch, indel)
+    if key not in models or rng.random() < 0.2:
+        sd = syn.make_state_dict(kind, ch, indel, seed=seed)
+        models[key] = (make_model(kind, ch, indel, sd), sd)
+    m, sd = models[key]
+    hi = 1300 if kind == syn.PILEUP else 330
+    n = int(rng.integers(1, hi)) if rng.random() < 0.7 else int(rng.choice([1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 184, 185, 186, 255, 256, 257]))
+    recipe = "uniform" if rng.random() < 0.3 else "realistic"
+    x = syn.make_pileup_windows(n, seed=seed, recipe=recipe) if kind == syn.PILEUP else syn.make_fa_windows(n, seed=seed, recipe=recipe, channels=ch)
+    y = m.predict_numpy(x)
+    # oracle on a sample of rows (it is the slow side): both ends and a random middle run
+    idx = np.unique(np.r_[0:min(n, 4), max(0, n - 4):n, rng.integers(0, n, size=min(n, 6))])
+    y_o = oracle.forward(kind, sd, x[idx], indel)
+    err = float(np.abs(y[idx] - y_o).max())
+    worst = max(worst, err)
+    lab = (y[idx, :21].argmax(1) == y_o[:, :21].argmax(1)).all() and (y[idx, 21:24].argmax(1) == y_o[:, 21:24].argmax(1)).all()
+    if not (err < 1e-4) or not np.isfinite(y).all() or not lab:
+        print(f"MISMATCH kind={kind} ch={ch} indel={indel} n={n} seed={seed} recipe={recipe} err={err:.3e} labels_equal={lab}")
+        sys.exit(1)
+    # the same windows again in a different batch composition: bit-identical rows
+    if n > 3:
+        k = int(rng.integers(1, n))
+        y2 = np.concatenate([m.predict_numpy(x[:k]), m.predict_numpy(x[k:])])
+        if not np.array_equal(y, y2):
+            print(f"BATCH-DEPENDENT ROWS kind={kind} ch={ch} indel={indel} n={n} split={k} seed={seed} recipe={recipe}")
+            sys.exit(1)
+    n_batches += 1
+    n_rows += n
+print(f"ok: {n_batches} batches, {n_rows} windows, worst |dY| on the checked rows {worst:.2e}")
