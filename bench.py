@@ -25,9 +25,11 @@ probability rows travel to rank 0 in one RCCL gather per GATHER_EVERY steps (SUR
                   forms every contraction uses, 157.3 for the fp32 fallbacks); frac = achieved / peak; mfma_util = FLOP
                   the matrix instructions EXECUTE (three fp16 piece products per fp32 product, tile padding) / time /
                   peak; traffic / hbm_frac from the committed rocprofv3 PMC passes (profiles/pmc_traffic*.json);
-  cpu_baseline    the reference CPU path's arithmetic (oracle/torch_port.py: the ATen operators the reference modules
-                  call) on this node's host cores, rank 0, N = 1, bounded sample: (i) in-process at its best thread
-                  count, (ii) one thread (how the reference pipeline runs its workers) x visible cores;
+  cpu_baseline    the reference CPU path on this node's host cores, rank 0, N = 1, bounded sample: kind "reference" = the
+                  reference's own clair3/model.py modules called as its _torch_predict does (staged into the git-ignored
+                  oracle/_ref by oracle/stage_reference.py; "port" = oracle/torch_port.py, the same ATen operators, when
+                  no staged copy is there): (i) in-process at its best thread count, (ii) one thread (how the
+                  reference pipeline runs its workers) x usable cores;
   gt_concordance  arg-max of the gt21 and zygosity heads of the GPU rows vs the CPU baseline's rows on the same batch.
 """
 import argparse
@@ -136,6 +138,9 @@ def run_workload(name, args, rank, world, local):
             torch.cuda.synchronize()
 
     last_rows = [None]
+    # N > 1: the rows of GATHER_EVERY steps travel to rank 0 in one gather -- on RCCL directly (c3_gather_rows), watched: a
+    # rendezvous or first collective that does not complete in time sends every rank to torch.distributed's gather instead
+    exchange = c3dist.RowExchange(rank, world, device=local, timeout_s=args.gather_timeout, direct=not args.torch_gather)
 
     def timed(n_streams):
         counter = [0]
@@ -156,44 +161,77 @@ def run_workload(name, args, rank, world, local):
                 return gatherer.add(y)
             return y
 
-        gatherer = c3dist.RowGatherer(n_total, every=GATHER_EVERY, dst=0)
+        gatherer = c3dist.RowGatherer(n_total, every=GATHER_EVERY, dst=0, exchange=exchange)
         for _ in range(args.warmup):
             step()
         gatherer.flush()
-        fence()
-        t0 = time.perf_counter()
-        out = None
-        for _ in range(args.steps):
-            got = step()
+        blocks, own = [], []
+        for _ in range(max(1, args.repeats)):  # every block: EXACTLY K steps between two fences, MAX over ranks
+            fence()
+            t0 = time.perf_counter()
+            out = None
+            for _ in range(args.steps):
+                got = step()
+                out = got if got is not None else out
+            got = gatherer.flush()
             out = got if got is not None else out
-        got = gatherer.flush()
-        out = got if got is not None else out
-        fence()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        if rank == 0:
-            assert out is not None and out.shape[1] == (90 if indel else 24) and out.shape[0] % n_total == 0 and out.shape[0] > 0
-            assert bool(torch.isfinite(out).all())
-        return elapsed
+            torch.cuda.synchronize()
+            own.append(time.perf_counter() - t0)
+            fence()
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            blocks.append(elapsed)
+            if rank == 0:
+                assert out is not None and out.shape[1] == (90 if indel else 24) and out.shape[0] % n_total == 0 and out.shape[0] > 0
+                assert bool(torch.isfinite(out).all())
+        return blocks, own
 
-    single = timed(1)
-    multi = timed(S) if S > 1 else single
-    elapsed, in_flight = (multi, S) if multi <= single else (single, 1)
+    def stats(blocks, n=n_total):
+        r = sorted(n * args.steps / b for b in blocks)
+        return {"median": r[len(r) // 2] if len(r) % 2 else 0.5 * (r[len(r) // 2 - 1] + r[len(r) // 2]), "min": r[0], "max": r[-1],
+                "repeats": len(r), "steps_per_repeat": args.steps}
+
+    def describe(mi):
+        import ctypes as C
+        from clair3_amd import _lib
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.lib().c3_model_describe(mi._handle, buf, 256), "c3_model_describe")
+        return buf.value.decode()
+
+    single_blocks, single_own = timed(1)
+    variants = {"one_batch_in_flight": describe(model)}
+    multi_blocks, multi_own = timed(S) if S > 1 else (single_blocks, single_own)
+    if S > 1:
+        variants[f"{S}_batches_in_flight"] = describe(models[-1])
+    med = lambda b: float(np.median(b))
+    single, multi = med(single_blocks), med(multi_blocks)
+    elapsed, in_flight, own = (multi, S, multi_own) if multi <= single else (single, 1, single_own)
+    per_rank = None
+    if world > 1:  # every rank's own K-step time (before the MAX), so the driver can see N ranks at work
+        t = torch.tensor([med(own)], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank = [batch * args.steps / float(p.item()) for p in parts]
     # the device-resident entry is unchecked (asynchronous): the handles report afterwards whether any batch came near
     # the range of the fp16x3 kernels
     flags = [m.range_status() for m in models]
     res = {
         "workload": cfg, "batch_per_gpu": batch, "windows_per_step": n_total, "batches_in_flight": in_flight,
         "value": n_total * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
-        "one_batch_in_flight": {"value": n_total * args.steps / single, "ms_per_step": 1e3 * single / args.steps},
-        f"{S}_batches_in_flight": {"value": n_total * args.steps / multi, "ms_per_step": 1e3 * multi / args.steps},
+        "value_stats": stats(multi_blocks if in_flight > 1 else single_blocks),
+        "one_batch_in_flight": {"value": n_total * args.steps / single, "ms_per_step": 1e3 * single / args.steps, **stats(single_blocks)},
+        f"{S}_batches_in_flight": {"value": n_total * args.steps / multi, "ms_per_step": 1e3 * multi / args.steps, **stats(multi_blocks)},
+        "kernel_variants": variants,
         "flop_per_window": flop_w, "bytes_per_window": bytes_w,
         "range_flag_raised": any(f for f, _ in flags), "on_fp32_fallback": any(o for _, o in flags),
         "rows_rank0": last_rows[0].cpu().numpy() if rank == 0 else None,
     }
+    if world > 1:
+        res["multi_gpu"] = {**exchange.report(), "per_rank_windows_per_s": per_rank, "ranks": world,
+                            "gather_every_steps": GATHER_EVERY}
 
     # ---- host-inclusive leg (H2D + kernels + D2H), N = 1 ----
     if world == 1 and not args.no_host_leg:
@@ -231,6 +269,24 @@ def run_workload(name, args, rank, world, local):
             hl["batch_1000"]["sync_call"] = {"value": bref * k / el_sync, "ms_per_call": 1e3 * el_sync / k,
                                              "frac_of_device_resident": el_dev / el_sync,
                                              "path": "model.predict_numpy = _hip_predict = c3_predict: one blocking call per batch"}
+            # what the UNMODIFIED reference loop gets after callvar.install(): its batch generator rebound to
+            # worker.lookahead_batches (batches submitted two ahead) and one _torch_predict (= predict._hip_predict) per batch
+            from clair3_amd import predict as c3predict, worker as c3worker
+
+            def loop(n_batches):
+                gen = c3worker.lookahead_batches(model, ((xb[:], None, None) for _ in range(n_batches)), c3predict._PENDING, depth=2)
+                for X, _, _ in gen:  # clair3/CallVariantsFromCffi.py:308-317
+                    yy = c3predict._hip_predict(model, None, X)
+                return yy
+            loop(3)
+            t0 = time.perf_counter()
+            y = loop(k)
+            el_loop = time.perf_counter() - t0
+            assert y.shape[0] == bref and np.isfinite(y).all()
+            hl["batch_1000"]["dropin_loop"] = {"value": bref * k / el_loop, "ms_per_call": 1e3 * el_loop / k,
+                                               "frac_of_device_resident": el_dev / el_loop,
+                                               "path": "callvar.install(): tensor_generator_for_chunk -> worker.lookahead_batches (2 ahead), "
+                                                       "one blocking _torch_predict per batch = wait for rows already in flight"}
             # every handle of the device-resident headline fed from the host: batch i on handle i % S, two submits in flight each
             if len(models) > 1:
                 el3, y = host_leg(models, xb, k, 3, slots=2)
@@ -251,6 +307,8 @@ def run_workload(name, args, rank, world, local):
                 hl["batch_1000_registered_source"] = {"error": repr(e)}
         res["host_inclusive"] = hl
 
+    if args.no_profiled_pass:
+        return res
     # ---- profiled pass: HIP events around every kernel launch on the launch stream ----
     model.profile(True)
     model.profile_reset()
@@ -301,6 +359,9 @@ def run_workload(name, args, rank, world, local):
         "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
         "share_of_step_time": ms / max(sum(r["total_ms"] for r in stats), 1e-9),
         "step_us_sum_of_kernels": 1e3 * step_ms_profiled,
+        "kernel_us_per_step": 1e3 * ms / max(args.steps, 1),  # the dominant family's kernels alone: <= ms_per_step of one batch in flight
+        "step_us_one_batch_in_flight": 1e3 * res["one_batch_in_flight"]["ms_per_step"],
+        "kernel_variants": describe(model),
         "whole_forward_frac": res["value"] / world * flop_w / (peak * 1e12),
         "whole_forward_frac_one_in_flight": res["one_batch_in_flight"]["value"] / world * flop_w / (peak * 1e12),
         "algorithmic_bytes_per_window": bytes_w,
@@ -312,32 +373,131 @@ def run_workload(name, args, rank, world, local):
     return res
 
 
+def staged_reference():
+    """The reference's own modules for the CPU baseline: oracle/_ref (staged by oracle/stage_reference.py, travels with the
+    snapshot) or $CLAIR3_REFERENCE.  /root/reference itself is never read by the bench."""
+    for cand in (os.environ.get("CLAIR3_REFERENCE"), os.path.join(ROOT, "oracle", "_ref")):
+        if cand and os.path.isfile(os.path.join(cand, "clair3", "model.py")):
+            return cand
+    return None
+
+
 def cpu_worker(name, threads, budget_s, batch, rows_path):
-    """One clean process per thread count (OMP_NUM_THREADS is set by the parent): times the reference CPU
-    arithmetic on the same synthetic batch and prints one JSON line."""
+    """One clean process per thread count (OMP_NUM_THREADS is set by the parent): times the reference CPU path on the same
+    synthetic batch and prints one JSON line.  kind "reference": the reference's own modules and model call
+    (clair3/model.py Clair3_P / Clair3_F in eval(), clair3/CallVariantsFromCffi.py:48-52 _torch_predict) from the staged
+    copy; kind "port" (no staged copy): oracle/torch_port.py, the same ATen operators restated."""
     import torch
     from clair3_amd import synthetic as syn
-    from oracle import torch_port
     kind, b, channels, indel, _, _, _ = WORKLOADS[name]
     b = batch or b
     torch.set_num_threads(threads)
-    sd = torch_port.to_torch(syn.make_state_dict(kind, channels, indel, seed=0))
-    x = torch.from_numpy(syn.make_windows(kind, b, seed=1000, channels=channels))
+    sd_np = syn.make_state_dict(kind, channels, indel, seed=0)
+    x = syn.make_windows(kind, b, seed=1000, channels=channels)
     if threads == 1:
         x = x[: max(8, b // 8)]  # one thread: a bounded slice of the batch (rate per window is what is reported)
-    kw = {"lstms": torch_port.make_lstms(sd)} if kind == "pileup" else {}
-    torch_port.forward(kind, sd, x[: max(1, len(x) // 4)], indel, **kw)  # warm-up
+    ref = staged_reference() if not os.environ.get("C3_BENCH_CPU_PORT") else None
+    how = "port"
+    if ref:
+        try:
+            sys.path.insert(0, ref)
+            from clair3.model import Clair3_F, Clair3_P
+            m = (Clair3_P if kind == "pileup" else Clair3_F)(add_indel_length=indel, predict=True, input_channels=channels)
+            m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})  # strict, as :28
+            m.eval()
+            device = torch.device("cpu")
+
+            def _torch_predict(model, device, X):  # clair3/CallVariantsFromCffi.py:48-52, the call being replaced
+                with torch.inference_mode():
+                    X_tensor = torch.from_numpy(X).to(device)
+                    Y = model(X_tensor)
+                return Y.detach().cpu().numpy()
+            run = lambda xs: _torch_predict(m, device, xs)
+            how = "reference"
+        except Exception as e:
+            print(f"[bench] staged reference unusable ({e!r}); timing the port", file=sys.stderr)
+    if how == "port":
+        from oracle import torch_port
+        sd = torch_port.to_torch(sd_np)
+        kw = {"lstms": torch_port.make_lstms(sd)} if kind == "pileup" else {}
+        run = lambda xs: torch_port.forward(kind, sd, torch.from_numpy(xs), indel, **kw)
+    run(np.ascontiguousarray(x[: max(1, len(x) // 4)]))  # warm-up
     times = []
     y = None
     t_start = time.perf_counter()
     while len(times) < 5 and (time.perf_counter() - t_start < budget_s or not times):
         t0 = time.perf_counter()
-        y = torch_port.forward(kind, sd, x, indel, **kw)
+        y = run(x)
         times.append(time.perf_counter() - t0)
     if rows_path and rows_path != "-":
         np.save(rows_path, np.asarray(y, dtype=np.float32))
     print(json.dumps({"threads": threads, "batch": int(len(x)), "reps": len(times), "median_s": float(np.median(times)),
-                      "torch": torch.__version__}), flush=True)
+                      "torch": torch.__version__, "kind": how}), flush=True)
+
+
+def ref_gpu_worker(name, budget_s, batch):
+    """The reference AS IT IS on this GPU: its own modules (staged copy) moved to the device by PyTorch-ROCm and called the way
+    its worker does (clair3/CallVariantsFromCffi.py:48-52: H2D, forward through ATen / MIOpen / rocBLAS, D2H per batch) -- what
+    `--use_gpu` gives a user of the reference on an MI355X today.  Prints one JSON line."""
+    import torch
+    from clair3_amd import synthetic as syn
+    kind, b, channels, indel, _, _, _ = WORKLOADS[name]
+    ref = staged_reference()
+    if not ref or not torch.cuda.is_available():
+        print(json.dumps({"error": "no staged reference or no GPU"}))
+        return
+    sys.path.insert(0, ref)
+    from clair3.model import Clair3_F, Clair3_P
+    device = torch.device("cuda")
+    m = (Clair3_P if kind == "pileup" else Clair3_F)(add_indel_length=indel, predict=True, input_channels=channels)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_state_dict(kind, channels, indel, seed=0).items()})
+    m.to(device)
+    m.eval()
+
+    def _torch_predict(model, device, X):  # clair3/CallVariantsFromCffi.py:48-52
+        with torch.inference_mode():
+            X_tensor = torch.from_numpy(X).to(device)
+            Y = model(X_tensor)
+        return Y.detach().cpu().numpy()
+    out = {"torch": torch.__version__}
+    for bb in sorted({batch or b, 1000}):
+        x = syn.make_windows(kind, bb, seed=1000, channels=channels)
+        t0 = time.perf_counter()
+        y = _torch_predict(m, device, x)  # first call: MIOpen / rocBLAS kernel selection
+        first = time.perf_counter() - t0
+        _torch_predict(m, device, x)
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 20 and (time.perf_counter() - t_start < budget_s / 2 or len(times) < 3):
+            t0 = time.perf_counter()
+            y = _torch_predict(m, device, x)
+            times.append(time.perf_counter() - t0)
+        out[f"batch_{bb}"] = {"value": bb / float(np.median(times)), "ms_per_call": 1e3 * float(np.median(times)), "calls": len(times),
+                              "first_call_s": first, "finite": bool(np.isfinite(y).all())}
+    print(json.dumps(out), flush=True)
+
+
+def reference_gpu(name, budget_s, r):
+    """rank 0, N = 1: run ref_gpu_worker in its own process (bounded; a failure only costs this entry)"""
+    import subprocess
+    if not staged_reference():
+        return None
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--ref-gpu-worker", name, str(budget_s), "0"],
+                           capture_output=True, text=True, timeout=budget_s * 4 + 240)
+        got = json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+    if "error" in got:
+        return got
+    got["what"] = ("the reference's own clair3/model.py modules on this MI355X through PyTorch-ROCm (ATen / MIOpen / rocBLAS), one blocking "
+                   "_torch_predict per batch as its GPU loop does (clair3/CallVariantsFromCffi.py:48-52,317) -- the path libc3hip replaces")
+    mine = r.get("host_inclusive", {}).get("batch_1000", {})
+    if "batch_1000" in got and mine.get("sync_call"):
+        got["libc3hip_blocking_call_speedup_at_batch_1000"] = mine["sync_call"]["value"] / got["batch_1000"]["value"]
+        if mine.get("dropin_loop"):
+            got["libc3hip_dropin_loop_speedup_at_batch_1000"] = mine["dropin_loop"]["value"] / got["batch_1000"]["value"]
+    return got
 
 
 def cpu_baseline(name, budget_s, batch, gpu_rows):
@@ -380,9 +540,11 @@ def cpu_baseline(name, budget_s, batch, gpu_rows):
     rate = lambda r: r["batch"] / r["median_s"]
     best = max(runs, key=rate)
     one = next((r for r in runs if r["threads"] == 1), None)
-    out = {"value": rate(best), "unit": "candidate-windows/s", "cores": best["threads"], "kind": "port",
-           "sample": f"{best['reps']} x one batch of {best['batch']} windows, median, own process; oracle/torch_port.py = "
-                     f"the ATen/oneDNN operators the reference modules call; in-process rates by thread count "
+    kind = "reference" if all(r.get("kind") == "reference" for r in runs) else "port"
+    what = ("the reference's own clair3/model.py module in eval() called as clair3/CallVariantsFromCffi.py:48-52 _torch_predict does "
+            "(staged copy oracle/_ref)") if kind == "reference" else "oracle/torch_port.py = the ATen/oneDNN operators the reference modules call"
+    out = {"value": rate(best), "unit": "candidate-windows/s", "cores": best["threads"], "kind": kind,
+           "sample": f"{best['reps']} x one batch of {best['batch']} windows, median, own process; {what}; in-process rates by thread count "
                      f"{ {r['threads']: round(rate(r)) for r in runs} } windows/s on {cores} visible cores; torch {best['torch']}",
            "ms_per_batch": 1e3 * best["median_s"], "host_cores_visible": cores, "cpu_quota_cores": quota}
     if one:
@@ -399,7 +561,8 @@ def cpu_baseline(name, budget_s, batch, gpu_rows):
         if y_cpu.shape == gpu_rows.shape:
             heads = {"gt21": (0, 21), "zygosity": (21, 24)}
             conc = {"windows": int(len(y_cpu)), "max_abs_dy": float(np.abs(y_cpu.astype(np.float64) - gpu_rows).max()),
-                    "vs": "cpu_baseline rows (oracle/torch_port.py, pinned to the reference's goldens at 2e-6) on the same batch"}
+                    "vs": "cpu_baseline rows on the same batch (" + ("the reference's own modules" if kind == "reference" else
+                                                                      "oracle/torch_port.py, pinned to the reference's goldens at 2e-6") + ")"}
             for k, (lo, hi) in heads.items():
                 a, b = gpu_rows[:, lo:hi].argmax(1), y_cpu[:, lo:hi].argmax(1)
                 top2 = np.sort(y_cpu[:, lo:hi], axis=1)[:, -2:]
@@ -421,11 +584,20 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--no-profiled-pass", action="store_true", help="skip the HIP-event pass (for rocprofv3 runs of one leg)")
+    ap.add_argument("--no-reference-gpu", action="store_true", help="skip the leg that times the reference's own modules on the GPU through PyTorch-ROCm")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of K steps each; value = the median block")
+    ap.add_argument("--gather-timeout", type=float, default=20.0, help="seconds RCCL's rendezvous / first gather may take before the rows go through torch.distributed (N > 1)")
+    ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather through torch.distributed from the start")
+    ap.add_argument("--ref-gpu-worker", nargs=3, metavar=("WORKLOAD", "BUDGET", "BATCH"), help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker", nargs=5, metavar=("WORKLOAD", "THREADS", "BUDGET", "BATCH", "ROWS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         cpu_worker(args.cpu_worker[0], int(args.cpu_worker[1]), float(args.cpu_worker[2]), int(args.cpu_worker[3]),
                    args.cpu_worker[4])
+        return
+    if args.ref_gpu_worker:
+        ref_gpu_worker(args.ref_gpu_worker[0], float(args.ref_gpu_worker[1]), int(args.ref_gpu_worker[2]))
         return
 
     from clair3_amd import dist as c3dist
@@ -447,10 +619,15 @@ def main():
                    "batches_in_flight": r["batches_in_flight"], "one_batch_in_flight": r["one_batch_in_flight"],
                    **{k: v for k, v in r.items() if k.endswith("_batches_in_flight") and k != "one_batch_in_flight"},
                    "config": {"workload": r["workload"], "batch_per_gpu": r["batch_per_gpu"]},
-                   "range_flag_raised": r["range_flag_raised"], "on_fp32_fallback": r["on_fp32_fallback"],
-                   "roofline": r["roofline"], "kernels": r["kernels"]}
+                   "value_stats": r["value_stats"], "kernel_variants": r["kernel_variants"],
+                   "range_flag_raised": r["range_flag_raised"], "on_fp32_fallback": r["on_fp32_fallback"]}
+            for key in ("roofline", "kernels", "multi_gpu"):
+                if key in r:
+                    sub[key] = r[key]
             if "host_inclusive" in r:
                 sub["host_inclusive"] = r["host_inclusive"]
+            if world == 1 and not args.no_reference_gpu and budget > 0:
+                sub["reference_on_this_gpu"] = reference_gpu(n, min(budget, 15.0), r)
             if world == 1 and not args.no_cpu_baseline and budget > 0:
                 sub["cpu_baseline"], sub["gt_concordance"] = cpu_baseline(n, budget, args.batch, rows)
                 if sub["cpu_baseline"]:
@@ -464,12 +641,12 @@ def main():
         h = sub_line(names[0], head, args.cpu_budget)
         line = {
             "metric": "candidate-windows/sec", "value": h["value"], "unit": "candidate-windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats, "ms_per_step": h["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32(fp16x3)", "data": "synthetic",
             "dtype_note": "fp32 storage, accumulation and results; every fp32 product formed from two fp16 pieces per operand (three 16-bit MFMA products, DESIGN.md 1)",
             "config": {"workload": head["workload"], "batch_per_gpu": head["batch_per_gpu"],
                        "windows_per_step": head["windows_per_step"], "weights": "seeded random (no checkpoints offline)",
-                       "sharding": f"windows x{world}, rows gathered to rank 0 every {GATHER_EVERY} steps (one RCCL gather)" if world > 1 else "single GPU",
+                       "sharding": f"windows x{world}, rows gathered to rank 0 every {GATHER_EVERY} steps (one gather: {head.get('multi_gpu', {}).get('gather')})" if world > 1 else "single GPU",
                        "inputs": "resident in HBM before the timed region (host-to-host rate: host_inclusive)", "batches_in_flight": head["batches_in_flight"]},
             **{k: v for k, v in h.items() if k not in ("value", "unit", "ms_per_step", "config", "batches_in_flight")},
         }

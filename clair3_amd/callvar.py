@@ -4,7 +4,9 @@
 model call of the GPU path -- nothing else of the pipeline is touched:
 
   clair3.CallVariantsFromCffi   _torch_predict (:48-52), _load_torch_checkpoint (:19-28), _select_device (:31-34),
-                                _limit_gpu_memory (:37-45, a CUDA-caching-allocator knob: no-op here)
+                                _limit_gpu_memory (:37-45, a CUDA-caching-allocator knob: no-op here),
+                                tensor_generator_for_chunk (:106-148; GPU branch with tensor files only: same batches,
+                                submitted to the GPU two ahead of the loop -- see _make_batch_generator)
   clair3.model                  Clair3_P (:58), Clair3_F (:282)  -- imported lazily by the worker at :230/:239
   clair3.CallVariantsFromCffiGPU get_gpu_memory (:13-19), check_gpu_memory (:21-43)  (nvidia-smi -> hipMemGetInfo)
 
@@ -17,6 +19,7 @@ pass in libc3hip.  ``sitecustomize``-style use:
 
 or add the two lines shown in INTEGRATION.md to clair3.py.
 """
+import os
 import sys
 
 from . import _lib, predict
@@ -45,6 +48,36 @@ def _check_gpu_memory_or_exit(memory, device_ids=None, print_log=True):
         sys.exit(1)
 
 
+def _make_batch_generator(original):
+    """tensor_generator_for_chunk (clair3/CallVariantsFromCffi.py:106-148) for the GPU branch: the same batches in the same
+    order from the same ``--output_tensor_can_fn_list`` files, but memory-mapped and submitted to the GPU ``PREFETCH_DEPTH``
+    batches ahead of the loop (clair3_amd/worker.py), so that the loop's one blocking ``_torch_predict`` per batch finds its
+    rows computed -- the unmodified loop then runs at the rate of the submit / wait ring instead of H2D -> forward -> D2H
+    in sequence.  Every other use (in-process tensors, no model loaded through the rebound loader, CPU) is the
+    reference's own generator."""
+    from . import worker as transport
+
+    def tensor_generator_for_chunk(gen_cls, args, batch_size=50):
+        model = predict.current_model()
+        if (getattr(args, "output_tensor_can_fn_list", None) is None or not getattr(args, "use_gpu", False)
+                or model is None or PREFETCH_DEPTH <= 0):
+            yield from original(gen_cls, args, batch_size=batch_size)
+            return
+        want = bool(predict.DECODER_COLUMNS and model.add_indel_length)
+        if want != model._decode_cols:
+            model.decode_columns(want)
+        yield from transport.lookahead_batches(model, transport.iter_batches(args.output_tensor_can_fn_list, batch_size),
+                                               predict._PENDING, depth=PREFETCH_DEPTH)
+
+    tensor_generator_for_chunk._c3hip_original = original
+    return tensor_generator_for_chunk
+
+
+# batches the rebound generator keeps submitted ahead of the reference loop (0 = the reference's generator, one blocking
+# c3_predict per batch); env C3HIP_PREFETCH_DEPTH
+PREFETCH_DEPTH = int(os.environ.get("C3HIP_PREFETCH_DEPTH", "2"))
+
+
 def install(worker=True, gpu_wrapper=True, decoder=False):
     """Patch the imported (or importable) reference modules in place.  Returns the list of rebound names.
     decoder=True additionally makes the full-alignment rows carry the decoder columns of libc3hip and
@@ -60,8 +93,11 @@ def install(worker=True, gpu_wrapper=True, decoder=False):
         w._load_torch_checkpoint = predict._load_torch_checkpoint
         w._select_device = _select_device_for_worker
         w._limit_gpu_memory = _limit_gpu_memory
+        if not hasattr(w.tensor_generator_for_chunk, "_c3hip_original"):
+            w.tensor_generator_for_chunk = _make_batch_generator(w.tensor_generator_for_chunk)
         done += ["clair3.CallVariantsFromCffi." + n for n in
-                 ("_torch_predict", "_load_torch_checkpoint", "_select_device", "_limit_gpu_memory")]
+                 ("_torch_predict", "_load_torch_checkpoint", "_select_device", "_limit_gpu_memory",
+                  "tensor_generator_for_chunk")]
     if decoder:
         from . import decode
         if worker:

@@ -8,6 +8,7 @@
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types, enums and prototypes only: the symbols are bound with dlopen below, nothing links librccl
 #include <stdint.h>
 
 #include <string>
@@ -15,24 +16,22 @@
 
 namespace c3 {
 
-struct RcclUniqueId {  // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
-    char b[128];
-};
-
+// Function-pointer types are taken from rccl.h's own prototypes (decltype), so the by-value 128-byte ncclUniqueId, the
+// ncclDataType_t numbering and every argument list are the header's, not a transcription of it.
 struct RcclApi {
-    typedef int (*GetUniqueId_t)(RcclUniqueId *id);
-    typedef int (*CommInitRank_t)(void **comm, int nranks, RcclUniqueId id, int rank);
-    typedef int (*CommDestroy_t)(void *comm);
-    typedef int (*Group_t)(void);
-    typedef int (*SendRecv_t)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream);
-    typedef const char *(*ErrorString_t)(int);
     void *handle = nullptr;
-    GetUniqueId_t GetUniqueId = nullptr;
-    CommInitRank_t CommInitRank = nullptr;
-    CommDestroy_t CommDestroy = nullptr;
-    Group_t GroupStart = nullptr, GroupEnd = nullptr;
-    SendRecv_t Send = nullptr, Recv = nullptr;
-    ErrorString_t GetErrorString = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
 
     static RcclApi &get() {
@@ -43,30 +42,40 @@ struct RcclApi {
         if (handle) return true;
         const char *names[] = {getenv("C3HIP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
         // first: a copy that is already in the process (PyTorch's), then the system one
+        const char *why = nullptr;
         for (int pass = 0; pass < 2 && !handle; ++pass)
             for (const char *n : names) {
                 if (!n) continue;
                 handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
                 if (handle) break;
+                if (pass == 1) {
+                    const char *e = dlerror();  // reading it clears it: once per failure
+                    if (e && !why) why = e;
+                }
             }
         if (!handle) {
-            error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+            error = std::string("cannot load librccl: ") + (why ? why : "not found");
             return false;
         }
+        bool ok = true;
         auto sym = [&](const char *s) -> void * {
             void *p = dlsym(handle, s);
-            if (!p) error = std::string("librccl has no symbol ") + s;
+            if (!p) error = std::string("librccl has no symbol ") + s, ok = false;
             return p;
         };
-        GetUniqueId = (GetUniqueId_t)sym("ncclGetUniqueId");
-        CommInitRank = (CommInitRank_t)sym("ncclCommInitRank");
-        CommDestroy = (CommDestroy_t)sym("ncclCommDestroy");
-        GroupStart = (Group_t)sym("ncclGroupStart");
-        GroupEnd = (Group_t)sym("ncclGroupEnd");
-        Send = (SendRecv_t)sym("ncclSend");
-        Recv = (SendRecv_t)sym("ncclRecv");
-        GetErrorString = (ErrorString_t)sym("ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
+        CommCount = (decltype(CommCount))sym("ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))sym("ncclCommUserRank");
+        CommGetAsyncError = (decltype(CommGetAsyncError))sym("ncclCommGetAsyncError");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!ok) {
             handle = nullptr;
             return false;
         }
@@ -74,11 +83,9 @@ struct RcclApi {
     }
 };
 
-constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h)
-
 }  // namespace c3
 
 struct c3_comm {
-    void *nccl = nullptr;  // ncclComm_t, null when world == 1
+    ncclComm_t nccl = nullptr;  // null when world == 1
     int rank = 0, world = 1, device = 0;
 };

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <chrono>
 #include <mutex>
@@ -73,8 +74,8 @@ static bool is_registered(const void *p, size_t n) {
 }
 
 // stage [src, src + bytes) through `pin` into `dev` on stream s, piecewise
-static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s) {
-    if (is_registered(src, bytes)) {  // zero-copy: the DMA engine reads the caller's pages
+static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s, bool src_locked = false) {
+    if (src_locked || is_registered(src, bytes)) {  // zero-copy: the DMA engine reads the caller's pages
         HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, s));
         return 0;
     }
@@ -238,6 +239,9 @@ struct c3_model {
     int64_t last_n = 0;  // windows of the last micro-batch (for debug fetch)
 
     HostSlot slot[kHostSlots];
+
+    // which of the bit-identical kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
+    const char *choice_lstm1 = "-", *choice_proj2 = "-", *choice_lstm2 = "-", *choice_fa = "-";
 
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -1145,7 +1149,11 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
 }
 
 static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float *y) {
-    if (fa_planes_ok(m)) return run_fa_planes(m, s, x, n, y);
+    if (fa_planes_ok(m)) {
+        m->choice_fa = "planes-f16x3";
+        return run_fa_planes(m, s, x, n, y);
+    }
+    m->choice_fa = m->f16_ok ? "fp32-activations-winograd-f16x3" : "fp32-activations-fp32-mfma";
     m->last_planes = false;
     int hh[10], ww[10];
     fa_geometry(m, hh, ww);
@@ -1325,6 +1333,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             const bool half1 = want_half && (m->lstm_opt & 1) && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 2 &&
                                !(m->lstm_trace_left > 0);
             if constexpr (sizeof(T) == 1) {
+                m->choice_lstm1 = half1 ? "fused-f16x3-half-tiles" : "fused-f16x3-full-tiles";
                 if (half1) {
                     grid = dim3((unsigned)((n + 7) / 8), 2);
                     hipLaunchKernelGGL((lstm1_fused_kernel<T, true, 7>), grid, dim3(512), 0, s, lp);
@@ -1406,12 +1415,14 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
                 if (m->adaptive && m->concurrent) wp.lanes_per_xcd = std::max(1, wp.lanes_per_xcd / 2);
                 static const int env_lanes = getenv("C3HIP_WRES_LANES") ? atoi(getenv("C3HIP_WRES_LANES")) : 0;  // A/B
                 if (env_lanes > 0) wp.lanes_per_xcd = env_lanes;
+                m->choice_proj2 = wp.lanes_per_xcd >= std::max(1, m->wg_slots / 16 / wp.tiles_n) ? "weights-resident" : "weights-resident-half-grid";
                 hipLaunchKernelGGL(dense_planes_wres_kernel<0>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
             } else
             if ((m->dense_mode == 5 || (m->adaptive && m->dense_mode == 3 && m->concurrent)) && m->proj2_pw32) {
                 DenseBigParams bp;
                 bp.a = m->h1, bp.w = m->proj2_pw32, bp.bias = m->proj_b[1], bp.c = m->gx2, bp.post_scale = 1.f / m->proj2_pwscale;
                 bp.M = M, bp.N = 1280, bp.K = 256, bp.tiles_n = 1280 / kBgBN, bp.tiles = ((M + kBgBM - 1) / kBgBM) * bp.tiles_n;
+                m->choice_proj2 = "256x256-tiles";
                 hipLaunchKernelGGL(dense_planes_big_kernel, dim3(std::min(bp.tiles, m->wg_slots / 2)), dim3(kDnThreads), 0, s, bp);
             } else
             if (m->dense_mode == 4) hipLaunchKernelGGL(dense_planes_ws_kernel<false>, dim3(grid), dim3(kWsThreads), 0, s, dp);
@@ -1471,8 +1482,10 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
                     hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true, 8>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
                     HIP_TRY(lstm_trace_print(m, s, "lstm2", Tn, "top -> matrix instructions issued -> gates exchanged -> cell + h written -> barrier -> next top"));
                 } else if (half2) {
+                    m->choice_lstm2 = "f16x3-half-tiles";
                     hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true, 4>), dim3((unsigned)((n + 7) / 8), 2), dim3(512), 0, s, lp);
                 } else {
+                    m->choice_lstm2 = "f16x3-full-tiles";
                     hipLaunchKernelGGL((lstm_recurrent_kernel_v2<160, true>), dim3((unsigned)((n + 15) / 16), 2), dim3(512), 0, s, lp);
                 }
             } else {
@@ -1810,7 +1823,13 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     return 0;
 }
 
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked);
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
+    return predict_submit(m, x_host, x_dtype, batch, y_host, slot, false);
+}
+// src_locked: the caller (c3_predict) has page-locked x_host for the duration of ITS call -- a private fact of that call, not
+// published in g_registered, so no other thread or handle ever DMAs from pages that are about to be unlocked
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked) {
     if (!m) return fail("null model");
     if (slot < 0 || slot >= kHostSlots) return fail("slot must be in [0, %d)", kHostSlots);
     if (batch < 0) return fail("negative batch");
@@ -1824,7 +1843,7 @@ int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batc
     if (batch > 0) {
         // the slot becomes busy only once everything has been queued: a failure on the way leaves it free
         TRY(ensure_slot(m, sl, xb, yb));
-        TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream));
+        TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream, src_locked));
         HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
         const bool f16 = m->f16_ok;
@@ -1901,8 +1920,6 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
         (void)hipSetDevice(m->device);
         if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
             reg_base = (void *)lo;
-            std::lock_guard<std::mutex> lk(g_registered_mu);
-            g_registered.push_back({(const char *)lo, (size_t)(hi - lo)});
         } else {
             (void)hipGetLastError();  // not fatal: staged copy
         }
@@ -1919,7 +1936,8 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
         take = std::min(take, max_microbatch(m));
         if (n_sub - n_done == kRing) rc = c3_predict_wait(m, (int)(n_done++ % kRing));
         if (rc == 0)
-            rc = c3_predict_submit(m, (const char *)x_host + off * wbytes, x_dtype, take, y_host + off * m->row, (int)(n_sub % kRing));
+            rc = predict_submit(m, (const char *)x_host + off * wbytes, x_dtype, take, y_host + off * m->row, (int)(n_sub % kRing),
+                                reg_base != nullptr);
         if (rc != 0) break;
         off += take;
         next = std::min(2 * next, 4 * chunk);
@@ -1929,17 +1947,7 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
         const int r = c3_predict_wait(m, (int)(n_done % kRing));
         if (rc == 0) rc = r;
     }
-    if (reg_base) {
-        {
-            std::lock_guard<std::mutex> lk(g_registered_mu);
-            for (size_t i = 0; i < g_registered.size(); ++i)
-                if (g_registered[i].p == (const char *)reg_base) {
-                    g_registered.erase(g_registered.begin() + i);
-                    break;
-                }
-        }
-        (void)hipHostUnregister(reg_base);
-    }
+    if (reg_base) (void)hipHostUnregister(reg_base);  // every chunk has been waited for: nothing reads the pages any more
     if (!first_error.empty()) g_err = first_error;
     return rc;
 }
@@ -2052,10 +2060,11 @@ int c3_comm_unique_id(void *id128) {
     if (!id128) return fail("null buffer");
     RcclApi &r = RcclApi::get();
     if (!r.load()) return fail("%s", r.error.c_str());
-    RcclUniqueId id;
-    const int rc = r.GetUniqueId(&id);
-    if (rc) return fail("ncclGetUniqueId failed: %s", r.GetErrorString(rc));
-    memcpy(id128, id.b, 128);
+    static_assert(sizeof(ncclUniqueId) == 128, "c3_comm_unique_id hands out 128 bytes");
+    ncclUniqueId id;
+    const ncclResult_t rc = r.GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail("ncclGetUniqueId failed: %s", r.GetErrorString(rc));
+    memcpy(id128, &id, 128);
     return 0;
 }
 
@@ -2082,10 +2091,10 @@ c3_comm *c3_comm_create(const void *id128, int rank, int world, int device) {
         delete c;
         return nullptr;
     }
-    RcclUniqueId id;
-    memcpy(id.b, id128, 128);
-    const int rc = r.CommInitRank(&c->nccl, world, id, rank);
-    if (rc) {
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    const ncclResult_t rc = r.CommInitRank(&c->nccl, world, id, rank);
+    if (rc != ncclSuccess) {
         fail("ncclCommInitRank failed: %s", r.GetErrorString(rc));
         delete c;
         return nullptr;
@@ -2115,8 +2124,8 @@ int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int6
         return 0;
     }
     RcclApi &r = RcclApi::get();
-    int rc = r.GroupStart();
-    if (rc) return fail("ncclGroupStart failed: %s", r.GetErrorString(rc));
+    int rc = (int)r.GroupStart();
+    if (rc) return fail("ncclGroupStart failed: %s", r.GetErrorString((ncclResult_t)rc));
     if (c->rank == dst) {
         size_t off = 0;
         for (int src = 0; src < c->world && !rc; ++src) {
@@ -2127,18 +2136,65 @@ int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int6
                     if (e != hipSuccess) rc = -1;
                 }
             } else if (n) {
-                rc = r.Recv(all_dev + off, n, kNcclFloat, src, c->nccl, s);
+                rc = (int)r.Recv(all_dev + off, n, ncclFloat32, src, c->nccl, s);
             }
             off += n;
         }
     } else if (mine) {
-        rc = r.Send(const_cast<float *>(rows_dev), mine, kNcclFloat, dst, c->nccl, s);
+        rc = (int)r.Send(rows_dev, mine, ncclFloat32, dst, c->nccl, s);
     }
-    const int rc2 = r.GroupEnd();
-    if (rc > 0) return fail("ncclSend/ncclRecv failed: %s", r.GetErrorString(rc));
+    const ncclResult_t rc2 = r.GroupEnd();
+    if (rc > 0) return fail("ncclSend/ncclRecv failed: %s", r.GetErrorString((ncclResult_t)rc));
     if (rc < 0) return fail("device copy inside the gather failed");
-    if (rc2) return fail("ncclGroupEnd failed: %s", r.GetErrorString(rc2));
+    if (rc2 != ncclSuccess) return fail("ncclGroupEnd failed: %s", r.GetErrorString(rc2));
     return 0;
+}
+
+int c3_comm_count(c3_comm *c, int *ranks_out, int *rank_out) {
+    if (!c || !ranks_out) return fail("null argument");
+    if (!c->nccl) {  // world == 1: no communicator
+        *ranks_out = c->world;
+        if (rank_out) *rank_out = c->rank;
+        return 0;
+    }
+    RcclApi &r = RcclApi::get();
+    ncclResult_t rc = r.CommCount(c->nccl, ranks_out);
+    if (rc != ncclSuccess) return fail("ncclCommCount failed: %s", r.GetErrorString(rc));
+    if (rank_out) {
+        rc = r.CommUserRank(c->nccl, rank_out);
+        if (rc != ncclSuccess) return fail("ncclCommUserRank failed: %s", r.GetErrorString(rc));
+    }
+    return 0;
+}
+
+int c3_comm_abort(c3_comm *c) {
+    if (!c) return 0;
+    if (c->nccl) {
+        RcclApi &r = RcclApi::get();
+        const ncclResult_t rc = r.CommAbort(c->nccl);
+        c->nccl = nullptr;
+        c->world = 1;  // whatever is asked of this handle from now on is local
+        if (rc != ncclSuccess) return fail("ncclCommAbort failed: %s", r.GetErrorString(rc));
+    }
+    return 0;
+}
+
+int c3_stream_wait(void *stream, int device, int timeout_ms) {
+    HIP_TRY(hipSetDevice(device));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery((hipStream_t)stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail("hipStreamQuery: %s", hipGetErrorString(e));
+        if (timeout_ms >= 0 &&
+            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) {
+            (void)hipGetLastError();
+            g_err = "timeout";
+            return 1;
+        }
+        struct timespec ts = {0, 50000};  // 50 us
+        nanosleep(&ts, nullptr);
+    }
 }
 
 int c3_host_register(void *p, size_t bytes) {
@@ -2162,6 +2218,17 @@ int c3_host_unregister(void *p) {
         if (!found) return fail("buffer was not registered with c3_host_register");
     }
     HIP_TRY(hipHostUnregister(p));
+    return 0;
+}
+
+int c3_model_describe(c3_model *m, char *buf, int n) {
+    if (!m || !buf || n <= 0) return fail("null argument");
+    if (m->kind == C3_KIND_PILEUP)
+        snprintf(buf, (size_t)n, "other_handles_active=%d lstm1=%s proj2=%s lstm2=%s on_fp32_fallback=%d", (int)m->concurrent,
+                 m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok);
+    else
+        snprintf(buf, (size_t)n, "other_handles_active=%d conv_stack=%s on_fp32_fallback=%d", (int)m->concurrent, m->choice_fa,
+                 (int)!m->f16_ok);
     return 0;
 }
 

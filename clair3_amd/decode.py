@@ -95,6 +95,14 @@ def decode_columns(model, y):
     return rows
 
 
+# reference base -> A/C/G/T index exactly as output_from resolves it (clair3/CallVariants.py:690: BASE2ACGT[...] =
+# shared/utils.py:42-45 IUPAC_base_to_ACGT_base_dict, upper-case keys only -- a lower-case base is a KeyError there, an
+# error here): U -> T, R/W/M/D/H/V/N -> A, Y/S/B -> C, K -> G
+_REF_BASE_INDEX = np.full(256, -1, np.int8)
+for _b, _t in zip("ACGTURYSWKMBDHVN", "ACGTTACCAGACAAAA"):
+    _REF_BASE_INDEX[ord(_b)] = "ACGT".index(_t)
+
+
 def first_decisions(rows, ref_bases, output_size):
     """Vectorised read-out of the decoder columns for rows whose reference base IS known (the worker knows it from the
     .info position string): what output_from (clair3/CallVariants.py:722-751) decides on its first pass and what
@@ -111,9 +119,10 @@ def first_decisions(rows, ref_bases, output_size):
     if isinstance(ref_bases, (bytes, bytearray)):
         ref_bases = ref_bases.decode()
     b = np.frombuffer(ref_bases.encode(), dtype=np.uint8) if isinstance(ref_bases, str) else np.asarray(ref_bases, dtype=np.uint8)
-    base = np.zeros(256, np.int8)
-    base[[ord("A"), ord("C"), ord("G"), ord("T")]] = (0, 1, 2, 3)
-    bi = base[b].astype(np.int64)
+    bi = _REF_BASE_INDEX[b].astype(np.int64)
+    if (bi < 0).any():
+        bad = sorted({chr(v) for v in np.asarray(b)[bi < 0]})
+        raise _lib.C3Error(f"reference bases {bad} are outside the IUPAC table of shared/utils.py:42-45")
     r = np.arange(len(rows))
     cls = cols[r, 23 + bi].astype(np.int8)
     pos = np.where(cls > 0, cols[r, 13 + np.maximum(cls.astype(np.int64), 1) - 1], 0).astype(np.int32)

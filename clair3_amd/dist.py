@@ -74,8 +74,9 @@ class RowGatherer:
     other ranks) and None otherwise; ``flush()`` sends an incomplete group.  Every step must bring the same number of
     rows per rank (``rows_per_step_total`` = that number x world size)."""
 
-    def __init__(self, rows_per_step_total, every=8, dst=0):
+    def __init__(self, rows_per_step_total, every=8, dst=0, exchange=None):
         self.n_total, self.every, self.dst, self.pending = int(rows_per_step_total), int(every), dst, []
+        self.exchange = exchange  # a RowExchange: RCCL directly, torch.distributed if that does not come up; None = gather_rows
 
     def add(self, y):
         self.pending.append(y)
@@ -88,6 +89,9 @@ class RowGatherer:
         rows = torch.cat(self.pending) if len(self.pending) > 1 else self.pending[0]
         k = len(self.pending)
         self.pending = []
+        if self.exchange is not None and self.exchange.world > 1:
+            counts = [shard_range(self.n_total * k, r, self.exchange.world) for r in range(self.exchange.world)]
+            return self.exchange.gather(rows, [b - a for a, b in counts], dst=self.dst)
         return gather_rows(rows, self.n_total * k, dst=self.dst)
 
 
@@ -135,12 +139,17 @@ class RcclComm:
     """The gather on RCCL itself (c3_gather_rows: grouped ncclSend / ncclRecv on the caller's HIP stream) -- the data
     path of a sharded job touches no framework.  torch.distributed (any backend, gloo is enough) is used ONCE, as the
     control plane that carries rank 0's 128-byte unique id to the other ranks; a launcher with another store can pass
-    ``unique_id`` itself.  world == 1 needs neither RCCL nor a rendezvous."""
+    ``unique_id`` itself.  world == 1 needs neither RCCL nor a rendezvous.
 
-    def __init__(self, rank=0, world=1, device=0, unique_id=None):
+    ``create_timeout_s``: ncclCommInitRank blocks until every rank has joined; it runs on a helper thread and a rendezvous
+    that does not complete in time raises ``TimeoutError`` instead of hanging the job (RowExchange then gathers through
+    torch.distributed)."""
+
+    def __init__(self, rank=0, world=1, device=0, unique_id=None, create_timeout_s=None):
         import ctypes as C
         from . import _lib
         self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self._h = None
         idbuf = (C.c_char * 128)()
         if self.world > 1:
             if unique_id is None:
@@ -155,14 +164,38 @@ class RcclComm:
                 dist.broadcast(t, src=0)
                 unique_id = bytes(t.cpu().numpy().tobytes())
             idbuf.raw = unique_id
-        h = _lib.lib().c3_comm_create(idbuf, self.rank, self.world, self.device)
-        if not h:
-            raise _lib.C3Error(f"c3_comm_create: {_lib.last_error()}")
-        self._h = C.c_void_p(h)
+        box = {}
 
-    def gather(self, y_dev, counts, dst=0, stream=None):
+        def create():
+            box["h"] = _lib.lib().c3_comm_create(idbuf, self.rank, self.world, self.device)
+            box["err"] = _lib.last_error() if not box["h"] else ""  # thread-local: read it on the thread that failed
+
+        if create_timeout_s is None or self.world == 1:
+            create()
+        else:
+            import threading
+            th = threading.Thread(target=create, daemon=True)
+            th.start()
+            th.join(create_timeout_s)
+            if th.is_alive():
+                raise TimeoutError(f"ncclCommInitRank did not return within {create_timeout_s} s")
+        if not box.get("h"):
+            raise _lib.C3Error(f"c3_comm_create: {box.get('err')}")
+        self._h = C.c_void_p(box["h"])
+
+    def ranks_seen(self):
+        """(ranks, this rank) as RCCL reports them (ncclCommCount / ncclCommUserRank)"""
+        import ctypes as C
+        from . import _lib
+        n, r = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().c3_comm_count(self._h, C.byref(n), C.byref(r)), "c3_comm_count")
+        return n.value, r.value
+
+    def gather(self, y_dev, counts, dst=0, stream=None, timeout_s=None):
         """y_dev: this rank's (counts[rank], W) float32 CUDA tensor.  Returns the (sum(counts), W) tensor on ``dst`` (rows in
-        rank order), None elsewhere.  Asynchronous on the current stream, like any other kernel."""
+        rank order), None elsewhere.  Asynchronous on the current stream, like any other kernel -- unless ``timeout_s`` is
+        given: then the call waits for the stream (c3_stream_wait, polling hipStreamQuery) and raises ``TimeoutError`` after
+        aborting the communicator (ncclCommAbort) if the collective has not finished by then."""
         import ctypes as C
         import torch
         from . import _lib
@@ -175,6 +208,12 @@ class RcclComm:
         s = torch.cuda.current_stream(y_dev.device).cuda_stream if stream is None else stream
         _lib.check(_lib.lib().c3_gather_rows(self._h, y_dev.data_ptr(), width, cnt, out.data_ptr() if out is not None else None,
                                              dst, C.c_void_p(s)), "c3_gather_rows")
+        if timeout_s is not None:
+            rc = _lib.lib().c3_stream_wait(C.c_void_p(s), self.device, int(timeout_s * 1000))
+            if rc == 1:
+                _lib.lib().c3_comm_abort(self._h)
+                raise TimeoutError(f"c3_gather_rows did not finish within {timeout_s} s (communicator aborted)")
+            _lib.check(rc, "c3_stream_wait")
         return out
 
     def close(self):
@@ -188,3 +227,76 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+class RowExchange:
+    """The gather of a sharded job with a way out: rows travel on RCCL directly (RcclComm) as long as that works, and through
+    torch.distributed (``gather_counts``: backend "nccl" = RCCL under PyTorch on GPUs, "gloo" on CPU) from the moment it
+    does not -- a rendezvous or a first collective that does not complete within ``timeout_s`` must cost a job one timeout,
+    not its life.  The FIRST gather is the guarded one (waits for the stream, then all ranks agree through one small
+    all-reduce whether everybody got through); later gathers stay asynchronous.  ``mode`` says which path carries the rows:
+    "rccl_direct", "torch_fallback" or "single" (world of one)."""
+
+    def __init__(self, rank, world, device=0, timeout_s=20.0, direct=True):
+        self.rank, self.world, self.device, self.timeout_s = int(rank), int(world), int(device), float(timeout_s)
+        self.mode, self.comm, self.ranks_seen, self.fallback_reason, self._proven = "single", None, 1, None, False
+        if self.world == 1:
+            return
+        self.mode = "torch_fallback"
+        if direct and self._cuda_job():
+            ok, why = True, None
+            try:
+                self.comm = RcclComm(rank, world, device, create_timeout_s=self.timeout_s)
+                self.ranks_seen = self.comm.ranks_seen()[0]
+                ok = self.ranks_seen == self.world
+                why = None if ok else f"RCCL sees {self.ranks_seen} ranks, the job has {self.world}"
+            except Exception as e:  # no librccl, rendezvous timed out, ...
+                ok, why = False, repr(e)
+            if self._all_ok(ok):
+                self.mode = "rccl_direct"
+            else:
+                self.fallback_reason = why or "another rank could not create its communicator"
+                self.comm = None
+        elif direct:
+            self.fallback_reason = "rows are not on GPUs"
+
+    def _cuda_job(self):
+        import torch
+        import torch.distributed as dist
+        return torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
+    def _all_ok(self, ok):
+        """every rank learns whether EVERY rank succeeded (one 1-element all-reduce on the control plane)"""
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            t = t.cuda(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def gather(self, y, counts, dst=0):
+        """y: this rank's (counts[rank], W) float32 rows (CUDA tensor on a GPU job, host tensor under gloo).  Returns all rows
+        in rank order on ``dst``, None elsewhere."""
+        if self.world == 1:
+            return y
+        if self.mode == "rccl_direct":
+            guarded = not self._proven
+            ok, out, why = True, None, None
+            try:
+                out = self.comm.gather(y, counts, dst=dst, timeout_s=self.timeout_s if guarded else None)
+            except Exception as e:
+                ok, why = False, repr(e)
+            if guarded:
+                if self._all_ok(ok):
+                    self._proven = True
+                    return out
+                self.mode, self.fallback_reason, self.comm = "torch_fallback", why or "another rank's first gather failed", None
+            elif ok:
+                return out
+            else:
+                raise RuntimeError(f"RCCL gather failed after it had worked: {why}")
+        return gather_counts(y, counts, dst=dst)
+
+    def report(self):
+        return {"gather": self.mode, "rccl_ranks_seen": self.ranks_seen, "fallback_reason": self.fallback_reason}

@@ -8,8 +8,9 @@ writes its own VCF shard, SortVcf merges them (clair3/CallVariantsFromCffiGPU.py
     concatenation of the ranks' rows in rank order IS the reference's window order -- no sort step;
   * every rank drives its GPU with ``worker.predict_batches`` (memory-mapped files, the reference's batch boundaries, a ring of
     submit/wait slots);
-  * the (n_r, 24|90) rows meet on rank 0 in one gather: on RCCL directly (``dist.RcclComm``) when the rows are on GPUs, through
-    torch.distributed's gloo for the CPU tests.
+  * the (n_r, 24|90) rows meet on rank 0 in one gather (``dist.RowExchange``): on RCCL directly (``c3_gather_rows``) on a GPU
+    job -- through torch.distributed when RCCL's own rendezvous or first collective does not complete -- and through
+    torch.distributed's gloo in the CPU tests.
 
 ``write_synthetic_job`` produces the stand-in for a 50x ONT genome the survey describes (no BAM is available offline): N windows of
 the named shape in <= 10 000-window ``.npy`` / ``.info`` pairs plus the list file, positions numbered so that order is checkable.
@@ -74,11 +75,14 @@ def shard_files(counts, world):
     return cuts
 
 
-def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume=None):
+def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume=None, exchange=None):
     """Every rank calls this with the same list.  Returns on rank 0 a dict with the rows of the whole job in window order
     (numpy), the positions seen, and timings; on other ranks the timings only.
-    ``model``: a loaded clair3_amd model (or a pair / any object with submit/wait, see worker.predict_batches).
-    ``comm``: a dist.RcclComm for GPU rows; None -> torch.distributed (gloo) gather of host rows, or nothing for world 1."""
+    ``model``: a loaded clair3_amd model (or a list of handles / any object with submit/wait, see worker.predict_batches).
+    ``exchange``: a dist.RowExchange (RCCL directly, torch.distributed when that does not come up; made here when None);
+    ``comm``: a dist.RcclComm to use as it is (no fallback).
+    The worker ring delivers every batch's rows to the HOST (that is where the decoder runs while the job is in flight), so
+    on a GPU job the rank's rows are uploaded once more for the gather and ``gather_s`` includes that -- 360 B per window."""
     names, counts = file_window_counts(list_fn)
     cuts = shard_files(counts, world)
     mine = names[cuts[rank]:cuts[rank + 1]]
@@ -95,30 +99,38 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
     n_done = worker.predict_file_list(model, list_fn, take, batch_size=batch_size, first=cuts[rank], stop=cuts[rank + 1]) if mine else 0
     t_compute = time.perf_counter() - t0
     assert n_done == per_rank[rank]
-    width = rows[0].shape[1] if rows else None
     y_local = np.concatenate(rows) if rows else None
     out = {"rank": rank, "windows_local": n_done, "compute_s": t_compute, "files_local": len(mine), "per_rank": per_rank}
     if world == 1:
-        out.update(rows=y_local, positions=positions, gather_s=0.0, total_s=time.perf_counter() - t0)
+        out.update(rows=y_local, positions=positions, gather_s=0.0, total_s=time.perf_counter() - t0, gather="single")
         return out
     import torch
     import torch.distributed as dist
-    # every rank needs the row width even when it owns no file
-    w = torch.tensor([width or 0], dtype=torch.int64)
-    dist.all_reduce(w, op=dist.ReduceOp.MAX)
-    width = int(w.item())
+    m0 = model[0] if isinstance(model, (list, tuple)) else model
+    on_gpu = dist.get_backend() == "nccl"  # then every tensor a collective touches lives on the rank's GPU
+    device = comm.device if comm is not None else (exchange.device if exchange is not None else int(getattr(m0, "_device", 0) or 0))
+    # the row width follows from the model; a stand-in without row_size (tests) and without rows asks the other ranks
+    width = getattr(m0, "row_size", None) or (rows[0].shape[1] if rows else None)
+    if width is None:
+        w = torch.tensor([0], dtype=torch.int64, device=f"cuda:{device}" if on_gpu else "cpu")
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        width = int(w.item())
     if y_local is None:
-        y_local = np.zeros((0, width), np.float32)
+        y_local = np.zeros((0, int(width)), np.float32)
     t1 = time.perf_counter()
-    if comm is not None:
-        yd = torch.from_numpy(y_local).cuda(comm.device)
-        got = comm.gather(yd, per_rank, dst=0)
-        torch.cuda.synchronize(comm.device)
-        y_all = got.cpu().numpy() if got is not None else None
-    else:
-        got = c3dist.gather_counts(torch.from_numpy(y_local), per_rank, dst=0)
-        y_all = got.numpy() if got is not None else None
-    out.update(gather_s=time.perf_counter() - t1, total_s=time.perf_counter() - t0)
+    if comm is None and exchange is None:
+        exchange = c3dist.RowExchange(rank, world, device=device)
+    y_t = torch.from_numpy(y_local)
+    if on_gpu or comm is not None:
+        y_t = y_t.cuda(device)
+    got = comm.gather(y_t, per_rank, dst=0) if comm is not None else exchange.gather(y_t, per_rank, dst=0)
+    if y_t.is_cuda:
+        torch.cuda.synchronize(device)
+    y_all = got.cpu().numpy() if got is not None else None
+    out.update(gather_s=time.perf_counter() - t1, total_s=time.perf_counter() - t0,
+               gather="rccl_direct" if comm is not None else exchange.mode)
+    if exchange is not None:
+        out.update(exchange.report())
     if rank == 0:
         out["rows"] = y_all
     out["positions"] = positions

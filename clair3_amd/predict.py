@@ -21,6 +21,25 @@ def _load_torch_checkpoint(model, checkpoint_path, device=None):
     else:
         state_dict = checkpoint
     model.load_state_dict(state_dict)
+    _register_current(model)
+
+
+# The model the worker process is calling variants with: the reference loop creates ONE model, loads it here, and only then
+# creates its batch generator (clair3/CallVariantsFromCffi.py:246-273), so the rebound generator (callvar.install: the
+# transport of clair3_amd/worker.py behind tensor_generator_for_chunk) can find the handle it should run ahead on.
+_CURRENT_MODEL = None
+# id(X) -> (model, ticket, X) of batches the rebound generator has already submitted (worker.lookahead_batches)
+_PENDING = {}
+
+
+def _register_current(model):
+    global _CURRENT_MODEL
+    import weakref
+    _CURRENT_MODEL = weakref.ref(model) if hasattr(model, "submit") else None
+
+
+def current_model():
+    return _CURRENT_MODEL() if _CURRENT_MODEL is not None else None
 
 
 def _select_device(use_gpu=True):
@@ -44,6 +63,10 @@ def _hip_predict(model, device, X):
     With DECODER_COLUMNS the 90-column rows are followed by model.DECODE_COLS decoder columns."""
     if device is not None and model._device is not None and _device_index(device) != model._device:
         model.to(device)
+    ent = _PENDING.pop(id(X), None)
+    if ent is not None and ent[0] is model and ent[2] is X:
+        # submitted ahead by the rebound batch generator (worker.lookahead_batches): the rows are on their way or here
+        return model.wait(ent[1])
     want = bool(DECODER_COLUMNS and model.add_indel_length)
     if want != model._decode_cols:
         model.decode_columns(want)
@@ -79,23 +102,46 @@ def get_gpu_memory(gpu_id=None):
     return [int(_lib.mem_info(d)[0] // (1024 * 1024)) for d in ids]
 
 
+# Worker processes ("GPU threads") per MI355X.  The reference sizes this for 16-80 GB CUDA cards: free_MB // 8000 (full
+# alignment) or // 5000 (pileup) processes per device (clair3/CallVariantsFromCffiGPU.py:33-34,55-56) -- 36 / 57 on a 288 GB
+# MI355X, each with its own HIP context, workspace (up to ~3 GB for pileup), staging threads and `cpu_threads` decode
+# processes, all behind one PCIe link.  One libc3hip handle fed through its submit / wait ring already fills the chip
+# (bench.py: host-inclusive rate 0.9-0.97 of the device-resident one; three handles side by side add < 10 % on the device and
+# LOSE when fed from the host), so the slot count is 1 per device unless C3HIP_SLOTS_PER_GPU says otherwise
+# (capped by the reference's own memory rule).
+def slots_per_gpu():
+    import os
+    try:
+        return max(1, int(os.environ.get("C3HIP_SLOTS_PER_GPU", "1")))
+    except ValueError:
+        return 1
+
+
 def check_gpu_memory(memory, device_ids=None, print_log=True):
-    """clair3/CallVariantsFromCffiGPU.py:21-43: one "GPU thread" (worker slot) per `memory` MB of free device
-    memory; returns the device id repeated once per slot.  The reference sys.exit(1)s when nothing is usable;
-    this raises C3Error and the installed wrapper (callvar.install) converts it back into the exit."""
+    """clair3/CallVariantsFromCffiGPU.py:21-43: returns the device id repeated once per worker slot.  The reference gives
+    every `memory` MB of free device memory a slot; here a device gets min(that, slots_per_gpu()) slots -- see above.
+    ``device_ids`` (from ``--device=cuda:2,3``, :60-65) are the PHYSICAL ids the caller exported as CUDA_VISIBLE_DEVICES
+    before asking: visible ordinal i is physical device_ids[i], and that is what a slot must carry, because the slot's
+    worker sets CUDA_VISIBLE_DEVICES to it (clair3/CallVariantsFromCffi.py:216; the reference returns the ordinal there).
+    The reference sys.exit(1)s when nothing is usable; this raises C3Error and the installed wrapper
+    (callvar.install) converts it back into the exit."""
     all_device_ids = list(range(_lib.device_count()))
     if device_ids is None:
         device_ids = all_device_ids
     if not all_device_ids:
         return
     gpu_id_list = []
+    cap = slots_per_gpu()
     for device_id in all_device_ids:
         free_mem = get_gpu_memory(gpu_id=device_id)[0]
-        gpu_threads = free_mem // memory
-        gpu_id_list += [device_id] * int(gpu_threads)
+        by_memory = int(free_mem // memory)
+        gpu_threads = min(by_memory, cap)
+        physical = device_ids[device_id] if device_id < len(device_ids) else device_id
+        gpu_id_list += [physical] * gpu_threads
         if print_log:
-            print(f"GPU {device_id} free memory: {free_mem} MB, assigning {memory} MB per thread, "
-                  f"{gpu_threads} threads available")
+            print(f"GPU {physical} free memory: {free_mem} MB, assigning {memory} MB per thread, "
+                  f"{gpu_threads} threads available (one libc3hip worker fills an MI355X; the reference's "
+                  f"free // {memory} rule would start {by_memory}; C3HIP_SLOTS_PER_GPU overrides)")
     if len(device_ids) == 0:
         raise _lib.C3Error("No GPU available, Please disabling --use_gpu for variant calling, exiting.")
     if len(gpu_id_list) == 0:

@@ -57,6 +57,59 @@ def iter_batches(list_fn, batch_size, first=0, stop=None):
             yield tensor[lo:hi], positions[lo:hi], alt_infos[lo:hi]
 
 
+HOST_SLOTS = 4  # C3_HOST_SLOTS (include/c3hip.h): submits in flight per handle
+
+
+def lookahead_batches(model, batches, pending, depth=2):
+    """The transport behind the reference's OWN loop.  ``call_variants_from_cffi`` pulls one batch from its generator and
+    makes one blocking ``_torch_predict`` call on it (clair3/CallVariantsFromCffi.py:302-317); this generator keeps the
+    loop's shape and runs ``depth`` batches ahead of it: before batch i is yielded, batches i .. i + depth have been handed
+    to ``model.submit`` (staging copy, H2D, kernels and D2H queued), and ``pending[id(X_i)] = (model, ticket, X_i)`` tells
+    the rebound ``_torch_predict`` (predict._hip_predict) that its rows only need to be waited for.  Same batches, same
+    order, same rows as the blocking calls -- a window's row does not depend on the batch it travels in."""
+    from collections import deque
+    slots = depth + 1
+    if not 1 <= slots <= HOST_SLOTS:
+        raise ValueError(f"depth must be in [0, {HOST_SLOTS - 1}], got {depth}")
+    queue = deque()  # (X, ticket, positions, alt_infos), oldest first
+    it = iter(batches)
+    n_submitted, exhausted, last = 0, False, None
+    try:
+        while True:
+            if last is not None:
+                # the loop did not call _torch_predict on the batch it was given (it would have popped the entry): the slot
+                # must be free before it is used again
+                ent = pending.pop(id(last), None)
+                if ent is not None:
+                    model.wait(ent[1])
+                last = None
+            while not exhausted and len(queue) < slots:
+                try:
+                    X, positions, alt_infos = next(it)
+                except StopIteration:
+                    exhausted = True
+                    break
+                X = np.ascontiguousarray(X)
+                ticket = model.submit(X, slot=n_submitted % slots)
+                n_submitted += 1
+                queue.append((X, ticket, positions, alt_infos))
+            if not queue:
+                return
+            X, ticket, positions, alt_infos = queue.popleft()
+            pending[id(X)] = (model, ticket, X)
+            last = X
+            yield X, positions, alt_infos
+    finally:
+        # abandoned or failed half way: nothing may stay in flight on the handle
+        if last is not None and id(last) in pending:
+            queue.appendleft((last, pending.pop(id(last))[1], None, None))
+        for X, ticket, _, _ in queue:
+            try:
+                model.wait(ticket)
+            except Exception:
+                pass
+
+
 def predict_batches(model, batches, consume, slots=3):
     """Run ``model`` over an iterator of (X, positions, alt_infos) with a ring of ``slots`` submits in flight per handle
     (c3_predict_submit / c3_predict_wait, at most C3_HOST_SLOTS = 4) and call ``consume(positions, alt_infos, Y)`` for
@@ -68,6 +121,8 @@ def predict_batches(model, batches, consume, slots=3):
     ``model`` may also be a list of handles loaded with the same weights: batch i then runs on handle i % len (own
     workspace and HIP streams each), so the kernels of consecutive batches overlap on the GPU as well."""
     from collections import deque
+    if not 1 <= int(slots) <= HOST_SLOTS:
+        raise ValueError(f"slots must be in [1, {HOST_SLOTS}] (C3_HOST_SLOTS of include/c3hip.h), got {slots}")
     models = list(model) if isinstance(model, (list, tuple)) else [model]
     total = 0
     pending = deque()  # (model, ticket, positions, alt_infos), oldest first

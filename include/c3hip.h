@@ -101,7 +101,9 @@ int c3_model_row_size(const c3_model *m);
 /* bytes of one input window for dtype x_dtype (594 / 2376 / 23496 / 26433 for the ONT shapes) */
 int64_t c3_model_window_bytes(const c3_model *m, int x_dtype);
 
-/* y_host[batch][24|90 (c3_model_row_size)] = forward(x_host[batch][...]); synchronous */
+/* y_host[batch][24|90 (c3_model_row_size)] = forward(x_host[batch][...]); synchronous.  A batch of two or more chunks (256
+ * full-alignment / 4096 pileup windows) travels through slots 0..2 of the submit / wait ring below in growing pieces, from the
+ * caller's pages page-locked for the duration of the call: no c3_predict_submit of this handle may be pending on those slots. */
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host);
 /* Note on the arithmetic: the contractions form their fp32 products from two fp16 pieces per operand (fp16x3, DESIGN.md 1:
  * fp32-level parity).  Should a checkpoint ever drive an activation towards the fp16 range (|x| >= 16000), c3_predict /
@@ -174,6 +176,18 @@ int c3_comm_unique_id(void *id128);
 c3_comm *c3_comm_create(const void *id128, int rank, int world, int device);
 int c3_comm_destroy(c3_comm *c);
 int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int64_t *counts, float *all_dev, int dst, void *stream);
+/* what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): *ranks_out ranks, this one *rank_out
+ * (may be NULL); world == 1 answers without RCCL.  bench.py prints it as rccl_ranks_seen. */
+int c3_comm_count(c3_comm *c, int *ranks_out, int *rank_out);
+/* give up on a collective that does not complete (ncclCommAbort); the handle then behaves like a world of one and the
+ * caller routes its rows another way (clair3_amd/dist.py falls back to torch.distributed) */
+int c3_comm_abort(c3_comm *c);
+/* watchdog for work queued on `stream` of `device` (hipStreamQuery polled every 50 us): 0 = finished, 1 = still running after
+ * timeout_ms (c3_last_error() == "timeout"; timeout_ms < 0 waits for ever), other = error */
+int c3_stream_wait(void *stream, int device, int timeout_ms);
+/* which of the bit-identical kernel forms the handle's last forward pass took (tile shapes that depend on whether other
+ * handles of the process are feeding the GPU), as "key=value ..." text; bench.py reports it next to its rates */
+int c3_model_describe(c3_model *m, char *buf, int buf_bytes);
 /* blocks until everything enqueued on the model's own stream has finished */
 int c3_model_synchronize(c3_model *m);
 int c3_model_destroy(c3_model *m);

@@ -135,6 +135,15 @@ def test_first_decision_and_qual_match_the_real_reference(indel):
     rows = np.arange(len(wide))[live]
     assert np.array_equal(d["pos"][live], g["argmax"][rows, g["winner"][live].astype(int)] * (g["winner"][live] > 0))
     assert np.array_equal(d["prob"][live].view(np.uint32), g["maxp"][rows, g["winner"][live].astype(int)].view(np.uint32))
+    # IUPAC reference bases resolve as output_from resolves them (clair3/CallVariants.py:690 -> shared/utils.py:42-45):
+    # U -> T, R -> A, Y / S / B -> C, K -> G ...; anything else (lower case included: a KeyError there) is an error
+    alias = {"A": "RWMDHVN", "C": "YSB", "G": "K", "T": "U"}
+    iupac = "".join(alias[c][i % len(alias[c])] for i, c in enumerate(letters))
+    d2 = decode.first_decisions(wide, iupac, g["y"].shape[1])
+    assert all(np.array_equal(d[k], d2[k]) for k in d)
+    from clair3_amd import _lib
+    with pytest.raises(_lib.C3Error, match="IUPAC"):
+        decode.first_decisions(wide[:2], "a?", g["y"].shape[1])
 
 
 @pytest.mark.gpu

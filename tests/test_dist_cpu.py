@@ -109,3 +109,72 @@ def test_row_gatherer_groups_steps_and_loses_nothing(tmp_path):
             for step in group:
                 want += [1000.0 * step + 100.0 * rank + r for r in range(B)]
     assert np.array_equal(y[:, 0], np.array(want, dtype=np.float32))
+
+
+EXCHANGE = textwrap.dedent("""
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, {root!r})
+    from clair3_amd import dist as c3dist
+    rank, world, _ = c3dist.init_from_env(backend="gloo")
+    scenario = {scenario!r}
+
+    class FakeComm:  # what RowExchange needs of RcclComm, with the failure under test
+        def __init__(self, rank, world, device, create_timeout_s=None):
+            self.rank, self.world, self.device = rank, world, device
+            if scenario == "create_fails_on_rank_1" and rank == 1:
+                raise TimeoutError("ncclCommInitRank did not return")
+        def ranks_seen(self):
+            return (1 if scenario == "rccl_sees_one_rank" and self.rank == 0 else self.world), self.rank
+        def gather(self, y, counts, dst=0, timeout_s=None):
+            if scenario == "first_gather_times_out_on_rank_0":
+                assert timeout_s is not None  # the first gather is the guarded one
+                if self.rank == 0:
+                    raise TimeoutError("c3_gather_rows did not finish")
+                return None  # the sender's ncclSend was accepted: rank 1 believes it got through
+            return c3dist.gather_counts(y, counts, dst=dst)  # a working direct path
+        def close(self):
+            pass
+
+    if scenario != "gloo_job":
+        c3dist.RcclComm = FakeComm
+        c3dist.RowExchange._cuda_job = lambda self: True
+    ex = c3dist.RowExchange(rank, world, device=0, timeout_s=1.0)
+    counts = [3, 5]
+    outs = []
+    for it in range(3):
+        y = torch.full((counts[rank], 4), 10.0 * it + rank)
+        outs.append(ex.gather(y, counts, dst=0))
+    rep = ex.report()
+    if rank == 0:
+        for it, o in enumerate(outs):
+            assert o.shape == (8, 4) and bool((o[:3] == 10.0 * it).all()) and bool((o[3:] == 10.0 * it + 1).all())
+        open({out!r}, "w").write(repr((rep["gather"], rep["rccl_ranks_seen"], bool(rep["fallback_reason"]))))
+    else:
+        assert all(o is None for o in outs)
+        open({out!r} + ".1", "w").write(rep["gather"])
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+""")
+
+
+def _run_exchange(tmp_path, scenario):
+    out = str(tmp_path / f"{scenario}.txt")
+    script = tmp_path / f"{scenario}.py"
+    script.write_text(EXCHANGE.format(root=ROOT, out=out, scenario=scenario))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return eval(open(out).read()), open(out + ".1").read()
+
+
+def test_row_exchange_falls_back_together(tmp_path):
+    """dist.RowExchange (what bench.py --gpus N and job.run_job gather with): RCCL directly while it works, torch.distributed
+    for EVERY rank from the moment one rank's rendezvous or first collective fails -- and the rows arrive either way"""
+    assert _run_exchange(tmp_path, "gloo_job") == (("torch_fallback", 1, True), "torch_fallback")  # host rows: nothing for RCCL
+    assert _run_exchange(tmp_path, "direct_works") == (("rccl_direct", 2, False), "rccl_direct")
+    assert _run_exchange(tmp_path, "create_fails_on_rank_1") == (("torch_fallback", 2, True), "torch_fallback")
+    assert _run_exchange(tmp_path, "rccl_sees_one_rank") == (("torch_fallback", 1, True), "torch_fallback")
+    assert _run_exchange(tmp_path, "first_gather_times_out_on_rank_0") == (("torch_fallback", 2, True), "torch_fallback")

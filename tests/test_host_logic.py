@@ -57,12 +57,15 @@ def test_install_rebinds_the_reference_call_sites():
         import clair3.CallVariantsFromCffi as w
         import clair3.CallVariantsFromCffiGPU as g
         orig = {n: inspect.signature(getattr(w, n)) for n in ("_torch_predict", "_load_torch_checkpoint", "_select_device",
-                                                              "_limit_gpu_memory")}
+                                                              "_limit_gpu_memory", "tensor_generator_for_chunk")}
         orig_g = {n: inspect.signature(getattr(g, n)) for n in ("get_gpu_memory", "check_gpu_memory")}
         from clair3_amd import callvar, predict
         from clair3_amd.model import Clair3_F, Clair3_P
         names = callvar.install()
-        assert len(names) == 8
+        assert len(names) == 9
+        assert w.tensor_generator_for_chunk._c3hip_original.__module__ == "clair3.CallVariantsFromCffi"
+        assert callvar.install() == names  # idempotent: the generator is wrapped once
+        assert not hasattr(w.tensor_generator_for_chunk._c3hip_original, "_c3hip_original")
         import clair3.model as ref_model
         assert ref_model.Clair3_P is Clair3_P and ref_model.Clair3_F is Clair3_F
         assert w._torch_predict is predict._hip_predict
@@ -79,7 +82,7 @@ def test_install_rebinds_the_reference_call_sites():
         unpatched = cv.batch_output
         assert not predict.DECODER_COLUMNS
         names = callvar.install(decoder=True)
-        assert len(names) == 10 and predict.DECODER_COLUMNS
+        assert len(names) == 11 and predict.DECODER_COLUMNS
         assert cv.batch_output is not unpatched and w.batch_output is cv.batch_output
         for n, params in sig.items():
             assert list(inspect.signature(getattr(cv, n)).parameters) == params, n
@@ -89,3 +92,35 @@ def test_install_rebinds_the_reference_call_sites():
         sys.path.remove(ref)
         for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")]:
             del sys.modules[k]
+
+
+def test_gpu_slots_on_a_288_gb_device(monkeypatch, capsys):
+    """the GPU wrapper's slot rule (clair3/CallVariantsFromCffiGPU.py:21-43,55-56) on MI355X-sized memory.
+    free_MB // 8000 would start 36 full-alignment (57 pileup) workers per device; one libc3hip worker fills the chip."""
+    from clair3_amd import _lib, predict
+    free = {0: 287_000 * 2**20, 1: 150_000 * 2**20, 2: 3_000 * 2**20}
+    monkeypatch.setattr(_lib, "device_count", lambda: 3)
+    monkeypatch.setattr(_lib, "mem_info", lambda d=0: (free[d], 288 * 2**30))
+    monkeypatch.delenv("C3HIP_SLOTS_PER_GPU", raising=False)
+    assert predict.get_gpu_memory() == [287_000, 150_000, 3_000]
+    assert predict.get_gpu_memory(gpu_id=1) == [150_000]
+    # one slot per device that has the memory at all; the 3 GB device gets none (the reference's rule still applies as a cap)
+    assert predict.check_gpu_memory(8000, None, print_log=False) == [0, 1]
+    assert predict.check_gpu_memory(5000, None, print_log=True) == [0, 1]
+    out = capsys.readouterr().out
+    assert "GPU 0 free memory: 287000 MB, assigning 5000 MB per thread, 1 threads available" in out
+    assert "would start 57" in out
+    # --device=cuda:4,5,6 -> CUDA_VISIBLE_DEVICES=4,5,6 (:60-65): the slot carries the PHYSICAL id its worker will export
+    assert predict.check_gpu_memory(8000, [4, 5, 6], print_log=False) == [4, 5]
+    monkeypatch.setenv("C3HIP_SLOTS_PER_GPU", "3")
+    assert predict.check_gpu_memory(8000, None, print_log=False) == [0, 0, 0, 1, 1, 1]
+    monkeypatch.setenv("C3HIP_SLOTS_PER_GPU", "100")
+    assert predict.check_gpu_memory(8000, None, print_log=False) == [0] * 35 + [1] * 18
+    # nothing usable: the reference's messages (the installed wrapper turns them back into sys.exit(1))
+    free[0] = free[1] = 100 * 2**20
+    with pytest.raises(_lib.C3Error, match="No memory in GPU"):
+        predict.check_gpu_memory(8000, None, print_log=False)
+    with pytest.raises(_lib.C3Error, match="No GPU available"):
+        predict.check_gpu_memory(8000, [], print_log=False)
+    monkeypatch.setattr(_lib, "device_count", lambda: 0)
+    assert predict.check_gpu_memory(8000, None, print_log=False) is None

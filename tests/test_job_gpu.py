@@ -48,3 +48,39 @@ def test_rccl_library_binds():
     buf = (C.c_char * 128)()
     _lib.check(_lib.lib().c3_comm_unique_id(buf), "c3_comm_unique_id")
     assert any(b != 0 for b in buf.raw)
+
+
+def test_communicator_introspection_and_watchdog():
+    """c3_comm_count (what bench.py prints as rccl_ranks_seen), c3_stream_wait (the watchdog RowExchange puts behind its first
+    gather) and RowExchange's one-rank mode"""
+    import ctypes as C
+    import torch
+    from clair3_amd import _lib
+    comm = c3dist.RcclComm(0, 1, 0)
+    assert comm.ranks_seen() == (1, 0)
+    y = torch.ones((5, 24), dtype=torch.float32, device="cuda:0")
+    out = comm.gather(y, [5], timeout_s=5.0)  # waits for the stream: finished, no timeout
+    assert torch.equal(out, y)
+    s = torch.cuda.Stream(device="cuda:0")
+    with torch.cuda.stream(s):
+        torch.cuda._sleep(int(2.4e9 * 0.3))  # ~0.3 s of device time on that stream
+    assert _lib.lib().c3_stream_wait(C.c_void_p(s.cuda_stream), 0, 20) == 1  # still running after 20 ms
+    assert _lib.last_error() == "timeout"
+    assert _lib.lib().c3_stream_wait(C.c_void_p(s.cuda_stream), 0, 5000) == 0
+    comm.close()
+    ex = c3dist.RowExchange(0, 1, device=0)
+    assert ex.mode == "single" and ex.gather(y, [5]) is y and ex.report()["rccl_ranks_seen"] == 1
+
+
+def test_describe_names_the_kernel_forms():
+    import ctypes as C
+    from clair3_amd import _lib
+    from clair3_amd.model import Clair3_P
+    m = Clair3_P(add_indel_length=False, predict=True, input_channels=18).to("cuda:0")
+    m.load_state_dict(syn.make_state_dict(syn.PILEUP, 18, False, seed=1))
+    m.predict_numpy(syn.make_windows(syn.PILEUP, 1024, seed=2))
+    buf = C.create_string_buffer(256)
+    assert _lib.lib().c3_model_describe(m._handle, buf, 256) == 0
+    text = buf.value.decode()
+    assert "lstm1=fused-f16x3-half-tiles" in text and "proj2=weights-resident" in text and "lstm2=f16x3-half-tiles" in text, text
+    assert "other_handles_active=0" in text and "on_fp32_fallback=0" in text

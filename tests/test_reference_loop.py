@@ -34,7 +34,7 @@ def write_tensor_files(tmp_path, sizes):
     return str(lst)
 
 
-def run_worker(tmp_path, lst, decoder, tag):
+def run_worker(tmp_path, lst, decoder, tag, prefetch=False, batch=0):
     """one run of the reference worker in this process (fresh reference modules each time)"""
     sys.path.insert(0, REF)
     sys.modules.setdefault("libclair3", types.ModuleType("libclair3"))  # the cffi extension of the tensor stage: not built here, not used
@@ -56,7 +56,8 @@ def run_worker(tmp_path, lst, decoder, tag):
         decode.outcome_from_columns = counting_outcome
         names = callvar.install(gpu_wrapper=False, decoder=decoder)
         assert ("clair3.CallVariants.batch_output" in names) == decoder
-        calls = {"plain": 0, "wide": 0}
+        calls = {"plain": 0, "wide": 0, "submitted": 0, "max_in_flight": 0}
+        in_flight = set()
         sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=2, peaked=True)
 
         class OracleBacked(Clair3_F):
@@ -79,9 +80,24 @@ def run_worker(tmp_path, lst, decoder, tag):
                 calls["plain"] += 1
                 return y
 
+            # the asynchronous pair of the real handle (c3_predict_submit / _wait), answered by the oracle
+            def submit(self, x, slot=0):
+                assert slot not in in_flight, "slot reused while in flight"
+                in_flight.add(slot)
+                calls["submitted"] += 1
+                calls["max_in_flight"] = max(calls["max_in_flight"], len(in_flight))
+                return slot, self.predict_numpy(x)
+
+            def wait(self, ticket):
+                in_flight.remove(ticket[0])
+                return ticket[1]
+
         ref_model.Clair3_F = OracleBacked
         w._select_device = lambda use_gpu: "cuda:0"
-        w._load_torch_checkpoint = lambda model, path, device=None: None
+        # with `prefetch` the loader registers the handle like the real one does (predict._load_torch_checkpoint), which is
+        # what switches the rebound batch generator to worker.lookahead_batches
+        w._load_torch_checkpoint = (lambda model, path, device=None: predict._register_current(model)) if prefetch \
+            else (lambda model, path, device=None: None)
         call_fn = str(tmp_path / f"out_{tag}.vcf")
         args = types.SimpleNamespace(
             enable_dwell_time=False, pileup=False, output_tensor_can_fn_list=lst, use_gpu=True, use_triton_gpu=False,
@@ -91,6 +107,8 @@ def run_worker(tmp_path, lst, decoder, tag):
         import shared.param_f as param
         import clair3.CallVariants as cv
         cv.param = param
+        if prefetch is not None and batch:
+            param.predictBatchSize = batch // 5  # the loop's GPU batch is predictBatchSize * 5 (:265-269); small for the oracle
         cfg = cv.OutputConfig(
             is_show_reference=True, is_debug=False, is_haploid_precise_mode_enabled=False,
             is_haploid_sensitive_mode_enabled=False, is_output_for_ensemble=False, quality_score_for_pass=None,
@@ -101,10 +119,13 @@ def run_worker(tmp_path, lst, decoder, tag):
         with open(call_fn) as f:
             rows = [r for r in f.read().split("\n") if r and not r.startswith("#")]
         calls["rows_decoded_from_columns"] = from_columns.value
+        assert not in_flight and not predict._PENDING
         return rows, calls
     finally:
         from clair3_amd import decode as _d, predict as _p
         _p.DECODER_COLUMNS = False
+        _p._CURRENT_MODEL = None
+        _p._PENDING.clear()
         if "real_outcome" in locals():
             _d.outcome_from_columns = real_outcome
         sys.path.remove(REF)
@@ -118,8 +139,23 @@ def test_worker_loop_prints_the_same_vcf_with_decoder_columns(tmp_path):
     plain_rows, plain_calls = run_worker(tmp_path, lst, decoder=False, tag="plain")
     wide_rows, wide_calls = run_worker(tmp_path, lst, decoder=True, tag="wide")
     # one batch per file (<= 1000); in the second run every row was decoded from its columns, inside the forked workers
-    assert plain_calls == {"plain": 3, "wide": 0, "rows_decoded_from_columns": 0}
-    assert wide_calls == {"plain": 0, "wide": 3, "rows_decoded_from_columns": 37 + 5 + 60}
+    assert plain_calls == {"plain": 3, "wide": 0, "rows_decoded_from_columns": 0, "submitted": 0, "max_in_flight": 0}
+    assert wide_calls == {"plain": 0, "wide": 3, "rows_decoded_from_columns": 37 + 5 + 60, "submitted": 0, "max_in_flight": 0}
     assert len(plain_rows) >= 60
     # the reference writes batches in completion order of its decode workers: compare as sets of rows
     assert sorted(plain_rows) == sorted(wide_rows)
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+def test_worker_loop_on_the_lookahead_generator(tmp_path, decoder):
+    """callvar.install() also rebinds tensor_generator_for_chunk: once a model has been loaded through the rebound loader,
+    the loop's batches are submitted to the handle two ahead of its blocking _torch_predict calls (worker.lookahead_batches).
+    Same batches, same VCF text; three submits in flight at most; nothing left in flight at the end."""
+    sizes = [40 + 40 + 7, 5, 30, 40]  # 3 + 1 + 1 + 1 batches of 40 (the loop's GPU batch, 1000, scaled down for the oracle)
+    lst = write_tensor_files(tmp_path, sizes)
+    plain_rows, plain_calls = run_worker(tmp_path, lst, decoder=decoder, tag="blocking", batch=40)
+    ahead_rows, ahead_calls = run_worker(tmp_path, lst, decoder=decoder, tag="ahead", prefetch=True, batch=40)
+    assert plain_calls["submitted"] == 0 and plain_calls["plain" if not decoder else "wide"] == 6
+    assert ahead_calls["submitted"] == 6 and ahead_calls["max_in_flight"] == 3
+    assert len(plain_rows) >= sum(sizes) // 2
+    assert sorted(plain_rows) == sorted(ahead_rows)

@@ -1,0 +1,135 @@
+"""The reference's UNMODIFIED GPU worker -- stage B of clair3/CallVariantsFromCffiGPU.py:163-199,289-318, i.e.
+``python clair3.py CallVariantsFromCffi --use_gpu True --gpu_id G --cpu_threads N --output_tensor_can_fn_list LIST`` with its
+loop at clair3/CallVariantsFromCffi.py:196-353 (model created before the ProcessPoolExecutor, one blocking _torch_predict
+per batch of 1000, forked decode workers, shared-memory hand-off of the rows, VCF text) -- against the REAL libc3hip on an
+MI355X, in its own process, next to the same command on the reference's own modules on the CPU.
+
+The reference modules come from the git-ignored oracle/_ref/ (staged by oracle/stage_reference.py from __graft_entry__.build();
+the GPU box has no /root/reference).  This is the test of everything no stand-in can show: HIP initialised before the fork of
+the decode workers, page-locking of numpy pages, the staging threads, CUDA_VISIBLE_DEVICES set by --gpu_id after the library
+is loaded, the rebound batch generator running two batches ahead of the loop, decoder columns through shared memory."""
+import json
+import os
+import re
+
+import pytest
+
+from clair3_amd import synthetic as syn
+from tests import refloop
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (kind, channels, indel heads, pileup flag, dwell flag, windows per tensor file)
+    "full_alignment": (syn.FULL_ALIGNMENT, 8, True, False, False, [2300, 1000, 37]),
+    "pileup": (syn.PILEUP, 18, False, True, False, [5000, 1200, 1]),
+    "dwell": (syn.FULL_ALIGNMENT, 9, True, False, True, [1100]),
+}
+
+
+@pytest.fixture(scope="module")
+def ref():
+    root = refloop.reference_root()
+    if root is None:
+        pytest.skip("no reference modules: run tools/stage_reference.sh in the build container (oracle/_ref travels with the snapshot)")
+    return root
+
+
+def elapsed(out):
+    m = re.search(r"Total time elapsed: ([0-9.]+) s", out)
+    return float(m.group(1)) if m else None
+
+
+@pytest.fixture(scope="module")
+def jobs(tmp_path_factory, ref):
+    """tensor files, checkpoint and the reference's own CPU run of every case (made once)"""
+    made = {}
+
+    def get(name):
+        if name in made:
+            return made[name]
+        kind, channels, indel, pileup, dwell, sizes = CASES[name]
+        d = str(tmp_path_factory.mktemp(name))
+        lst = refloop.write_job(d, kind, sizes, channels=channels)
+        ck = os.path.join(d, "model")  # the loader appends .pt (clair3/CallVariantsFromCffi.py:21-22)
+        refloop.write_checkpoint(ck + ".pt", kind, channels, indel)
+        want = os.path.join(d, "reference_cpu.vcf")
+        rc, out = refloop.run_worker(ref, lst, ck, want, pileup, indel, dwell=dwell, hip=False)
+        assert rc == 0, out[-3000:]
+        assert f"Total processed positions : {sum(sizes)}" in out, out[-3000:]
+        made[name] = dict(dir=d, lst=lst, ck=ck, want=want, n=sum(sizes), ref_s=elapsed(out))
+        return made[name]
+    return get
+
+
+def check(name, job, got_vcf, out, tag):
+    s = refloop.compare_vcfs(got_vcf, job["want"])
+    s.update(case=name, run=tag, windows=job["n"], loop_seconds=elapsed(out), reference_cpu_loop_seconds=job["ref_s"])
+    os.makedirs(os.path.join(refloop.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(refloop.ROOT, "gpurun_out", f"ref_loop_{name}_{tag}.json"), "w") as f:
+        json.dump(s, f, default=str)
+    print(json.dumps(s, default=str))
+    assert s["records_a"] == s["records_b"] and s["records_a"] >= job["n"] // 2, s
+    assert not s["only_a"] and not s["only_b"], s
+    # the same calls; QUAL is printed with two decimals from a log of probabilities that agree to ~1e-6, so a handful of rows may
+    # differ in the last digit (counted in qual_only); a different call is allowed only on < 0.1 % of the rows (near-ties)
+    assert len(s["call_differs"]) <= max(1, job["n"] // 1000), s
+    assert s["identical_text"] + s["qual_only"] >= s["records_a"] - len(s["call_differs"])
+    assert s["identical_text"] >= 0.98 * s["records_a"], s
+    return s
+
+
+@pytest.mark.parametrize("name", ["full_alignment", "pileup", "dwell"])
+def test_unmodified_worker_command_on_libc3hip(name, ref, jobs):
+    kind, channels, indel, pileup, dwell, sizes = CASES[name]
+    job = jobs(name)
+    got = os.path.join(job["dir"], "hip.vcf")
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, dwell=dwell, hip=True,
+                                 extra_env={"C3HIP_VERBOSE": "1"})
+    assert rc == 0, out[-3000:]
+    assert "tensor_generator_for_chunk" in out  # install() ran in that process
+    assert f"Total processed positions : {sum(sizes)}" in out, out[-3000:]
+    check(name, job, got, out, "hip")
+
+
+def test_blocking_calls_without_the_lookahead_generator(ref, jobs):
+    """C3HIP_PREFETCH_DEPTH=0: the reference's own generator and one blocking c3_predict per batch (page-locks the numpy pages
+    of the batch for the call, chunks through the ring) -- same VCF"""
+    job = jobs("full_alignment")
+    got = os.path.join(job["dir"], "hip_blocking.vcf")
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, False, True, hip=True, extra_env={"C3HIP_PREFETCH_DEPTH": "0"})
+    assert rc == 0, out[-3000:]
+    check("full_alignment", job, got, out, "hip_blocking")
+
+
+def test_decoder_columns_through_the_reference_loop(ref, jobs):
+    """install(decoder=True): 121-column rows through the loop's shared memory into its forked decode workers, the rebound
+    batch_output reading the device's decoder columns there -- same VCF text as the reference's enumeration"""
+    job = jobs("full_alignment")
+    got = os.path.join(job["dir"], "hip_decoder.vcf")
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, False, True, hip=True, decoder=True)
+    assert rc == 0, out[-3000:]
+    s = check("full_alignment", job, got, out, "hip_decoder")
+    # and against the run without the columns on the same device rows: character for character
+    plain = os.path.join(job["dir"], "hip.vcf")
+    if os.path.exists(plain):
+        t = refloop.compare_vcfs(got, plain)
+        assert t["identical_text"] == t["records_a"] == t["records_b"], t
+    assert s["records_a"] > 0
+
+
+def test_gpu_wrapper_slot_probe_on_the_device(ref):
+    """CallVariantsFromCffiGPU.check_gpu_memory after install(): hipMemGetInfo instead of nvidia-smi, one slot per MI355X"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, sys.argv[1]); from clair3_amd import callvar; callvar.install(worker=False);"
+            "import clair3.CallVariantsFromCffiGPU as g; print('SLOTS', g.check_gpu_memory(8000, None), g.get_gpu_memory(0))")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([refloop.ROOT, refloop.STUBS]))
+    r = subprocess.run([sys.executable, "-c", code, ref], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"SLOTS \[([0-9, ]*)\] \[(\d+)\]", r.stdout)
+    assert m, r.stdout
+    slots = [int(v) for v in m.group(1).split(",") if v.strip()]
+    assert slots == sorted(set(slots)) and len(slots) >= 1  # one slot per visible device
+    assert int(m.group(2)) > 100_000  # MB free on an MI355X
+    assert "would start" in r.stdout

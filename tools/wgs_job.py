@@ -41,7 +41,7 @@ def main():
     from clair3_amd.model import Clair3_F, Clair3_P
     rank, world, local = c3dist.init_from_env(backend="gloo" if os.environ.get("C3_JOB_GLOO") else None)
     torch.cuda.set_device(local)
-    comm = c3dist.RcclComm(rank, world, local)
+    exchange = c3dist.RowExchange(rank, world, device=local)  # RCCL directly; torch.distributed if that does not come up
     base = args.dir or tempfile.mkdtemp(prefix="c3_wgs_job_")
     for kind in args.kinds.split(","):
         n = max(1, int(FULL_JOB[kind] * args.scale))
@@ -61,10 +61,10 @@ def main():
             m.load_state_dict(sd)
             models.append(m)
         model = models if len(models) > 1 else models[0]
-        job.run_job(model, list_fn, rank, world, batch_size=args.batch, comm=comm)  # warm-up pass: workspaces, page cache
+        job.run_job(model, list_fn, rank, world, batch_size=args.batch, exchange=exchange)  # warm-up pass: workspaces, page cache
         if world > 1:
             torch.distributed.barrier()
-        res = job.run_job(model, list_fn, rank, world, batch_size=args.batch, comm=comm)
+        res = job.run_job(model, list_fn, rank, world, batch_size=args.batch, exchange=exchange)
         if rank == 0:
             y = res["rows"]
             assert y.shape == (n, 90 if indel else 24) and np.isfinite(y).all()
@@ -78,13 +78,14 @@ def main():
                               "windows_per_rank": res["per_rank"], "batch": args.batch, "handles": args.handles,
                               "candidate_windows_per_s": n / res["total_s"], "total_s": res["total_s"],
                               "rank0_compute_s": res["compute_s"], "gather_s": res["gather_s"], "write_files_s": t_write,
-                              "rows_in_window_order": order_ok, "gather": "RCCL (c3_gather_rows)" if world > 1 else "none (1 rank)"}),
+                              "rows_in_window_order": order_ok, **exchange.report()}),
                   flush=True)
             assert order_ok
         if world > 1:
             torch.distributed.barrier()
         del models, model
-    comm.close()
+    if exchange.comm is not None:
+        exchange.comm.close()
     if args.dir is None and rank == 0:
         shutil.rmtree(base, ignore_errors=True)
     if world > 1:
