@@ -73,6 +73,18 @@ static bool is_registered(const void *p, size_t n) {
     return false;
 }
 
+// Small batches (the pileup network: 594 B per window in, 96 B out) cross PCIe inside the COMPUTE stream instead: a copy kernel
+// reads the pinned staging buffer / writes the pinned result buffer directly (both are device-mapped), so a batch is ONE chain
+// of launches on one queue -- no copy engine, no cross-queue event waits, whose barrier packets cost a 210 us pileup batch
+// ~60 us of idle GPU per batch.  The transfer is then serial with the kernels, which is only worth it while it is
+// short: up to kKernelCopyMax bytes (~15 us at PCIe Gen5 rates); full-alignment batches (23.5 MB) keep the DMA engines.
+constexpr size_t kKernelCopyMax = (size_t)2 << 20;
+__global__ __launch_bounds__(256) void host_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                       const uint32_t *flag_src, uint32_t *flag_dst) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (flag_dst && blockIdx.x == 0 && threadIdx.x == 0) *flag_dst = *flag_src;
+}
+
 // stage [src, src + bytes) through `pin` into `dev` on stream s, piecewise
 static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s, bool src_locked = false) {
     if (src_locked || is_registered(src, bytes)) {  // zero-copy: the DMA engine reads the caller's pages
@@ -242,6 +254,8 @@ struct c3_model {
 
     // which of the bit-identical kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
     const char *choice_lstm1 = "-", *choice_proj2 = "-", *choice_lstm2 = "-", *choice_fa = "-";
+
+    int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
 
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -1634,6 +1648,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
         return nullptr;
     }
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
+    if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
     if (const char *e = getenv("C3HIP_WINOGRAD")) m->wino_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_BN64MASK")) m->conv_bn64_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char *e = getenv("C3HIP_CONV_SPLITMASK")) m->conv_split_mask = (unsigned)strtoul(e, nullptr, 0);
@@ -1840,6 +1855,20 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
     const size_t yb = (size_t)batch * m->row * sizeof(float);
+    if (batch > 0 && m->host_copy_kernel && xb <= kKernelCopyMax && yb <= kKernelCopyMax && !src_locked && !is_registered(x_host, xb)) {
+        TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, (yb + 255) & ~(size_t)255));
+        memcpy(sl.pin_x, x_host, xb);
+        hipLaunchKernelGGL(host_copy_kernel, dim3(128), dim3(256), 0, m->stream, (const uint4 *)sl.pin_x, (uint4 *)sl.dev_x, (xb + 15) / 16,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+        const bool f16 = m->f16_ok;
+        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
+        hipLaunchKernelGGL(host_copy_kernel, dim3(32), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
+                           (const uint32_t *)m->range_flag, sl.pin_flag);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
+        sl.used_f16 = f16;
+    } else
     if (batch > 0) {
         // the slot becomes busy only once everything has been queued: a failure on the way leaves it free
         TRY(ensure_slot(m, sl, xb, yb));
