@@ -6,6 +6,7 @@
 // Rendezvous is the caller's business (128-byte unique id from rank 0 to everybody -- the Python layer sends it through
 // whatever control plane launched the ranks, e.g. torch.distributed's store); the data path is RCCL only.
 #pragma once
+#include "c3_model.h"
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types, enums and prototypes only: the symbols are bound with dlopen below, nothing links librccl
@@ -89,3 +90,149 @@ struct c3_comm {
     ncclComm_t nccl = nullptr;  // null when world == 1
     int rank = 0, world = 1, device = 0;
 };
+
+extern "C" {
+
+// ---- the gather of the sharded job on RCCL (c3_comm.h) ----
+int c3_comm_unique_id(void *id128) {
+    if (!id128) return fail("null buffer");
+    RcclApi &r = RcclApi::get();
+    if (!r.load()) return fail("%s", r.error.c_str());
+    static_assert(sizeof(ncclUniqueId) == 128, "c3_comm_unique_id hands out 128 bytes");
+    ncclUniqueId id;
+    const ncclResult_t rc = r.GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail("ncclGetUniqueId failed: %s", r.GetErrorString(rc));
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+c3_comm *c3_comm_create(const void *id128, int rank, int world, int device) {
+    if (world < 1 || rank < 0 || rank >= world) {
+        fail("bad rank %d of %d", rank, world);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail("hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    c3_comm *c = new c3_comm();
+    c->rank = rank, c->world = world, c->device = device;
+    if (world == 1) return c;  // nothing to talk to: c3_gather_rows is a device copy
+    if (!id128) {
+        fail("null unique id");
+        delete c;
+        return nullptr;
+    }
+    RcclApi &r = RcclApi::get();
+    if (!r.load()) {
+        fail("%s", r.error.c_str());
+        delete c;
+        return nullptr;
+    }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    const ncclResult_t rc = r.CommInitRank(&c->nccl, world, id, rank);
+    if (rc != ncclSuccess) {
+        fail("ncclCommInitRank failed: %s", r.GetErrorString(rc));
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+int c3_comm_destroy(c3_comm *c) {
+    if (!c) return 0;
+    if (c->nccl) (void)RcclApi::get().CommDestroy(c->nccl);
+    delete c;
+    return 0;
+}
+
+int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int64_t *counts, float *all_dev, int dst, void *stream) {
+    if (!c || !counts) return fail("null argument");
+    if (dst < 0 || dst >= c->world || row_floats <= 0) return fail("bad arguments (dst %d of %d ranks, %d floats per row)", dst, c->world, row_floats);
+    for (int r = 0; r < c->world; ++r)
+        if (counts[r] < 0) return fail("negative row count for rank %d", r);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t mine = (size_t)counts[c->rank] * row_floats;
+    if (mine && !rows_dev) return fail("null rows");
+    if (c->rank == dst && !all_dev) return fail("the destination rank needs the gathered buffer");
+    if (c->world == 1) {
+        if (mine && all_dev != rows_dev) HIP_TRY(hipMemcpyAsync(all_dev, rows_dev, mine * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    RcclApi &r = RcclApi::get();
+    int rc = (int)r.GroupStart();
+    if (rc) return fail("ncclGroupStart failed: %s", r.GetErrorString((ncclResult_t)rc));
+    if (c->rank == dst) {
+        size_t off = 0;
+        for (int src = 0; src < c->world && !rc; ++src) {
+            const size_t n = (size_t)counts[src] * row_floats;
+            if (src == dst) {
+                if (n && all_dev + off != rows_dev) {
+                    hipError_t e = hipMemcpyAsync(all_dev + off, rows_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+                    if (e != hipSuccess) rc = -1;
+                }
+            } else if (n) {
+                rc = (int)r.Recv(all_dev + off, n, ncclFloat32, src, c->nccl, s);
+            }
+            off += n;
+        }
+    } else if (mine) {
+        rc = (int)r.Send(rows_dev, mine, ncclFloat32, dst, c->nccl, s);
+    }
+    const ncclResult_t rc2 = r.GroupEnd();
+    if (rc > 0) return fail("ncclSend/ncclRecv failed: %s", r.GetErrorString((ncclResult_t)rc));
+    if (rc < 0) return fail("device copy inside the gather failed");
+    if (rc2 != ncclSuccess) return fail("ncclGroupEnd failed: %s", r.GetErrorString(rc2));
+    return 0;
+}
+
+int c3_comm_count(c3_comm *c, int *ranks_out, int *rank_out) {
+    if (!c || !ranks_out) return fail("null argument");
+    if (!c->nccl) {  // world == 1: no communicator
+        *ranks_out = c->world;
+        if (rank_out) *rank_out = c->rank;
+        return 0;
+    }
+    RcclApi &r = RcclApi::get();
+    ncclResult_t rc = r.CommCount(c->nccl, ranks_out);
+    if (rc != ncclSuccess) return fail("ncclCommCount failed: %s", r.GetErrorString(rc));
+    if (rank_out) {
+        rc = r.CommUserRank(c->nccl, rank_out);
+        if (rc != ncclSuccess) return fail("ncclCommUserRank failed: %s", r.GetErrorString(rc));
+    }
+    return 0;
+}
+
+int c3_comm_abort(c3_comm *c) {
+    if (!c) return 0;
+    if (c->nccl) {
+        RcclApi &r = RcclApi::get();
+        const ncclResult_t rc = r.CommAbort(c->nccl);
+        c->nccl = nullptr;
+        c->world = 1;  // whatever is asked of this handle from now on is local
+        if (rc != ncclSuccess) return fail("ncclCommAbort failed: %s", r.GetErrorString(rc));
+    }
+    return 0;
+}
+
+int c3_stream_wait(void *stream, int device, int timeout_ms) {
+    HIP_TRY(hipSetDevice(device));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery((hipStream_t)stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail("hipStreamQuery: %s", hipGetErrorString(e));
+        if (timeout_ms >= 0 &&
+            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) {
+            (void)hipGetLastError();
+            g_err = "timeout";
+            return 1;
+        }
+        struct timespec ts = {0, 50000};  // 50 us
+        nanosleep(&ts, nullptr);
+    }
+}
+
+}  // extern "C"

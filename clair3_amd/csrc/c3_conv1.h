@@ -1,18 +1,14 @@
 // c3_conv1.h -- the first full-alignment convolution (3x3, stride 2, pad 1, 8 int8 channels -> 64, BN, ReLU;
-// clair3/model.py:316-317,391) as a barrier-free, LDS-free MFMA kernel.
+// clair3/model.py:316-317,391) as a barrier-free, LDS-free MFMA kernel of its own.  In the product conv1 is computed INSIDE the
+// first residual block (c3_conv3.h SRC8) and this launch does not exist; it runs when every layer keeps its own output
+// (c3_debug_keep_activations, the layer-by-layer parity tests) and behind C3HIP_CONV1_FUSED=0.
 //
-// K = 72 is three k-steps of the tiled implicit GEMM -- a workgroup's prologue and epilogue outweigh its main loop,
-// and the generic kernel ran this layer at 40 TFLOP/s.  Here nothing is shared between waves, so nothing is
-// synchronised: a wave keeps the WHOLE weight matrix as MFMA B fragments in registers (36 k-steps x 2 column blocks =
-// 72 VGPRs, BatchNorm and the 1/100 input scale folded in on the host) plus the bias as two ready-made C operands, and
-// walks over groups of 32 output pixels:
-//   lane (pixel m = lane & 31, k-half kk = lane >> 5) loads ONE dword per tap -- the 4 channels 4kk..4kk+3 of the 8-byte
-//   pixel; the K order is chosen to match (k = 2 s + kk, s = 4 tap + j  <->  channel 4 kk + j), so the bytes of that
-//   dword are exactly the lane's A operands of k-steps 4 tap .. 4 tap + 3, no cross-lane movement;
-//   padding taps are redirected out of range of the buffer descriptor (the load returns 0 = the zero padding);
-//   72 x v_mfma_f32_32x32x2_f32 per group, the first of each column block taking the bias as C;
-//   ReLU and 32 dword stores per lane (32 lanes x 4 B = one 128-byte line each), rows beyond M dropped by the
-//   descriptor's range check;  the next group's 9 dwords are requested before the MFMAs of the current one.
+// K = 72 is three k-steps of a tiled implicit GEMM -- a workgroup's prologue and epilogue would outweigh its main loop.  Here
+// nothing is shared between waves, so nothing is synchronised: a wave keeps the WHOLE weight matrix as matrix-instruction
+// fragments in registers and walks over groups of 32 output pixels; padding taps are redirected out of range of the buffer
+// descriptor (the load returns 0 = the zero padding); the next group's taps are requested before the matrix instructions of
+// the current one.
+
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,121 +17,7 @@
 
 namespace c3 {
 
-struct Conv1Params {
-    const int8_t *x;     // [B][H][W][8]
-    const float *wfrag;  // [36 k-steps][2 column blocks][64 lanes]: W'[cout = 32 cb + (lane & 31)][tap = s / 4][channel = 4 (lane >> 5) + s % 4]
-    const float *bias;   // [64] (BatchNorm folded)
-    float *out;          // [B][OH][OW][64]
-    int B, H, W, OH, OW;
-    int M;       // B * OH * OW output pixels
-    int groups;  // ceil(M / 32)
-};
-
-__global__ __launch_bounds__(256, 2) void conv1_i8_kernel(Conv1Params p) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 31, kk = lane >> 5;
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    if (gw >= p.groups) return;
-
-    // descriptor shifted one row + one pixel back so that the offset of tap (0,0) = pixel (2oy-1, 2ox-1) is never negative
-    const int rowB = p.W * 8;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.x)) - (rowB + 8), 0, p.B * p.H * rowB + rowB + 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.M * 256, 0x00020000);
-
-    // resident weights and bias
-    float wf[36][2];
-#pragma unroll
-    for (int s = 0; s < 36; ++s)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) wf[s][cb] = p.wfrag[(s * 2 + cb) * 64 + lane];
-    f32x16 biasv[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const float b = p.bias[32 * cb + m];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) biasv[cb][v] = b;
-    }
-
-    const int ohw = p.OH * p.OW;
-    // the 9 dwords of output pixel g*32 + m (zeros where the tap is padding or the pixel is beyond M)
-    auto request = [&](int g, uint32_t (&d)[9]) __attribute__((always_inline)) {
-        const int pix = g * 32 + m;
-        const int b = pix / ohw, r = pix - b * ohw;
-        const int oy = r / p.OW, ox = r - oy * p.OW;
-        const uint32_t base = (uint32_t)(((b * p.H + 2 * oy) * p.W + 2 * ox) * 8 + 4 * kk);
-        const bool valid = pix < p.M;
-        bool rok[3], cok[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            rok[k] = valid && 2 * oy - 1 + k >= 0 && 2 * oy - 1 + k < p.H;
-            cok[k] = 2 * ox - 1 + k >= 0 && 2 * ox - 1 + k < p.W;
-        }
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const uint32_t voff = (rok[ky] && cok[kx] ? base : 0x80000000u) + (uint32_t)(kx * 8);
-                d[ky * 3 + kx] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, ky * rowB, 0);
-            }
-    };
-
-    // Software pipeline over the groups of a wave: the 9 loads of group g+1 and the 32 stores of group g-1 are issued
-    // BETWEEN the MFMAs of group g (a vector-memory instruction costs ~60 cycles of issue when the wave has nothing else
-    // to do, next to nothing inside an MFMA stream -- DESIGN.md 3.7); the two accumulator sets swap roles by name.
-    // ReLU is a signed-integer max of the bit pattern (one v_max_i32; fmaxf would first canonicalise the MFMA result
-    // with a second v_max_f32).  The row offset stays in the VECTOR offset: (a) the descriptor's range check then drops
-    // the surplus rows of the last, partial group; (b) a store whose scalar offset is a REGISTER reads its data register
-    // late on gfx950 and the compiler does not pad that case (29 % of the outputs were wrong that way).
-    auto store_one = [&](const f32x16 (&r)[2], uint32_t o0, int idx) __attribute__((always_inline)) {
-        const int cb = idx >> 4, v = idx & 15;
-        const uint32_t off = o0 + (uint32_t)(((v & 3) + 8 * (v >> 2)) * 256 + cb * 128);
-        const float val = r[cb][v];  // (bit-casting the vector element expression directly is miscompiled: element 0 every time)
-        const int relu = max(__float_as_int(val), 0);
-        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)relu, orsrc, off, 0, 0);
-    };
-    uint32_t d[9];
-    request(gw, d);
-    auto body = [&](int g, f32x16 (&acc)[2], const f32x16 (&prev)[2], uint32_t prev_o0) __attribute__((always_inline)) {
-        // int8 -> fp32: byte j of tap t is the A operand of k-step 4t + j
-        float a[36];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[4 * t + j] = (float)(int8_t)(d[t] >> (8 * j));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 36; ++s) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wf[s][cb], s == 0 ? biasv[cb] : acc[cb], 0, 0, 0);
-            if (s == 1 && g + nw < p.groups) request(g + nw, d);
-            if (s >= 2 && s < 34) store_one(prev, prev_o0, s - 2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // acc[cb][v] is pixel row (v & 3) + 8 (v >> 2) + 4 kk of its group, cout 32 cb + m
-    auto out_base = [&](int g) { return (uint32_t)((g * 32 + 4 * kk) * 256 + m * 4); };
-    f32x16 accA[2], accB[2];
-    uint32_t prev_o0 = 0x80000000u;  // nothing to store yet: out of range, dropped
-    int g = gw;
-    for (; g + nw < p.groups; g += 2 * nw) {
-        body(g, accA, accB, prev_o0);
-        body(g + nw, accB, accA, out_base(g));
-        prev_o0 = out_base(g + nw);
-    }
-    if (g < p.groups) {
-        body(g, accA, accB, prev_o0);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) store_one(accA, out_base(g), i);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) store_one(accB, prev_o0, i);
-    }
-}
-
-// ---- fp16 form: the int8 window is EXACT in fp16, so only the weights need two pieces: x * w = x h0 + x h1 on
+// The int8 window is EXACT in fp16, so only the weights need two pieces: x * w = x h0 + x h1 on
 // v_mfma_f32_32x32x16_f16 (fp32 accumulation) -- two matrix instructions of 32 cycles per 16 k and column block instead
 // of eight of 64.  K order = (tap, channel): k-step t holds taps 2t (lanes 0-31) and 2t + 1 (lanes 32-63), a lane loads
 // the 8 channels of its tap as one 8-byte piece; tap 9 does not exist (out-of-range offset -> zeros, zero weights).

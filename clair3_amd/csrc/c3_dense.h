@@ -1,25 +1,20 @@
-// c3_dense.h -- C[M][N] (fp32) = A (plane activations, c3_conv3.h) x W^T + bias on v_mfma_f32_32x32x16_f16, fp16x3 products.
+// c3_dense.h -- C = A (plane activations, c3_conv3.h) x W^T + bias on v_mfma_f32_32x32x16_f16, fp16x3 products.
 //
-// Used for the LSTM2 input projection of Clair3_P (clair3/model.py:96-107,132-133: gx2 = h1 W_ih2^T + b_ih + b_hh for both
-// directions at once): M = 33 B rows of 256 features -> 1280 gate pre-activations, 21.6 MFLOP per window, the largest kernel
-// of the pileup step.  The tiled GEMM of c3_gemm.h spent 105 us on it at B = 1024 (32-channel chunks, 8-byte loads, operand
-// split in the loader, 12 matrix instructions per barrier and wave: MfmaUtil 27 %).  Here:
-//  * LSTM1 writes h1 as planes (hi / lo fp16 pieces, 64-channel slabs of 256 B), so both operands reach LDS as plain 16-byte
-//    copies: 4 + 4 pieces per thread and 64-channel chunk;
-//  * one workgroup (512 threads = 8 waves as 2 x 4, 64 x 32 outputs per wave, one per CU, persistent) = 128 x 128 tiles;
-//    K = 256 is four chunks per tile, so the chunk stream runs on across tiles: chunk g + 1 sits in registers while chunk g
-//    is multiplied, and goes to the other LDS buffer at the top of chunk g + 1;
-//  * fragment reads run one k-step ahead of the matrix instructions (pinned order, as in conv3x3_planes_kernel);
-//  * the finished tile leaves through the LDS buffer its last chunk occupied: (row, 8-column) items, two 16-byte stores,
-//    16 lanes per 512-byte row segment (173 MB of fp32 per 1024 windows: the store shape matters, c3_conv3.h).
-// LDS rows are 272 B apart (conflict-free ds_read_b128 of 16 consecutive rows, immediate (piece, k-step) offsets).
+//   dense_planes_pipe_kernel<CONV = true>   the two stride-2 convolutions of Clair3_F (conv3, conv5; clair3/model.py:382-387) as
+//                                           implicit GEMMs on plane activations, 128 x 128 tiles, both operands streaming in
+//                                           64-channel chunks; epilogue of the plane pipeline (bias, ReLU, split into fp16
+//                                           pieces, range flag);
+//   dense_planes_pipe_kernel<CONV = false>  the LSTM2 input projection of Clair3_P (clair3/model.py:96-107,132-133: gx2 = h1
+//                                           W_ih2^T + b_ih + b_hh for both directions at once; M = 33 B rows of 256 features ->
+//                                           1280 gate pre-activations) for batches too small for the kernel below;
+//   dense_planes_wres_kernel                the same projection with its weights resident in registers (K = 256): the product.
+// Both produce bit-identical rows (same chunk order, same instruction sequence per accumulator).
 //
-// Three kernels share the tile shape, the operand layouts and the LDS stages:
-//   dense_planes_kernel       the first form, described above (whole chunk staged and re-requested at the top of a chunk); kept
-//                             for A/B (C3HIP_DENSE_MODE=0 staged / 1 direct fp32 epilogue) and for its phase trace;
-//   dense_planes_pipe_kernel  the product (mode 3): the chunk stream spread piecewise over the matrix stream, waits sized by hand;
-//   dense_planes_ws_kernel    8 multiplying + 4 moving waves (mode 4): faster alone, slower for the step.
-// tools/dense_probe.hip times all three on the projection shape with parts switched off (the ABL template bits).
+// Common ground: LSTM1 / the convolutions write their outputs as planes (hi / lo fp16 pieces, 64-channel slabs of 256 B), so
+// both operands reach LDS as plain 16-byte copies; one workgroup (512 threads = 8 waves) per CU, persistent; fragment reads
+// run one k-step ahead of the matrix instructions (pinned order, as in conv3x3_planes_kernel); LDS rows are 272 B apart
+// (conflict-free ds_read_b128 of 16 consecutive rows, immediate (piece, k-step) offsets).
+// tools/dense_probe.hip times both on the projection shape with parts switched off (the ABL template bits).
 #pragma once
 #include "c3_conv3.h"
 
@@ -44,276 +39,6 @@ struct DensePlanesParams {
     uint32_t mg_hw = 0, mg_w = 0;  // CONV: fast_div magics of Ho * Wo and Wo (c3_gemm.h)
     long long *trace = nullptr;  // TR (debug, C3HIP_DENSE_TRACE): {tag, shader clock} pairs of workgroup 0, waves 0 and 4, [2][512][2]
 };
-
-// CONV = false: the LSTM2 projection above.  CONV = true: the two stride-2 convolutions of Clair3_F (conv3, conv5;
-// clair3/model.py:382-387) on plane activations -- the same chunk stream with the A rows gathered per (tap, slab) from the
-// input pixels (out-of-window taps are out-of-range buffer offsets: zeros) and the epilogue of the plane pipeline (bias, ReLU,
-// split into fp16 pieces, range flag).  Replaces gemm_mfma_kernel<PlaneConvLoader> (32-channel chunks, 8-byte pieces).
-// DIRECT (CONV = false only): the fp32 tile leaves straight from the accumulators -- a lane owns 4 consecutive columns of a
-// row (the weights are the first matrix operand), i.e. one 16-byte store per (row block, column quad), bias from an LDS copy
-// of the whole vector -- instead of crossing LDS to become (row, 8-column) items.  No LDS traffic and no barrier between
-// the last chunk of a tile and the first of the next: with K = 256 a tile is only four chunks long, and the staged epilogue
-// (16 LDS accesses per thread, two barriers, the matrix pipe idle meanwhile) was a fifth of it.
-template <bool CONV = false, bool DIRECT = false, bool TR = false>
-__global__ __launch_bounds__(kDnThreads, 2) void dense_planes_kernel(DensePlanesParams p) {
-    static_assert(!(CONV && DIRECT), "the plane epilogue needs the (row, 8-column) items");
-    constexpr int NLT = kDnThreads;                // threads that request / stage operand pieces
-    constexpr int PJ = 2048 / NLT;                 // pieces per thread and operand: 128 rows x 16 pieces
-    constexpr int RJ = NLT / 16;                   // rows between a thread's consecutive pieces
-    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + (DIRECT ? 8192 : 0)];
-    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);
-    if constexpr (DIRECT) {
-        for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
-    const int frow = lane & 31, kh = lane >> 5;
-    const int NK = p.K / 64;
-    const int G = gridDim.x;
-    const int rowb = CONV ? p.Cin * 4 : (p.K / 64) * 256;  // bytes per row (pixel) of A
-    const int nsin = CONV ? p.Cin / 64 : 1;
-
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(p.a), 0, CONV ? (uint32_t)((int64_t)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win * rowb) : (uint32_t)((int64_t)p.M * rowb), 0x00020000);
-    const __amdgpu_buffer_rsrc_t crsrc =
-        __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
-    // CONV: input pixel (b, oh * stride - 1, ow * stride - 1) and tap validity of this thread's four rows of the tile whose
-    // chunks are being requested (recomputed when the request stream moves on to the next tile)
-    constexpr bool loader = true, storer = true;
-    const int ltid = tid & (NLT - 1);  // loader / storer index inside its group
-    int rbase[PJ];
-    uint32_t rmask[PJ];
-#pragma unroll
-    for (int j = 0; j < PJ; ++j) rbase[j] = 0, rmask[j] = 0u;
-    auto row_info = [&](int m0) __attribute__((always_inline)) {
-        if constexpr (CONV) {
-            if (!loader) return;
-            const int hw = p.Ho * p.Wo;
-#pragma unroll
-            for (int j = 0; j < PJ; ++j) {
-                const int m = m0 + (ltid >> 4) + RJ * j;
-                uint32_t mk = 0;
-                int base = 0;
-                if (m < p.M) {
-                    const int b = fast_div(m, p.mg_hw), rem = m - b * hw;
-                    const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
-                    const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
-                    base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
-                    mk = tap_mask9(ih0, iw0, p.Hin, p.Win);
-                }
-                rbase[j] = base, rmask[j] = mk;
-            }
-        }
-    };
-
-    // chunk stream of this workgroup: (tile v, v + G, ...) x (k chunk 0 .. NK - 1)
-    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
-        const int tile = xcd_tile_index(v, p.tiles);
-        const int tm = tile / p.tiles_n;
-        tn = tile - tm * p.tiles_n;
-        m0 = tm * kDnBM;
-    };
-    // this thread's four pieces of each operand chunk: piece idx = tid + 512 j -> row idx >> 4, position idx & 15
-    auto issue = [&](pl_u32x4 (&ra)[PJ], pl_u32x4 (&rb)[PJ], int m0, int tn, int kc) __attribute__((always_inline)) {
-        if (!loader) return;
-        const char *wsrc = reinterpret_cast<const char *>(p.w) + ((size_t)tn * NK + kc) * (kDnBN * 256) + ltid * 16;
-#pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            const int idx = ltid + NLT * j;
-            const int m = m0 + (idx >> 4);
-            uint32_t off;
-            if constexpr (CONV) {
-                const int tap = kc / nsin, slab = kc - tap * nsin;
-                const int kh3 = tap / 3, kw3 = tap - 3 * kh3;
-                off = ((rmask[j] >> tap) & 1u) ? (uint32_t)(rbase[j] + (kh3 * p.Win + kw3) * rowb + slab * 256 + (idx & 15) * 16) : kPlOob;
-            } else {
-                off = m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
-            }
-            ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
-            rb[j] = *reinterpret_cast<const pl_u32x4 *>(wsrc + j * (NLT * 16));
-        }
-    };
-    const int st_off = (ltid >> 4) * kPlRowB + (ltid & 15) * 16;  // RJ rows further per j
-    auto stage = [&](const pl_u32x4 (&ra)[PJ], const pl_u32x4 (&rb)[PJ], int buf) __attribute__((always_inline)) {
-        if (!loader) return;
-        char *dst = smem + buf * kDnStage + st_off;
-#pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            *reinterpret_cast<pl_u32x4 *>(dst + j * RJ * kPlRowB) = ra[j];
-            *reinterpret_cast<pl_u32x4 *>(dst + kDnABytes + j * RJ * kPlRowB) = rb[j];
-        }
-    };
-    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
-    };
-    const int a_rd[2] = {(wm * 64 + frow) * kPlRowB + kh * 16, (wm * 64 + 32 + frow) * kPlRowB + kh * 16};
-    const int b_rd = kDnABytes + (wn * 32 + frow) * kPlRowB + kh * 16;
-
-    int tr_n = 0;
-    auto trace = [&](int tag) __attribute__((always_inline)) {
-        if constexpr (TR) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (p.trace && blockIdx.x == 0 && (tid == 0 || tid == 256) && tr_n < 512) {
-                long long *tb = p.trace + ((tid ? 1 : 0) * 512 + tr_n) * 2;
-                tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
-                ++tr_n;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    int v = blockIdx.x;
-    if (v >= p.tiles) return;
-    int m0, tn;
-    tile_mn(v, m0, tn);
-    row_info(m0);
-    pl_u32x4 ra[PJ], rb[PJ];
-    issue(ra, rb, m0, tn, 0);
-    stage(ra, rb, 0);
-    // the chunk after the first: same tile if NK > 1, else the next tile's
-    int vq = v, m0q = m0, tnq = tn, kq = 1;  // (tile, chunk) of the chunk held in registers
-    if (kq == NK) {
-        kq = 0, vq = v + G;
-        if (vq < p.tiles) {
-            tile_mn(vq, m0q, tnq);
-            row_info(m0q);
-        }
-    }
-    if (vq < p.tiles) issue(ra, rb, m0q, tnq, kq);
-    lds_barrier();
-
-    int g = 0;  // chunks done: the current chunk sits in LDS stage g & 1
-    float omax = 0.f;
-    for (;;) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-        for (int kc = 0; kc < NK; ++kc) {
-            const char *cur = smem + (g & 1) * kDnStage;
-            // the chunk in registers -> the other stage (its readers passed the barrier that ended the previous chunk), then
-            // the request for the chunk after it
-            const bool have_next = vq < p.tiles;
-            trace(1);
-            if (have_next) stage(ra, rb, (g + 1) & 1);
-            trace(2);
-            if (have_next) {
-                if (++kq == NK) {
-                    kq = 0, vq += G;
-                    if (vq < p.tiles) {
-                        tile_mn(vq, m0q, tnq);
-                        row_info(m0q);
-                    }
-                }
-                if (vq < p.tiles) issue(ra, rb, m0q, tnq, kq);
-            }
-            trace(3);
-            __builtin_amdgcn_sched_barrier(0);
-            pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
-            auto frags = [&](int ks, int st) __attribute__((always_inline)) {
-                wh[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + ks * 32);
-                wl[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + 128 + ks * 32);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + ks * 32);
-                    xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + 128 + ks * 32);
-                }
-            };
-            frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int st = ks & 1;
-                if (ks < 3) frags(ks + 1, st ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[0] = mma(acc[0], wh[st], xl[st][0]);
-                acc[1] = mma(acc[1], wh[st], xl[st][1]);
-                acc[0] = mma(acc[0], wl[st], xh[st][0]);
-                acc[1] = mma(acc[1], wl[st], xh[st][1]);
-                acc[0] = mma(acc[0], wh[st], xh[st][0]);
-                acc[1] = mma(acc[1], wh[st], xh[st][1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            trace(4);
-            lds_barrier();
-            ++g;
-        }
-        trace(5);
-        if constexpr (DIRECT) {
-            const int cb0 = wn * 32 + 4 * kh;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = m0 + wm * 64 + i * 32 + frow;
-                const uint32_t rowoff = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + cb0) * 4) : kPlOob;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + tn * kDnBN + cb0 + 8 * q);
-                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
-                }
-            }
-            v += G;
-            if (v >= p.tiles) break;
-            tile_mn(v, m0, tn);
-            continue;
-        }
-        // ---- epilogue through the stage the tile's last chunk occupied ((g - 1) & 1; the next chunk is in the other one)
-        char *stg = smem + ((g - 1) & 1) * kDnStage;
-        constexpr int kRowE = 528;  // 128 columns x 4 B + 16 B pad: 16-byte accesses of consecutive rows land on different banks
-        static_assert(kDnBM * kRowE <= kDnStage, "staged tile must fit one stage");
-        const int cb0 = wn * 32 + 4 * kh;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + tn * kDnBN + cb0 + 8 * q);
-                f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
-                *reinterpret_cast<f32x4 *>(stg + (wm * 64 + i * 32 + frow) * kRowE + (cb0 + 8 * q) * 4) = val;
-            }
-        lds_barrier();
-        if (storer)
-#pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            const int idx = ltid + NLT * j;
-            const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
-            const int m = m0 + r;
-            if constexpr (CONV) {
-                f32x4 a = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32);
-                f32x4 b = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32 + 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[e] = __int_as_float(max(__float_as_int(a[e]), 0));  // ReLU on the bit pattern
-                    b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
-                }
-                omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-                u32x2 pa[2], pb[2];
-                split2_f16(a, pa);
-                split2_f16(b, pb);
-                const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
-                const int n = tn * kDnBN + c8 * 8;  // channel: slab n >> 6, hi piece at 2 (n & 63), lo piece 128 bytes further
-                const uint32_t off = m < p.M ? (uint32_t)m * (uint32_t)(p.N * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : kPlOob;
-                __builtin_amdgcn_raw_buffer_store_b128(hi, crsrc, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(lo, crsrc, off + 128, 0, 0);
-            } else {
-                const pl_u32x4 a = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32);
-                const pl_u32x4 b = *reinterpret_cast<const pl_u32x4 *>(stg + r * kRowE + c8 * 32 + 16);
-                const uint32_t off = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + c8 * 8) * 4) : kPlOob;
-                __builtin_amdgcn_raw_buffer_store_b128(a, crsrc, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(b, crsrc, off + 16, 0, 0);
-            }
-        }
-        v += G;
-        if (v >= p.tiles) break;
-        tile_mn(v, m0, tn);
-        lds_barrier();  // the staged tile has been read; the next chunk's stage() may overwrite it
-    }
-    if constexpr (CONV)
-        if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
-}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // dense_planes_pipe_kernel -- the same tiles, operands and LDS layout with the chunk stream spread over the matrix stream.
@@ -604,455 +329,6 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DenseP
     }
     if constexpr (CONV)
         if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// dense_planes_ws_kernel -- the same tiles with the work split by wave ROLE: waves 0-7 multiply (2 x 4, 64 x 32 outputs each,
-// as above) and store the results, waves 8-11 do nothing but move operand chunks: global -> registers -> LDS.
-//
-// tools/dense_probe.hip on the LSTM2 projection (us): whole kernel 102; without its result stores 76; operand loads + LDS
-// staging alone 33 (676 MB out of L2 per launch: ~20 TB/s); fragment reads + matrix instructions add 42, the stores 27 -- the
-// parts ADD UP instead of overlapping.  With every wave doing everything, every wave sits in turn behind its own loads
-// (s_waitcnt before staging), behind the LDS write path and behind the matrix pipe, in lockstep with its seven siblings, and a
-// wave's stores and loads share one in-order counter.  With the roles split, a chunk lasts max(move, multiply): the movers
-// never wait for the matrix pipe, the multipliers never execute a load, and the only stores a wave ever waits for are none.
-// One barrier per chunk as before (movers fill stage (g + 1) & 1 while the multipliers read stage g & 1).
-constexpr int kWsThreads = 768, kWsMovers = 256;
-template <bool CONV = false, int ABL = 0>
-__global__ __launch_bounds__(kWsThreads) void dense_planes_ws_kernel(DensePlanesParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + 8192];
-    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);
-    for (int i = threadIdx.x; i < p.N && i < 2048; i += kWsThreads) bias_lds[i] = p.bias[i];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NK = p.K / 64;
-    const int G = gridDim.x;
-    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
-        const int tile = xcd_tile_index(v, p.tiles);
-        const int tm = tile / p.tiles_n;
-        tn = tile - tm * p.tiles_n;
-        m0 = tm * kDnBM;
-    };
-    if (blockIdx.x >= p.tiles) return;
-
-    if (wave >= 8) {
-        // ------------------------------------------------------------------------------------------------ movers
-        const int ltid = tid - 512;
-        const int rowb = CONV ? p.Cin * 4 : (p.K / 64) * 256;  // bytes per row (pixel) of A
-        const int nsin = CONV ? p.Cin / 64 : 1;
-        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void *>(p.a), 0, CONV ? (uint32_t)((int64_t)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win * rowb) : (uint32_t)((int64_t)p.M * rowb), 0x00020000);
-        const __amdgpu_buffer_rsrc_t wrsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, (uint32_t)((int64_t)p.N * p.K * 4), 0x00020000);
-        // piece j of a chunk: row (ltid >> 4) + 16 j of each operand, 16-byte position ltid & 15
-        int rbase[8];
-        uint32_t rmask[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rbase[j] = 0, rmask[j] = 0u;
-        auto row_info = [&](int m0) __attribute__((always_inline)) {
-            if constexpr (CONV) {
-                const int hw = p.Ho * p.Wo;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int m = m0 + (ltid >> 4) + 16 * j;
-                    uint32_t mk = 0;
-                    int base = 0;
-                    if (m < p.M) {
-                        const int b = fast_div(m, p.mg_hw), rem = m - b * hw;
-                        const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
-                        const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
-                        base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
-                        mk = tap_mask9(ih0, iw0, p.Hin, p.Win);
-                    }
-                    rbase[j] = base, rmask[j] = mk;
-                }
-            }
-        };
-        pl_u32x4 ra[8], rb[8];
-        // `on` = false: the loads still issue, at out-of-range offsets (zeros): the same number of loads in flight on every
-        // path, so hipcc's s_waitcnt vmcnt(N) before each LDS write leaves the younger loads in flight
-        auto issue1 = [&](int j, int m0, int tn, int kc, bool on) __attribute__((always_inline)) {
-            const int idx = ltid + kWsMovers * j;
-            const int m = m0 + (idx >> 4);
-            uint32_t off;
-            if constexpr (CONV) {
-                const int tap = kc / nsin, slab = kc - tap * nsin;
-                const int kh3 = tap / 3, kw3 = tap - 3 * kh3;
-                off = (on && ((rmask[j] >> tap) & 1u)) ? (uint32_t)(rbase[j] + (kh3 * p.Win + kw3) * rowb + slab * 256 + (idx & 15) * 16) : kPlOob;
-            } else {
-                off = on && m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)(kc * 256 + (idx & 15) * 16) : kPlOob;
-            }
-            const uint32_t woff = on ? (uint32_t)((tn * NK + kc) * (kDnBN * 256) + idx * 16) : kPlOob;
-            if constexpr (!(ABL & 1)) {
-                ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
-                rb[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
-            } else {
-                ra[j] = pl_u32x4{off, woff, 0x3c003c00u, 0x3c003c00u}, rb[j] = pl_u32x4{woff, off, 0x3c003c00u, 0x3c003c00u};
-            }
-        };
-        const int st_off = (ltid >> 4) * kPlRowB + (ltid & 15) * 16;  // 16 rows further per j
-        auto stage1 = [&](int j, int buf) __attribute__((always_inline)) {
-            char *dst = smem + buf * kDnStage + st_off + j * 16 * kPlRowB;
-            if constexpr (!(ABL & 2)) {
-                *reinterpret_cast<pl_u32x4 *>(dst) = ra[j];
-                *reinterpret_cast<pl_u32x4 *>(dst + kDnABytes) = rb[j];
-            } else {
-                if (ra[j][1] == 0x12345u && rb[j][2] == 0x54321u) *reinterpret_cast<pl_u32x4 *>(dst) = ra[j];
-            }
-        };
-        int v = blockIdx.x;
-        int m0q, tnq;
-        tile_mn(v, m0q, tnq);
-        row_info(m0q);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) issue1(j, m0q, tnq, 0, true);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage1(j, 0);
-        int vq = v, kq = 1;  // (tile, chunk) of the chunk held in registers
-        if (kq == NK) {
-            kq = 0, vq = v + G;
-            if (vq < p.tiles) {
-                tile_mn(vq, m0q, tnq);
-                row_info(m0q);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) issue1(j, m0q, tnq, kq, vq < p.tiles);
-        lds_barrier();
-        int g = 0;
-        for (; v < p.tiles; v += G) {
-            for (int kc = 0; kc < NK; ++kc) {
-                bool req = false;
-                if (vq < p.tiles) {
-                    if (++kq == NK) {
-                        kq = 0, vq += G;
-                        if (vq < p.tiles) {
-                            tile_mn(vq, m0q, tnq);
-                            row_info(m0q);
-                        }
-                    }
-                    req = vq < p.tiles;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    stage1(j, (g + 1) & 1);  // zeros once the stream has ended: nobody reads them
-                    issue1(j, m0q, tnq, kq, req);
-                }
-                if constexpr (!(ABL & 32)) lds_barrier();
-                ++g;
-            }
-            if constexpr (CONV) {  // the multipliers' epilogue crosses LDS: its two barriers
-                lds_barrier();
-                lds_barrier();
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------------- multipliers
-    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
-    const int frow = lane & 31, kh = lane >> 5;
-    const __amdgpu_buffer_rsrc_t crsrc =
-        __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
-    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
-        if constexpr (ABL & 4) {
-            c[0] += __uint_as_float(w[0] ^ x[0]), c[5] += __uint_as_float(w[3] ^ x[3]);
-            return c;
-        } else {
-            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
-        }
-    };
-    const int a_rd[2] = {(wm * 64 + frow) * kPlRowB + kh * 16, (wm * 64 + 32 + frow) * kPlRowB + kh * 16};
-    const int b_rd = kDnABytes + (wn * 32 + frow) * kPlRowB + kh * 16;
-    const int cb0 = wn * 32 + 4 * kh;
-    lds_barrier();
-    int g = 0;
-    float omax = 0.f;
-    for (int v = blockIdx.x; v < p.tiles; v += G) {
-        int m0, tn;
-        tile_mn(v, m0, tn);
-        f32x16 acc[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-        for (int kc = 0; kc < NK; ++kc) {
-            const char *cur = smem + (g & 1) * kDnStage;
-            pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
-            auto frags = [&](int ks, int st) __attribute__((always_inline)) {
-                if constexpr (ABL & 8) {
-                    const pl_u32x4 f = {(uint32_t)(ks + g), (uint32_t)lane, 0x3c003c00u, 0x3c003c00u};
-                    wh[st] = wl[st] = xh[st][0] = xh[st][1] = xl[st][0] = xl[st][1] = f;
-                    return;
-                }
-                wh[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + ks * 32);
-                wl[st] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + 128 + ks * 32);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + ks * 32);
-                    xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd[i] + 128 + ks * 32);
-                }
-            };
-            frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int st = ks & 1;
-                if (ks < 3) frags(ks + 1, st ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[0] = mma(acc[0], wh[st], xl[st][0]);
-                acc[1] = mma(acc[1], wh[st], xl[st][1]);
-                acc[0] = mma(acc[0], wl[st], xh[st][0]);
-                acc[1] = mma(acc[1], wl[st], xh[st][1]);
-                acc[0] = mma(acc[0], wh[st], xh[st][0]);
-                acc[1] = mma(acc[1], wh[st], xh[st][1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (!(ABL & 32)) lds_barrier();
-            ++g;
-        }
-        if constexpr (!CONV) {
-            // fp32 tile straight from the accumulators: a lane owns 4 consecutive columns of a row (weights are the first operand)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = m0 + wm * 64 + i * 32 + frow;
-                const uint32_t rowoff = m < p.M ? (uint32_t)(((int64_t)m * p.N + tn * kDnBN + cb0) * 4) : kPlOob;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + tn * kDnBN + cb0 + 8 * q);
-                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
-                    if constexpr (ABL & 16) {
-                        if (val[0] == 1234.5f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
-                    }
-                }
-            }
-        } else {
-            // plane epilogue through the stage the tile's last chunk occupied ((g - 1) & 1; the movers are filling the other one and
-            // start on this one only behind the second barrier below)
-            char *stg = smem + ((g - 1) & 1) * kDnStage;
-            constexpr int kRowE = 528;  // 128 columns x 4 B + 16 B pad
-            static_assert(kDnBM * kRowE <= kDnStage, "staged tile must fit one stage");
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + tn * kDnBN + cb0 + 8 * q);
-                    f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
-                    *reinterpret_cast<f32x4 *>(stg + (wm * 64 + i * 32 + frow) * kRowE + (cb0 + 8 * q) * 4) = val;
-                }
-            lds_barrier();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = tid + 512 * j;
-                const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
-                const int m = m0 + r;
-                f32x4 a = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32);
-                f32x4 b = *reinterpret_cast<const f32x4 *>(stg + r * kRowE + c8 * 32 + 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[e] = __int_as_float(max(__float_as_int(a[e]), 0));  // ReLU on the bit pattern
-                    b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
-                }
-                omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-                u32x2 pa[2], pb[2];
-                split2_f16(a, pa);
-                split2_f16(b, pb);
-                const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
-                const int n = tn * kDnBN + c8 * 8;  // channel: slab n >> 6, hi piece at 2 (n & 63), lo piece 128 bytes further
-                const uint32_t off = m < p.M ? (uint32_t)m * (uint32_t)(p.N * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : kPlOob;
-                __builtin_amdgcn_raw_buffer_store_b128(hi, crsrc, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(lo, crsrc, off + 128, 0, 0);
-            }
-            lds_barrier();  // the staged tile has been read: the movers may fill this stage
-        }
-    }
-    if constexpr (CONV)
-        if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// dense_planes_big_kernel -- C[M][N] = A W^T + b on 256 x 256 tiles, for the LSTM2 projection (CONV = false only).
-//
-// The ablations of the 128 x 128 kernels (tools/dense_probe.hip) say their parts add up and two of the three
-// parts are traffic: 64 KB from L2 and through the LDS write path plus 192 KB of fragment reads per 1536 cycles of matrix work.
-// A 256 x 256 tile halves all of it per matrix instruction: a wave owns 128 x 64 outputs = 4 x 2 blocks of 32 x 32, so a k-step
-// reads 8 + 4 fragments for 24 matrix instructions (0.5 per instruction instead of 1.0), and a chunk stages 512 operand rows
-// for 2 x the products.  To fit two LDS stages the chunk is 32 channels (rows of 64 B hi | 64 B lo, 144 B apart: 16 consecutive
-// rows still cover all banks once): 73.7 KB per stage.  Otherwise dense_planes_pipe_kernel: pieces staged and re-requested one
-// at a time inside the matrix stream (one per 32 x 32 row block = per six matrix instructions), unconditional requests, results
-// stored at the top of the next tile, a tile's first chunk as its own copy of the code.  660 tiles for 1024 windows on 256
-// workgroups: three rounds, 86 % full.
-constexpr int kBgBM = 256, kBgBN = 256, kBgKC = 32, kBgRowB = 144;
-constexpr int kBgABytes = kBgBM * kBgRowB, kBgStage = (kBgBM + kBgBN) * kBgRowB;  // 73 728 B per stage
-
-struct DenseBigParams {
-    const void *a;      // plane activations [M][K/64][hi 64 | lo 64] fp16
-    const void *w;      // [N/256][K/32][256 rows][8 pieces of 16 B]: pieces 0-3 = hi of k 8g..8g+7 of the 32-channel chunk, 4-7 = lo; times 2^s
-    const float *bias;  // [N]
-    float *c;           // [M][N] fp32
-    float post_scale;   // 2^-s
-    int M, N, K;
-    int tiles_n, tiles;  // N / 256, ceil(M / 256) * tiles_n
-};
-
-__global__ __launch_bounds__(kDnThreads, 2) void dense_planes_big_kernel(DenseBigParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kBgStage + 8192];
-    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kBgStage);
-    for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 128 x 64 outputs each
-    const int frow = lane & 31, kh = lane >> 5;
-    const int NK = p.K / kBgKC;
-    const int G = gridDim.x;
-    const int rowb = (p.K / 64) * 256;  // bytes per row of A
-
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.a), 0, (uint32_t)((int64_t)p.M * rowb), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, (uint32_t)((int64_t)p.N * p.K * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
-    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
-        const int tile = xcd_tile_index(v, p.tiles);
-        const int tm = tile / p.tiles_n;
-        tn = tile - tm * p.tiles_n;
-        m0 = tm * kBgBM;
-    };
-    // piece j (0..3) of each operand: row (tid >> 3) + 64 j, 16-byte group g = tid & 7 (0-3 hi, 4-7 lo) of the 32-channel chunk
-    pl_u32x4 ra[4], rb[4];
-    const int pg = tid & 7;
-    const uint32_t a_in_row = pg < 4 ? (uint32_t)(pg * 16) : (uint32_t)(128 + (pg - 4) * 16);  // + slab * 256 + half * 64
-    auto issue1 = [&](int j, int m0, int tn, int kc, bool on) __attribute__((always_inline)) {
-        const int row = (tid >> 3) + 64 * j;
-        const int m = m0 + row;
-        const uint32_t off = on && m < p.M ? (uint32_t)m * (uint32_t)rowb + (uint32_t)((kc >> 1) * 256 + (kc & 1) * 64) + a_in_row : kPlOob;
-        const uint32_t woff = on ? (uint32_t)(((tn * NK + kc) * kBgBN + row) * 128 + pg * 16) : kPlOob;
-        ra[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
-        rb[j] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
-    };
-    const int st_off = (tid >> 3) * kBgRowB + pg * 16;  // 64 rows further per j
-    auto stage1 = [&](int j, int buf, bool b_operand) __attribute__((always_inline)) {
-        char *dst = smem + buf * kBgStage + st_off + j * 64 * kBgRowB + (b_operand ? kBgABytes : 0);
-        *reinterpret_cast<pl_u32x4 *>(dst) = b_operand ? rb[j] : ra[j];
-    };
-    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
-    };
-    // fragment of k-step ks: hi piece 2 ks + kh at byte (2 ks + kh) * 16 of the row, lo piece 64 bytes further
-    const int a_rd = (wm * 128 + frow) * kBgRowB + kh * 16;              // + i * 32 rows
-    const int b_rd = kBgABytes + (wn * 64 + frow) * kBgRowB + kh * 16;   // + j * 32 rows
-
-    int v = blockIdx.x;
-    if (v >= p.tiles) return;
-    int m0, tn;
-    tile_mn(v, m0, tn);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue1(j, m0, tn, 0, true);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stage1(j, 0, false), stage1(j, 0, true);
-    int vq = v, m0q = m0, tnq = tn, kq = 1;  // (tile, chunk) of the chunk held in registers
-    if (kq == NK) {
-        kq = 0, vq = v + G;
-        if (vq < p.tiles) tile_mn(vq, m0q, tnq);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue1(j, m0q, tnq, kq, vq < p.tiles);
-    lds_barrier();
-
-    int g = 0;  // chunks done: the current chunk sits in LDS stage g & 1
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    auto chunk = [&](auto first_tag) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const char *cur = smem + (g & 1) * kBgStage;
-        bool req = false;
-        if (vq < p.tiles) {
-            if (++kq == NK) {
-                kq = 0, vq += G;
-                if (vq < p.tiles) tile_mn(vq, m0q, tnq);
-            }
-            req = vq < p.tiles;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            pl_u32x4 wh[2], wl[2], xh[2], xl[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                wh[j] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + j * 32 * kBgRowB + ks * 32);
-                wl[j] = *reinterpret_cast<const pl_u32x4 *>(cur + b_rd + j * 32 * kBgRowB + 64 + ks * 32);
-            }
-            xh[0] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + ks * 32);
-            xl[0] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + 64 + ks * 32);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int st = i & 1;
-                if (i < 3) {
-                    xh[st ^ 1] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + (i + 1) * 32 * kBgRowB + ks * 32);
-                    xl[st ^ 1] = *reinterpret_cast<const pl_u32x4 *>(cur + a_rd + (i + 1) * 32 * kBgRowB + 64 + ks * 32);
-                }
-                // slot (ks, i) of the chunk: one operand piece goes to the other stage and is requested again
-                {
-                    const int slot = ks * 4 + i, j = slot >> 1;
-                    if (slot & 1) stage1(j, (g + 1) & 1, true);
-                    else stage1(j, (g + 1) & 1, false);
-                    if (slot & 1) issue1(j, m0q, tnq, kq, req);  // both registers of piece j are free now
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 c0 = acc[i][j];
-                    if (FIRST && ks == 0) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) c0[e] = 0.f;
-                    }
-                    c0 = mma(c0, wh[j], xl[st]);
-                    c0 = mma(c0, wl[j], xh[st]);
-                    acc[i][j] = mma(c0, wh[j], xh[st]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        lds_barrier();
-        ++g;
-    };
-    auto epilogue = [&](int pm0, int ptn, bool valid) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = pm0 + wm * 128 + i * 32 + frow;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n0 = ptn * kBgBN + wn * 64 + j * 32 + 4 * kh;
-                const uint32_t rowoff = valid && m < p.M ? (uint32_t)(((int64_t)m * p.N + n0) * 4) : kPlOob;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + n0 + 8 * q);
-                    f32x4 val = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
-                }
-            }
-        }
-    };
-    int pm0 = 0, ptn = 0;
-    bool have_prev = false;
-    for (;;) {
-        epilogue(pm0, ptn, have_prev);
-        if (v >= p.tiles) break;
-        chunk(std::true_type{});  // the copy behind the stores
-        for (int kc = 1; kc < NK; ++kc) chunk(std::false_type{});
-        pm0 = m0, ptn = tn, have_prev = true;
-        v += G;
-        if (v < p.tiles) tile_mn(v, m0, tn);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

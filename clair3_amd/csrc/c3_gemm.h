@@ -28,39 +28,15 @@ namespace c3 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int st_u32x2 __attribute__((__vector_size__(8)));  // the data operand type of __builtin_amdgcn_raw_buffer_store_b64
 
-// SPLIT mode (bf16x6): an fp32 value is the exact sum of three bf16 pieces x = x0 + x1 + x2 (8 mantissa bits each);
-// x*w is formed from the six piece products x0w0, x0w1, x1w0, x0w2, x1w1, x2w0 on v_mfma_f32_32x32x16_bf16 (products
-// exact, fp32 accumulation), dropping only terms below 2^-24 of the product -- the rounding an fp32 FMA chain makes
-// anyway (tests/diag/bf16x_study.py: rows as close to the reference as the fp32 path's).  Four values -> three 8-byte
-// groups of bf16, round-to-nearest-even at every level.
-__device__ __forceinline__ void split3_bf16(const f32x4 x, u32x2 (&piece)[3]) {
-    float r[4] = {x[0], x[1], x[2], x[3]};
-#pragma unroll
-    for (int lvl = 0; lvl < 3; ++lvl) {
-#pragma unroll
-        for (int i = 0; i < 4; i += 2) {
-            const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r[i], r[i + 1]}, bf16x2));
-            piece[lvl][i >> 1] = u;
-            if (lvl < 2) {
-                r[i] -= __uint_as_float(u << 16);
-                r[i + 1] -= __uint_as_float(u & 0xffff0000u);
-            }
-        }
-    }
-}
-
-// SPLIT mode 2 (fp16x3): x = h0 + h1 with two fp16 pieces (11 mantissa bits each, round to nearest, subnormals kept --
+// SPLIT (fp16x3): x = h0 + h1 with two fp16 pieces (11 mantissa bits each, round to nearest, subnormals kept --
 // v_mfma_f32_32x32x16_f16 honours subnormal inputs, tools/f16_denorm_probe.hip); x*w from x0w0 + x0w1 + x1w0, dropping
-// x1w1 < 2^-22 of the product.  Same operand bytes as fp32 (two 16-bit pieces), half the matrix instructions of bf16x6
-// and 2.5 instead of 4.5 vector instructions per split value; rows as close to the reference as the fp32 path's
-// (tests/diag/bf16x_study.py).  Needs |x| < 65504, which every activation and weight of these networks satisfies by orders of
+// x1w1 < 2^-22 of the product.  Same operand bytes as fp32 (two 16-bit pieces), 2.5 vector instructions per split
+// value; rows as close to the reference as the fp32 path's (tests/diag/bf16x_study.py).  Needs |x| < 65504, which every activation and weight of these networks satisfies by orders of
 // magnitude (int8/100 inputs, BatchNorm-scaled stages).
 __device__ __forceinline__ void split2_f16(const f32x4 x, u32x2 (&piece)[2]) {
 #pragma unroll
@@ -172,66 +148,6 @@ struct ConvLoader {
     }
 };
 
-// The same gather over PLANE activations (c3_conv3.h: per pixel C/64 slabs of [hi 64 x fp16][lo 64 x fp16]): a thread's
-// four channels are 8 bytes of the hi plane and 8 bytes of the lo plane -- already the two fp16 pieces the SPLIT = 2 staging
-// writes to LDS, so there is no split work at all (kPlanes: stage() stores the raw pieces).  Cin % 64 == 0.
-struct PlaneConvLoaderParams {
-    const void *x;
-    const void *zeros;  // >= 256 readable zero bytes
-    int Hin, Win, Cin, Ho, Wo, stride;
-    int chunks_per_tap;  // Cin / 32
-};
-template <int R>
-struct PlaneConvLoader {
-    typedef PlaneConvLoaderParams Params;
-    static constexpr bool kPlanes = true;
-    struct Raw {
-        u32x2 hi, lo;
-    };
-    const char *x, *zeros;
-    int64_t off[R];  // byte offset of pixel (b, ih0, iw0) + this thread's 4 channels inside a half slab
-    uint32_t mask[R];
-    int Win, pixb, cpt_shift, cpt_mask;
-    __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
-        x = reinterpret_cast<const char *>(p.x), zeros = reinterpret_cast<const char *>(p.zeros), Win = p.Win, pixb = 4 * p.Cin;
-        cpt_mask = p.chunks_per_tap - 1, cpt_shift = 31 - __builtin_clz(p.chunks_per_tap);  // power of two
-        const int hw = p.Ho * p.Wo;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            int m = m0 + lr + 32 * i;
-            if (m >= M) m = M - 1;
-            const int b = m / hw, rem = m - b * hw;
-            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-            const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
-            off[i] = (((int64_t)b * p.Hin + ih0) * p.Win + iw0) * pixb + lc * 8;
-            uint32_t mk = 0;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ih = ih0 + t / 3, iw = iw0 + t % 3;
-                if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) mk |= 1u << t;
-            }
-            mask[i] = mk;
-        }
-    }
-    __device__ __forceinline__ void issue(Raw (&raw)[R], int kc) const {
-        const int tap = kc >> cpt_shift, cc = kc & cpt_mask;  // chunk cc = channels 32 cc .. 32 cc + 31: half (cc & 1) of slab cc >> 1
-        const int kh = tap / 3, kw = tap - kh * 3;
-        const int64_t koff = (int64_t)(kh * Win + kw) * pixb + (cc >> 1) * 256 + (cc & 1) * 64;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const bool ok = (mask[i] >> tap) & 1u;
-            const char *src = ok ? x + off[i] + koff : zeros;
-            raw[i].hi = *reinterpret_cast<const u32x2 *>(src);
-            raw[i].lo = *reinterpret_cast<const u32x2 *>(src + 128);
-        }
-    }
-    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {  // bit patterns: {hi.x, hi.y, lo.x, lo.y}
-#pragma unroll
-        for (int i = 0; i < R; ++i)
-            out[i] = f32x4{__uint_as_float(raw[i].hi[0]), __uint_as_float(raw[i].hi[1]), __uint_as_float(raw[i].lo[0]), __uint_as_float(raw[i].lo[1])};
-    }
-};
-
 // conv1 of Clair3_F straight from the int8 window (B, H, W, C), stride 2, pad 1, 3*C <= 32.
 // K is padded to 3 chunks (one per kh) of 32 slots: slot j = kw*C + c for j < 3C (weights are zero beyond);
 // the three input pixels (kw = 0..2) of one kh are 3C consecutive bytes starting at pixel (ih, iw0).
@@ -295,44 +211,6 @@ struct Conv1Loader {
     }
 };
 
-// Row-major integer matrix (the pileup window rows: M = B*33 rows of C counts), K padded to one 32-chunk
-// (the packed weights are zero for k >= C, so the clamped duplicates loaded there contribute nothing).
-template <typename T>
-struct IntRowLoaderParams {
-    const T *x;
-    int C;
-};
-template <int R, typename T>
-struct IntRowLoader {
-    typedef IntRowLoaderParams<T> Params;
-    struct Raw {
-        int v[4];
-    };
-    const T *row[R];
-    int C, lc4;
-    __device__ __forceinline__ void init(const Params &p, int m0, int lr, int lc, int M) {
-        C = p.C, lc4 = lc * 4;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            int m = m0 + lr + 32 * i;
-            if (m >= M) m = M - 1;
-            row[i] = p.x + (int64_t)m * p.C;
-        }
-    }
-    __device__ __forceinline__ void issue(Raw (&raw)[R], int) const {  // single chunk
-#pragma unroll
-        for (int i = 0; i < R; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) raw[i].v[e] = (int)row[i][lc4 + e < C ? lc4 + e : C - 1];
-    }
-    __device__ __forceinline__ void finish(const Raw (&raw)[R], f32x4 (&out)[R]) const {
-#pragma unroll
-        for (int i = 0; i < R; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[i][e] = (float)raw[i].v[e];
-    }
-};
-
 // Row-major fp32 matrix A[M][lda]; the K range [k0, k0 + 32*nk) is selected by the kernel (split-K).
 struct DenseLoaderParams {
     const float *a;
@@ -381,7 +259,7 @@ struct EpilogueParams {
 
 struct GemmParams {
     const float *bt;  // [N][ldb]
-    const uint16_t *bt3;  // SPLIT: the same weights as three bf16 pieces, [3][N][ldb]
+    const uint16_t *bt3;  // SPLIT: the same weights as two fp16 pieces, [2][N][ldb], times the per-tensor power of two
     int64_t ldb;
     int M, N;
     int nk;          // K chunks per block (per split)
@@ -389,16 +267,16 @@ struct GemmParams {
     int tiles;       // tiles_m * tiles_n
 };
 
-// ABL: ablation switches for tools/mfma_probe (0 in the product).  bit0: no global loads in the loop,
-// bit1: no LDS staging writes, bit2: no barrier, bit3: no LDS fragment reads (MFMAs on stale registers).
-template <class Loader, int EPI, int BM, int BN, int ABL = 0, int SPLIT = 0>
+// SPLIT = 0: fp32 operands on v_mfma_f32_32x32x2_f32 (the forms of the range-guard fallback); SPLIT = 2: fp16x3.
+template <class Loader, int EPI, int BM, int BN, int SPLIT = 0>
 __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Params lp, GemmParams gp,
                                                               EpilogueParams ep) {
     constexpr int RA = BM / 32, RBt = BN / 32;  // staged rows per thread
     constexpr int RB = BM / 64, CB = BN / 64;   // 32x32 accumulators per wave (rows x cols)
     // fp32: rows of 32 floats (128 B).  SPLIT: per operand NP piece planes with rows of 32 16-bit values (64 B);
-    // SPLIT 1 = bf16x6 (three bf16 pieces, six products), SPLIT 2 = fp16x3 (two fp16 pieces, three products).
-    constexpr int NP = SPLIT == 1 ? 3 : 2;
+    // (two fp16 pieces, three products).
+    static_assert(SPLIT == 0 || SPLIT == 2, "fp32 or fp16x3");
+    constexpr int NP = 2;
     constexpr int kRowB = SPLIT ? 64 : 128;
     constexpr int kPlaneA = BM * 64, kPlaneB = BN * 64;          // SPLIT: bytes of one piece plane
     constexpr int kStage = SPLIT ? NP * (kPlaneA + kPlaneB) : (BM + BN) * 128;  // bytes per LDS stage
@@ -462,12 +340,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 u32x2 pc[NP];
-                if constexpr (requires { Loader::kPlanes; }) {  // the loader delivered the two fp16 pieces themselves
-                    static_assert(SPLIT == 2, "plane activations are fp16 piece pairs");
-                    pc[0] = u32x2{__float_as_uint(av[i][0]), __float_as_uint(av[i][1])};
-                    pc[1] = u32x2{__float_as_uint(av[i][2]), __float_as_uint(av[i][3])};
-                } else if constexpr (SPLIT == 1) split3_bf16(av[i], pc);
-                else split2_f16(av[i], pc);
+                split2_f16(av[i], pc);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(dst + q * kPlaneA + st_off_a[i]) = pc[q];
             }
@@ -499,18 +372,6 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    // ABL bit6 (64, tools/mfma_probe only): workgroup 0 records the shader clock at phase boundaries into ep.res
-    int tr_n = 0;
-    auto trace = [&](int tag) __attribute__((always_inline)) {
-        if constexpr (ABL & 64) {
-            if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && tr_n < 250) {
-                long long *tb = reinterpret_cast<long long *>(const_cast<float *>(ep.res)) + ((threadIdx.x >> 6) * 256 + tr_n) * 2;
-                tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
-                ++tr_n;
-            }
-        }
-    };
-    trace(10);
     // Software pipeline over K chunks, two register stages + two LDS stages, branch-free body:
     //   iteration kc:  issue global loads of chunk kc+2          (-> rawB / rbB, land during this iteration)
     //                  write chunk kc+1 (loaded LAST iteration)   (rawA / rbA -> LDS[nxt], no wait needed)
@@ -538,20 +399,13 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         const char *cur = smem + (kc & 1) * kStage;
         char *nxt = smem + ((kc + 1) & 1) * kStage;
         const int k2 = kc + 2 < last ? kc + 2 : last;
-        if constexpr (!(ABL & 1)) {
-            loader.issue(rNext, k2);
-            load_b(bNext, k2);
-        }
+        loader.issue(rNext, k2);
+        load_b(bNext, k2);
         __builtin_amdgcn_sched_barrier(0);  // keep the global loads at the top: they must fly during the MFMAs
-        trace(1);  // global loads issued
-        if constexpr (!(ABL & 2)) {
-            loader.finish(rCur, ra);
-            stage(nxt, ra, bCur);
-        }
-
-        trace(2);  // previous chunk's registers staged to LDS (issue)
+        loader.finish(rCur, ra);
+        stage(nxt, ra, bCur);
         if constexpr (SPLIT) {
-            // two k-groups of 16; per group and 32x32 block the six piece products, smallest first.  Weights are the
+            // two k-groups of 16; per group and 32x32 block the three piece products, smallest first.  Weights are the
             // FIRST operand, as in the fp32 path: the accumulators hold the block transposed (see the epilogue).
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             u32x4 af[2][RB][NP], bf[2][CB][NP];
@@ -566,10 +420,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
                 }
             };
             auto mma = [&](f32x16 t, u32x4 w, u32x4 x) __attribute__((always_inline)) {
-                if constexpr (SPLIT == 1)
-                    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), t, 0, 0, 0);
-                else
-                    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), t, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), t, 0, 0, 0);
             };
             frags(0, af[0], bf[0]);
 #pragma unroll
@@ -580,33 +431,18 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
 #pragma unroll
                     for (int c = 0; c < CB; ++c) {
                         f32x16 t = acc[i][c];
-                        if constexpr (SPLIT == 1) {
-                            t = mma(t, bf[g][c][0], af[g][i][2]);
-                            t = mma(t, bf[g][c][1], af[g][i][1]);
-                            t = mma(t, bf[g][c][2], af[g][i][0]);
-                        }
                         t = mma(t, bf[g][c][0], af[g][i][1]);
                         t = mma(t, bf[g][c][1], af[g][i][0]);
                         t = mma(t, bf[g][c][0], af[g][i][0]);
                         acc[i][c] = t;
                     }
             }
-            trace(3);
-            if constexpr (!(ABL & 4)) __syncthreads();
-            trace(4);
+            __syncthreads();
             return;
         }
         // fragments of k-group g+1 are read from LDS while the MFMAs of group g run
         f32x4 a[2][RB], b[2][CB];
-        if constexpr (ABL & 8) {  // stale-register operands, kept opaque so nothing is folded away
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                for (int i = 0; i < RB; ++i) a[u][i] = ra[i];
-#pragma unroll
-                for (int i = 0; i < CB; ++i) b[u][i] = ra[i];
-            }
-        } else {
+        {
             const int coff = (fhi ^ fsw) << 4;
 #pragma unroll
             for (int i = 0; i < RB; ++i) a[0][i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
@@ -615,7 +451,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g < 3 && !(ABL & 8)) {
+            if (g < 3) {
                 const int coff = ((2 * (g + 1) + fhi) ^ fsw) << 4;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) a[(g + 1) & 1][i] = *reinterpret_cast<const f32x4 *>(cur + rd_a[i] + coff);
@@ -630,9 +466,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
                     for (int c = 0; c < CB; ++c)
                         acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][c][j], a[g & 1][i][j], acc[i][c], 0, 0, 0);
         }
-        trace(3);  // MFMAs issued
-        if constexpr (!(ABL & 4)) __syncthreads();
-        trace(4);
+        __syncthreads();
     };
     // unrolled by two so the register stages swap roles by name (no copies: a copy would be a use of the
     // in-flight loads and stall on them)
@@ -752,7 +586,6 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
     }
     if constexpr (SPLIT != 0 && EPI != EPI_PARTIAL)
         if (ep.range_flag && !(omax < kF16Range)) atomicOr(ep.range_flag, 1u);  // also taken for NaN
-    trace(12);  // epilogue stores issued
 }
 
 }  // namespace c3

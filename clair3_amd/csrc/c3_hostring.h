@@ -1,0 +1,352 @@
+// c3_hostring.h -- the host <-> device side of the model call: c3_predict (the reference's blocking _torch_predict,
+// clair3/CallVariantsFromCffi.py:48-52), its asynchronous pair c3_predict_submit / c3_predict_wait (a ring of C3_HOST_SLOTS
+// batches in flight: staging copy, H2D, kernels, D2H, range guard), the region form of the pileup call, zero-copy sources, and
+// the decoder entry points that take host rows.
+#pragma once
+#include "c3_forward.h"
+
+// ------------------------------------------------------------------------------------------ host staging
+// The caller's windows are pageable numpy memory (clair3/CallVariantsFromCffi.py:112-133: np.load slices); they go
+// through a pinned buffer, cut into pieces: the H2D transfer of a piece is queued as soon as it is staged, so the DMA of
+// piece i runs under the memcpy of piece i + 1, and every piece's memcpy is split over the staging pool (c3_host.h).
+// Buffers the caller has registered (c3_host_register: page-locked for the device) skip the staging copy altogether.
+struct HostRange {
+    const char *p;
+    size_t n;
+};
+static std::vector<HostRange> g_registered;
+static std::mutex g_registered_mu;
+static bool is_registered(const void *p, size_t n) {
+    std::lock_guard<std::mutex> lk(g_registered_mu);
+    for (const HostRange &r : g_registered)
+        if ((const char *)p >= r.p && (const char *)p + n <= r.p + r.n) return true;
+    return false;
+}
+
+// Small batches (the pileup network: 594 B per window in, 96 B out) cross PCIe inside the COMPUTE stream instead: a copy kernel
+// reads the pinned staging buffer / writes the pinned result buffer directly (both are device-mapped), so a batch is ONE chain
+// of launches on one queue -- no copy engine, no cross-queue event waits, whose barrier packets cost a 210 us pileup batch
+// ~60 us of idle GPU per batch.  The transfer is then serial with the kernels, which is only worth it while it is
+// short: up to kKernelCopyMax bytes (~15 us at PCIe Gen5 rates); full-alignment batches (23.5 MB) keep the DMA engines.
+constexpr size_t kKernelCopyMax = (size_t)2 << 20;
+__global__ __launch_bounds__(256) void host_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                       const uint32_t *flag_src, uint32_t *flag_dst) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (flag_dst && blockIdx.x == 0 && threadIdx.x == 0) *flag_dst = *flag_src;
+}
+
+// stage [src, src + bytes) through `pin` into `dev` on stream s, piecewise
+static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s, bool src_locked = false) {
+    if (src_locked || is_registered(src, bytes)) {  // zero-copy: the DMA engine reads the caller's pages
+        HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    // >= 4 MiB and at most four pieces: every queued transfer costs ~15 us of host time (2 MiB x 8 was slower again)
+    const size_t piece = std::max<size_t>((size_t)4 << 20, ((bytes / 4) + 4095) & ~(size_t)4095);
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t n = std::min(piece, bytes - off);
+        StagePool::get().copy((char *)pin + off, (const char *)src + off, n);
+        HIP_TRY(hipMemcpyAsync((char *)dev + off, (char *)pin + off, n, hipMemcpyHostToDevice, s));
+    }
+    return 0;
+}
+
+extern "C" {
+
+static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
+    if (!sl.ev_h2d) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_compute, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+    if (!sl.pin_flag) HIP_TRY(hipHostMalloc((void **)&sl.pin_flag, 64, hipHostMallocDefault));
+    if (xb > sl.cap_x) {
+        if (sl.pin_x) (void)hipHostFree(sl.pin_x);
+        if (sl.dev_x) (void)hipFree(sl.dev_x);
+        sl.pin_x = sl.dev_x = nullptr, sl.cap_x = 0;
+        HIP_TRY(hipHostMalloc(&sl.pin_x, xb, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&sl.dev_x, xb));
+        sl.cap_x = xb;
+    }
+    if (yb > sl.cap_y) {
+        if (sl.pin_y) (void)hipHostFree(sl.pin_y);
+        if (sl.dev_y) (void)hipFree(sl.dev_y);
+        sl.pin_y = nullptr, sl.dev_y = nullptr, sl.cap_y = 0;
+        HIP_TRY(hipHostMalloc((void **)&sl.pin_y, yb, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&sl.dev_y, yb));
+        sl.cap_y = yb;
+    }
+    (void)m;
+    return 0;
+}
+
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked);
+int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
+    return predict_submit(m, x_host, x_dtype, batch, y_host, slot, false);
+}
+// src_locked: the caller (c3_predict) has page-locked x_host for the duration of ITS call -- a private fact of that call, not
+// published in g_registered, so no other thread or handle ever DMAs from pages that are about to be unlocked
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked) {
+    if (!m) return fail("null model");
+    if (slot < 0 || slot >= kHostSlots) return fail("slot must be in [0, %d)", kHostSlots);
+    if (batch < 0) return fail("negative batch");
+    if (batch > 0 && (!x_host || !y_host)) return fail("null buffer");
+    HostSlot &sl = m->slot[slot];
+    if (sl.busy) return fail("slot %d still in flight: call c3_predict_wait first", slot);
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->loaded) return fail("model has no weights: call c3_model_load first");
+    const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
+    const size_t yb = (size_t)batch * m->row * sizeof(float);
+    if (batch > 0 && m->host_copy_kernel && xb <= kKernelCopyMax && yb <= kKernelCopyMax && !src_locked && !is_registered(x_host, xb)) {
+        TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, (yb + 255) & ~(size_t)255));
+        memcpy(sl.pin_x, x_host, xb);
+        hipLaunchKernelGGL(host_copy_kernel, dim3(128), dim3(256), 0, m->stream, (const uint4 *)sl.pin_x, (uint4 *)sl.dev_x, (xb + 15) / 16,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+        const bool f16 = m->f16_ok;
+        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
+        hipLaunchKernelGGL(host_copy_kernel, dim3(32), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
+                           (const uint32_t *)m->range_flag, sl.pin_flag);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
+        sl.used_f16 = f16;
+    } else
+    if (batch > 0) {
+        // the slot becomes busy only once everything has been queued: a failure on the way leaves it free
+        TRY(ensure_slot(m, sl, xb, yb));
+        TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream, src_locked));
+        HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
+        HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
+        const bool f16 = m->f16_ok;
+        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
+        HIP_TRY(hipEventRecord(sl.ev_compute, m->stream));
+        HIP_TRY(hipStreamWaitEvent(m->d2h_stream, sl.ev_compute, 0));
+        HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->d2h_stream));
+        HIP_TRY(hipMemcpyAsync(sl.pin_flag, m->range_flag, 4, hipMemcpyDeviceToHost, m->d2h_stream));
+        HIP_TRY(hipEventRecord(sl.ev_out, m->d2h_stream));
+        sl.used_f16 = f16;
+    }
+    sl.y_host = y_host, sl.y_bytes = yb, sl.batch = batch, sl.x_dtype = x_dtype, sl.busy = true;
+    return 0;
+}
+
+int c3_predict_wait(c3_model *m, int slot) {
+    if (!m) return fail("null model");
+    if (slot < 0 || slot >= kHostSlots) return fail("slot must be in [0, %d)", kHostSlots);
+    HostSlot &sl = m->slot[slot];
+    if (!sl.busy) return fail("slot %d has nothing in flight", slot);
+    sl.busy = false;
+    if (sl.y_bytes == 0) return 0;
+    HIP_TRY(hipEventSynchronize(sl.ev_out));
+    if (sl.used_f16) {
+        // Safety net of the fp16x3 products, per batch: what matters is how THIS slot's rows were computed, not what the
+        // handle does now (another slot's wait may have switched it to fp32 while this batch was in flight).  An
+        // activation beyond the fp16 range (|x| >= 65504; never seen) surfaces as inf / NaN rows or as the
+        // range flag (sticky: an overflow in any earlier fp16x3 batch also lands here, which only costs a re-run).
+        const uint32_t *u = reinterpret_cast<const uint32_t *>(sl.pin_y);
+        bool bad = *sl.pin_flag != 0;  // a conv stage produced a value near the fp16 range (kF16Range): its consumers may have overflowed
+        for (size_t i = 0, n = sl.y_bytes / 4; i < n; ++i) bad |= (u[i] & 0x7f800000u) == 0x7f800000u;
+        if (bad) {
+            if (m->f16_ok)
+                fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
+            m->f16_ok = false;
+            TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.dev_y));
+            HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, sl.y_bytes, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+    }
+    memcpy(sl.y_host, sl.pin_y, sl.y_bytes);
+    return 0;
+}
+
+// The synchronous call of the reference loop (_torch_predict: H2D, forward, D2H one after the other,
+// clair3/CallVariantsFromCffi.py:48-52).  A batch well beyond one chunk (256 full-alignment / 4096 pileup windows; env
+// C3HIP_PREDICT_CHUNK) is cut into chunks that travel through the submit / wait ring: the staging copy and H2D transfer of chunk
+// i + 1 and the D2H transfer of chunk i - 1 run under the kernels of chunk i, so the caller's ONE blocking call costs little more
+// than the kernels of the whole batch.  Rows do not depend on the cut (a window's row is independent of the batch it travels in).
+static int64_t predict_chunk(const c3_model *m) {
+    static const int64_t env = getenv("C3HIP_PREDICT_CHUNK") ? atoll(getenv("C3HIP_PREDICT_CHUNK")) : -1;
+    if (env >= 0) return env;  // 0: never cut
+    return m->kind == C3_KIND_PILEUP ? 4096 : 256;
+}
+
+int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host) {
+    if (!m) return fail("null model");
+    const int64_t chunk = predict_chunk(m);
+    if (chunk <= 0 || batch < 2 * chunk) {
+        TRY(c3_predict_submit(m, x_host, x_dtype, batch, y_host, 0));
+        return c3_predict_wait(m, 0);
+    }
+    constexpr int kRing = 3;
+    const int64_t wbytes = c3_model_window_bytes(m, x_dtype);
+    // A blocking call cannot hide its staging copy behind a previous batch, and that copy (pageable -> pinned, ~16 GB/s with the
+    // staging pool) is as long as the kernels of a full-alignment batch.  So the caller's pages are page-locked for the duration of
+    // the call (~0.1 ms per 24 MB, hipHostRegister) and the DMA engine reads them directly; if the range cannot be registered
+    // (e.g. a read-only mapping) the chunks go through the staging buffer as before.
+    const size_t xbytes = (size_t)(batch * wbytes);
+    void *reg_base = nullptr;
+    if (xbytes >= ((size_t)4 << 20) && !is_registered(x_host, xbytes)) {
+        const uintptr_t lo = (uintptr_t)x_host & ~(uintptr_t)4095, hi = ((uintptr_t)x_host + xbytes + 4095) & ~(uintptr_t)4095;
+        (void)hipSetDevice(m->device);
+        if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+            reg_base = (void *)lo;
+        } else {
+            (void)hipGetLastError();  // not fatal: staged copy
+        }
+    }
+    int64_t n_sub = 0, n_done = 0;  // chunks submitted / waited for
+    int rc = 0;
+    // chunk sizes grow (chunk / 2, chunk, 2 chunk, 4 chunk, 4 chunk, ...): the kernels start after a SHORT first transfer, the
+    // later, longer transfers hide under ever longer kernel runs, and big chunks fill the chip better than small ones; a tail
+    // shorter than half the next size joins the last chunk
+    int64_t next = std::max<int64_t>(chunk / 2, 1);
+    for (int64_t off = 0; off < batch && rc == 0; ++n_sub) {
+        int64_t take = std::min(next, batch - off);
+        if (batch - off - take < next / 2 || batch - off - take < chunk / 2) take = batch - off;
+        take = std::min(take, max_microbatch(m));
+        if (n_sub - n_done == kRing) rc = c3_predict_wait(m, (int)(n_done++ % kRing));
+        if (rc == 0)
+            rc = predict_submit(m, (const char *)x_host + off * wbytes, x_dtype, take, y_host + off * m->row, (int)(n_sub % kRing),
+                                reg_base != nullptr);
+        if (rc != 0) break;
+        off += take;
+        next = std::min(2 * next, 4 * chunk);
+    }
+    const std::string first_error = rc != 0 ? g_err : std::string();
+    for (; n_done < n_sub; ++n_done) {  // drain, also after an error: no slot stays busy behind a failed call
+        const int r = c3_predict_wait(m, (int)(n_done % kRing));
+        if (rc == 0) rc = r;
+    }
+    if (reg_base) (void)hipHostUnregister(reg_base);  // every chunk has been waited for: nothing reads the pages any more
+    if (!first_error.empty()) g_err = first_error;
+    return rc;
+}
+
+int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, int64_t n_cols, const int32_t *starts_host,
+                             int64_t batch, float *y_host) {
+    if (!m) return fail("null model");
+    if (m->kind != C3_KIND_PILEUP) return fail("c3_predict_pileup_region needs a pileup model");
+    if (batch < 0 || n_cols < 0) return fail("negative size");
+    if (batch == 0) return 0;
+    if (!region_host || !starts_host || !y_host) return fail("null buffer");
+    if (x_dtype != C3_DTYPE_I8 && x_dtype != C3_DTYPE_I32 && x_dtype != C3_DTYPE_I64)
+        return fail("pileup regions must be int8, int32 or int64 / size_t (got dtype %d)", x_dtype);
+    // int64 = plp_data.matrix itself (size_t counts, src/clair3_pileup.h:113): narrowed to int32 on its way into the staging
+    // buffer, which is what the reference's PIPE mode feeds the model (CreateTensorPileupFromCffi.py:143-146 -> int32 windows)
+    const bool narrow = x_dtype == C3_DTYPE_I64;
+    if (narrow) x_dtype = C3_DTYPE_I32;
+    for (int64_t i = 0; i < batch; ++i)
+        if (starts_host[i] < 0 || (int64_t)starts_host[i] + m->positions > n_cols)
+            return fail("window %lld starts at column %d: outside the %lld-column region", (long long)i, starts_host[i], (long long)n_cols);
+    HostSlot &sl = m->slot[0];
+    if (sl.busy) return fail("slot 0 still in flight: call c3_predict_wait first");
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->loaded) return fail("model has no weights: call c3_model_load first");
+    const size_t item = x_dtype == C3_DTYPE_I32 ? 4 : 1;
+    const size_t rb = ((size_t)n_cols * m->C * item + 255) & ~(size_t)255;
+    const size_t sb = (size_t)batch * sizeof(int32_t);
+    const size_t yb = (size_t)batch * m->row * sizeof(float);
+    TRY(ensure_slot(m, sl, rb + sb, yb));
+    if (narrow) {
+        const int64_t *src = static_cast<const int64_t *>(region_host);
+        int32_t *dst = static_cast<int32_t *>(sl.pin_x);
+        for (size_t i = 0, e = (size_t)n_cols * m->C; i < e; ++i) dst[i] = (int32_t)src[i];
+    } else {
+        memcpy(sl.pin_x, region_host, (size_t)n_cols * m->C * item);
+    }
+    memcpy((char *)sl.pin_x + rb, starts_host, sb);
+    HIP_TRY(hipMemcpyAsync(sl.dev_x, sl.pin_x, rb + sb, hipMemcpyHostToDevice, m->stream));
+    TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y, (const int32_t *)((char *)sl.dev_x + rb)));
+    HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    memcpy(y_host, sl.pin_y, yb);
+    return 0;
+}
+
+int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uint8_t *ref21_host, float *maxp_host,
+                      int32_t *argmax_host, uint8_t *early_host) {
+    if (!m) return fail("null model");
+    if (batch < 0) return fail("negative batch");
+    if (batch == 0) return 0;
+    if (!y_host || !ref21_host || !maxp_host || !argmax_host || !early_host) return fail("null buffer");
+    for (int64_t i = 0; i < batch; ++i)
+        if (ref21_host[i] != 0 && ref21_host[i] != 4 && ref21_host[i] != 7 && ref21_host[i] != 9)
+            return fail("row %lld: reference gt21 index %d is not one of AA=0, CC=4, GG=7, TT=9", (long long)i, (int)ref21_host[i]);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t yb = (size_t)batch * m->nout * sizeof(float), rb = ((size_t)batch + 255) & ~(size_t)255;
+    const size_t mb = (size_t)batch * kDecodeClasses * sizeof(float);
+    const size_t total = yb + rb + 2 * mb + rb;
+    if (m->decode_bytes < total) {
+        if (m->decode_dev) (void)hipFree(m->decode_dev);
+        m->decode_dev = nullptr, m->decode_bytes = 0;
+        HIP_TRY(hipMalloc(&m->decode_dev, total));
+        m->decode_bytes = total;
+    }
+    char *base = (char *)m->decode_dev;
+    float *y = (float *)base;
+    uint8_t *ref = (uint8_t *)(base + yb);
+    float *maxp = (float *)(base + yb + rb);
+    int32_t *arg = (int32_t *)(base + yb + rb + mb);
+    uint8_t *early = (uint8_t *)(base + yb + rb + 2 * mb);
+    HIP_TRY(hipMemcpyAsync(y, y_host, yb, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(ref, ref21_host, (size_t)batch, hipMemcpyHostToDevice, m->stream));
+    DecodeParams dp{y, m->nout, ref, maxp, arg, early, nullptr, (int)batch, m->nout == 90 ? 1 : 0};
+    hipLaunchKernelGGL(outcome_maxima_kernel<false>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(maxp_host, maxp, mb, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(argmax_host, arg, mb, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(early_host, early, (size_t)batch, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *rows_host) {
+    if (!m) return fail("null model");
+    if (batch < 0) return fail("negative batch");
+    if (batch == 0) return 0;
+    if (!y_host || !rows_host) return fail("null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const int wide = m->nout + kDecodeCols;
+    const size_t total = (size_t)batch * wide * sizeof(float);
+    if (m->decode_bytes < total) {
+        if (m->decode_dev) (void)hipFree(m->decode_dev);
+        m->decode_dev = nullptr, m->decode_bytes = 0;
+        HIP_TRY(hipMalloc(&m->decode_dev, total));
+        m->decode_bytes = total;
+    }
+    float *rows = (float *)m->decode_dev;
+    HIP_TRY(hipMemcpy2DAsync(rows, (size_t)wide * sizeof(float), y_host, (size_t)m->nout * sizeof(float),
+                             (size_t)m->nout * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->stream));
+    DecodeParams dp{rows, wide, nullptr, nullptr, nullptr, nullptr, rows + m->nout, (int)batch, m->nout == 90 ? 1 : 0};
+    hipLaunchKernelGGL(outcome_maxima_kernel<true>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rows_host, rows, total, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int c3_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return fail("null buffer");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lk(g_registered_mu);
+    g_registered.push_back({(const char *)p, bytes});
+    return 0;
+}
+
+int c3_host_unregister(void *p) {
+    {
+        std::lock_guard<std::mutex> lk(g_registered_mu);
+        bool found = false;
+        for (size_t i = 0; i < g_registered.size(); ++i)
+            if (g_registered[i].p == (const char *)p) {
+                g_registered.erase(g_registered.begin() + i);
+                found = true;
+                break;
+            }
+        if (!found) return fail("buffer was not registered with c3_host_register");
+    }
+    HIP_TRY(hipHostUnregister(p));
+    return 0;
+}
+
+}  // extern "C"

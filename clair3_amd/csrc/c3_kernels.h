@@ -19,22 +19,8 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 // ------------------------------------------------------------------------------- LSTM recurrence
 // One workgroup = 16 windows x one direction, all T steps (clair3/model.py:132-133, torch.nn.LSTM:
 // gates = W_ih x_t + b_ih + W_hh h_{t-1} + b_hh, rows i,f,g,o; c' = s(f)c + s(i)tanh(g); h' = s(o)tanh(c')).
-// The x-projection (+ both biases) of every step was hoisted into one big MFMA GEMM (gx); this kernel adds
-// the recurrent term with v_mfma_f32_16x16x4_f32 and applies the cell.
-//   * wave w owns hidden units [16w, 16w+16) and keeps their 4 gate blocks as 4 accumulators, so the
-//     i/f/g/o values of one (window, unit) sit in the same lane and register index: no cross-lane traffic;
-//   * h_{t-1} (16 x H) is exchanged between the H/16 waves through a double-buffered LDS tile
-//     (row stride H+4 floats -> conflict-free ds_read_b128), one barrier per step;
-//   * W_hh is read as pre-packed MFMA B fragments, 1 KiB per wave-instruction, fully coalesced; it is
-//     L2-resident (<= 400 KiB per direction) and re-streamed every step;
-//   * the cell state c stays in registers for all T steps.
-struct LstmParams {
-    const float *gx;   // [B*T][ld_gx]; column = dir*4H + wave*64 + gate*16 + unit
-    const float *whh;  // [dir][wave][gate][q = H/16][lane][4]
-    float *hout;       // [B][T][2H]; column = dir*H + unit
-    int B, T;
-    int64_t ld_gx;
-};
+// The x-projection (+ both biases) of every step is hoisted into one matrix product (gx2, c3_dense.h); the kernel below adds
+// the recurrent term on the matrix cores and applies the cell; the cell state c stays in registers for all T steps.
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -78,116 +64,7 @@ __device__ __forceinline__ f32x2g pk_lstm_cell(f32x2g gi, f32x2g gf, f32x2g gg, 
     return og * pk_tanh(c);
 }
 
-// RESIDENT: keep this wave's W_hh fragments (4 gates x H/16 k-groups = H registers) in VGPRs for all T steps
-// (H = 128: 8 waves x 2 per SIMD fit the 512-entry file).  Otherwise stream them from L2 every step through
-// a 2-deep register ring so the loads of k-group q+1 fly while the MFMAs of group q issue.
-template <int H, bool RESIDENT>
-__global__ __launch_bounds__(H * 4) void lstm_recurrent_kernel(LstmParams p) {
-    constexpr int NW = H / 16;   // waves
-    constexpr int NQ = H / 16;   // k groups of 16
-    constexpr int LDH = H + 4;   // LDS row stride (floats)
-    __shared__ __attribute__((aligned(16))) float hbuf[2][16][LDH];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = lane >> 4, col = lane & 15;
-    const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * 16;
-
-    for (int i = tid; i < 16 * LDH; i += NW * 64) (&hbuf[0][0][0])[i] = 0.f;
-
-    const float *wbase = p.whh + ((int64_t)(dir * NW + wave) * 4 * NQ * 64 + lane) * 4;
-    const int gx_col = dir * 4 * H + wave * 64 + col;
-    const int h_col = dir * H + wave * 16 + col;
-
-    f32x4v wres[RESIDENT ? 4 * NQ : 1];
-    if constexpr (RESIDENT) {
-#pragma unroll
-        for (int i = 0; i < 4 * NQ; ++i) wres[i] = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)i * 256);
-    }
-
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
-    bool rowok[4];
-    int64_t rowbase[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        int b = b0 + 4 * s + v;
-        rowok[v] = b < p.B;
-        if (!rowok[v]) b = p.B - 1;
-        rowbase[v] = (int64_t)b * p.T;
-    }
-    // x-projection (+ both biases) of the first step
-    f32x4v gxn[4];
-    {
-        const int t0 = dir ? p.T - 1 : 0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) gxn[g][v] = p.gx[(rowbase[v] + t0) * p.ld_gx + gx_col + g * 16];
-    }
-    __syncthreads();
-
-    for (int step = 0; step < p.T; ++step) {
-        const int t = dir ? p.T - 1 - step : step;
-        const int cur = step & 1;
-        f32x4v acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = gxn[g];
-        if (step + 1 < p.T) {  // next step's projection: in flight during this step's MFMAs
-            const int tn = dir ? t - 1 : t + 1;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) gxn[g][v] = p.gx[(rowbase[v] + tn) * p.ld_gx + gx_col + g * 16];
-        }
-        if (step > 0) {  // h_{-1} = 0
-            if constexpr (RESIDENT) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    // A fragment: rows = windows (lane&15), k = 16q + 4s + e
-                    const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wres[g * NQ + q][e], acc[g], 0, 0, 0);
-                }
-            } else {
-                f32x4v wb[2][4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) wb[0][g] = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)(g * NQ) * 256);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (q + 1 < NQ) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            wb[(q + 1) & 1][g] = *reinterpret_cast<const f32x4v *>(wbase + (int64_t)(g * NQ + q + 1) * 256);
-                    }
-                    const f32x4v a = *reinterpret_cast<const f32x4v *>(&hbuf[cur][col][16 * q + 4 * s]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wb[q & 1][g][e], acc[g], 0, 0, 0);
-                }
-            }
-        }
-        // cell update.  C/D map of 16x16x4: col = lane&15 (unit), row = 4*(lane>>4) + v (window)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float ig = fast_sigmoid(acc[0][v]);
-            const float fg = fast_sigmoid(acc[1][v]);
-            const float gg = fast_tanh(acc[2][v]);
-            const float og = fast_sigmoid(acc[3][v]);
-            c[v] = fg * c[v] + ig * gg;
-            const float h = og * fast_tanh(c[v]);
-            hbuf[cur ^ 1][4 * s + v][wave * 16 + col] = h;
-            if (rowok[v]) p.hout[(rowbase[v] + t) * (2 * H) + h_col] = h;
-        }
-        lds_barrier();
-    }
-}
-
-// Variant for hidden sizes whose 16-unit blocks do not divide evenly over the SIMDs (H = 160: 10 blocks).
+// H = 160 gives 10 unit blocks, which do not divide evenly over the SIMDs.
 // The 4H/16 gate-column blocks (natural PyTorch order n = gate*H + unit) are dealt evenly to 8 waves
 // (H/32 blocks each), which balances the matrix pipes exactly and lets EVERY wave keep its W_hh fragments
 // resident (H/32 * H/16 * 4 = 200 VGPRs at H = 160: the whole 400 KiB matrix lives in the CU's register file
@@ -474,54 +351,7 @@ struct SppParams {
     // padding added by F.pad (model.py:267-268), in which case 0 takes part in the max.
     short h0[16], h1[16], w0[16], w1[16], pad[16];
 };
-// Compile-time geometry (ONT: 12 x 5 after the third stride-2 stage): the H*W loads of one (window, channel)
-// are fully unrolled -- 60 independent, channel-coalesced loads in flight per thread -- and every bin test
-// folds to a constant, leaving three v_max per value (one per pyramid level).
-template <int H, int W>
-__global__ __launch_bounds__(256) void spp_kernel_fixed(const float *__restrict__ in, float *__restrict__ out, int B, int C) {
-    constexpr int P[3] = {3, 2, 1};
-    constexpr int NB0 = ((H + (H + 2) / 3 - 1) / ((H + 2) / 3)) * ((W + (W + 2) / 3 - 1) / ((W + 2) / 3));
-    constexpr int NB1 = ((H + (H + 1) / 2 - 1) / ((H + 1) / 2)) * ((W + (W + 1) / 2 - 1) / ((W + 1) / 2));
-    constexpr int NBINS = NB0 + NB1 + 1;
-    const int64_t total = (int64_t)B * C;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int64_t b = i / C;
-        const float *src = in + b * H * W * C + c;
-        float v[H * W];
-#pragma unroll
-        for (int k = 0; k < H * W; ++k) v[k] = src[(int64_t)k * C];
-        float m[NBINS];
-        int base = 0;
-#pragma unroll
-        for (int pi = 0; pi < 3; ++pi) {
-            const int p = P[pi];
-            const int wh = (H + p - 1) / p, ww = (W + p - 1) / p;
-            const int ohn = (H + wh - 1) / wh, own = (W + ww - 1) / ww;
-            const int pad_h = ohn * wh - H > 0 ? ohn * wh - H : 0, pad_w = own * ww - W > 0 ? own * ww - W : 0;
-            const int pt = pad_h / 2, pl = pad_w / 2;
-#pragma unroll
-            for (int oh = 0; oh < ohn; ++oh)
-#pragma unroll
-                for (int ow = 0; ow < own; ++ow) {
-                    const int a0 = oh * wh - pt, a1 = a0 + wh, c0 = ow * ww - pl, c1 = c0 + ww;
-                    const bool padded = a0 < 0 || a1 > H || c0 < 0 || c1 > W;  // F.pad zeros take part in the max
-                    float mm = padded ? 0.f : -INFINITY;
-#pragma unroll
-                    for (int h = (a0 < 0 ? 0 : a0); h < (a1 > H ? H : a1); ++h)
-#pragma unroll
-                        for (int w = (c0 < 0 ? 0 : c0); w < (c1 > W ? W : c1); ++w) mm = fmaxf(mm, v[h * W + w]);
-                    m[base + oh * own + ow] = mm;
-                }
-            base += ohn * own;
-        }
-        float *dst = out + b * NBINS * C + c;
-#pragma unroll
-        for (int k = 0; k < NBINS; ++k) dst[(int64_t)k * C] = m[k];
-    }
-}
-
-// generic geometry fallback (bins described at run time)
+// bins described at run time (spp_bins in the host code); the fp32-activation form of the range-guard fallback
 __global__ __launch_bounds__(256) void spp_kernel(SppParams p) {
     const int64_t total = (int64_t)p.B * p.nbins * p.C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -533,112 +363,6 @@ __global__ __launch_bounds__(256) void spp_kernel(SppParams p) {
         for (int h = p.h0[bin]; h < p.h1[bin]; ++h)
             for (int w = p.w0[bin]; w < p.w1[bin]; ++w) m = fmaxf(m, src[((int64_t)h * p.W + w) * p.C]);
         p.out[i] = m;
-    }
-}
-
-// ------------------------------------------------------------------------------- FC tail
-// clair3/model.py:136-159 (pileup) / 391-414 (full alignment), dropout = identity in eval():
-//   x  = selu(sum_s part[s] + L4.bias)                  (deterministic split-K reduction of the L4 GEMM)
-//   h_b = selu(L5_b x + b5_b)           b = 0..NB-1
-//   y_b = softmax(selu(head_b h_b + bh_b))              heads 21 / 3 / 33 / 33, written concatenated.
-struct TailParams {
-    const float *part;  // [S][B][FC]
-    const float *b4;    // [FC]
-    const float *w5t;   // [FC][NB*128]
-    const float *b5;    // [NB*128]
-    const float *wh;    // [NB][128][64]  (head columns zero-padded to 64)
-    const float *bh;    // [NB][64]
-    float *y;           // [B][ldy]: nout probabilities at the start of every row
-    float *l4_dbg;      // optional [B][FC]
-    int B, S, NB, nout, ldy;
-};
-constexpr int kTailWindows = 2;  // windows per workgroup: B/2 workgroups keep every CU busy at B >= 512
-
-template <int FC>
-__global__ __launch_bounds__(256) void fc_tail_kernel(TailParams p) {
-    constexpr int TB = kTailWindows;
-    __shared__ float xs[TB][FC];
-    __shared__ float h5[TB][4 * 128];
-    __shared__ float lg[TB][96];
-    const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * TB;
-    // label_shape = 21, 3, 33, 33 (shared/param_p.py:37); ternaries instead of arrays keep these in SGPRs
-    auto head_n = [](int br) { return br == 0 ? 21 : br == 1 ? 3 : 33; };
-    auto head_off = [](int br) { return br == 0 ? 0 : br == 1 ? 21 : br == 2 ? 24 : 57; };
-
-    // 1. deterministic split-K reduction (fixed order s = 0..S-1) + bias + SELU
-    for (int i = tid; i < TB * FC; i += 256) {
-        const int t = i / FC, k = i - t * FC;
-        const int b = b0 + t < p.B ? b0 + t : p.B - 1;
-        const float *src = p.part + (int64_t)b * FC + k;
-        const int64_t sstride = (int64_t)p.B * FC;
-        float v = p.b4[k];
-        int s = 0;
-        for (; s + 4 <= p.S; s += 4) {  // 4 independent loads in flight, summed in order
-            const float v0 = src[(s + 0) * sstride], v1 = src[(s + 1) * sstride];
-            const float v2 = src[(s + 2) * sstride], v3 = src[(s + 3) * sstride];
-            v = (((v + v0) + v1) + v2) + v3;
-        }
-        for (; s < p.S; ++s) v += src[s * sstride];
-        v = selu_f(v);
-        if (p.l4_dbg && b0 + t < p.B) p.l4_dbg[(int64_t)b * FC + k] = v;
-        xs[t][k] = v;
-    }
-    __syncthreads();
-
-    // 2. the NB branch layers as one [FC] x [NB*128] product; weights are read coalesced, 8 k per batch of loads
-    const int n5 = p.NB * 128;
-    for (int j = tid; j < n5; j += 256) {
-        float acc[TB];
-#pragma unroll
-        for (int t = 0; t < TB; ++t) acc[t] = p.b5[j];
-        const float *w = p.w5t + j;
-        for (int k = 0; k < FC; k += 32) {  // 32 independent coalesced weight loads in flight per thread
-            float wv[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) wv[u] = w[(int64_t)(k + u) * n5];
-#pragma unroll
-            for (int u = 0; u < 32; ++u)
-#pragma unroll
-                for (int t = 0; t < TB; ++t) acc[t] = fmaf(xs[t][k + u], wv[u], acc[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < TB; ++t) h5[t][j] = selu_f(acc[t]);
-    }
-    __syncthreads();
-
-    // 3. heads (block diagonal: head b reads branch b) + SELU
-    for (int i = tid; i < TB * p.nout; i += 256) {
-        const int t = i / p.nout, o = i - t * p.nout;
-        const int br = o < 21 ? 0 : o < 24 ? 1 : o < 57 ? 2 : 3;
-        const int idx = o - head_off(br);
-        float acc = p.bh[br * 64 + idx];
-        const float *w = p.wh + (int64_t)br * 128 * 64 + idx;
-        const float *h = &h5[t][br * 128];
-        for (int k = 0; k < 128; k += 32) {
-            float wv[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) wv[u] = w[(k + u) * 64];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) acc = fmaf(h[k + u], wv[u], acc);
-        }
-        lg[t][o] = selu_f(acc);
-    }
-    __syncthreads();
-
-    // 4. soft-max per (window, head)
-    for (int i = tid; i < TB * p.NB; i += 256) {
-        const int t = i / p.NB, br = i - t * p.NB;
-        const int b = b0 + t;
-        if (b >= p.B) continue;
-        const float *l = &lg[t][head_off(br)];
-        const int n = head_n(br);
-        float m = l[0];
-        for (int k = 1; k < n; ++k) m = fmaxf(m, l[k]);
-        float sum = 0.f;
-        for (int k = 0; k < n; ++k) sum += expf(l[k] - m);
-        float *y = p.y + (int64_t)b * p.ldy + head_off(br);
-        for (int k = 0; k < n; ++k) y[k] = expf(l[k] - m) / sum;
     }
 }
 

@@ -1,0 +1,303 @@
+// c3_model.h -- the model handle of libc3hip.so and the helpers every host-side unit shares: error convention, device
+// memory, the profiling scope, the launch wrapper of the tiled contraction.
+//
+// The host side of the library is one translation unit (c3_model.hip) made of:
+//   c3_model.h     this file
+//   c3_pack.h      c3_model_load: BatchNorm folding, gate re-ordering, matrix-instruction fragment layouts, fp16 pieces
+//   c3_forward.h   the launch sequences of the two forward passes (clair3/model.py:130-161 and :377-416)
+//   c3_hostring.h  the host <-> device ring behind c3_predict / c3_predict_submit / _wait (staging, transfers, range guard)
+//   c3_comm.h      the gather of a sharded job on RCCL
+//   c3_debug.h     c3_debug_* / c3_profile_* (parity tests, bench.py)
+//   c3_model.hip   create / geometry / device-resident entries / describe / destroy
+// Every layer has exactly two forms: the product (fp16x3 split products on the 16-bit matrix instructions) and
+// one fp32-MFMA form that the range guard falls back to (and that C3HIP_FP32=1 selects from the start).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/c3hip.h"
+#include "c3_gemm.h"
+#include "c3_kernels.h"
+#include "c3_conv1.h"
+#include "c3_tail.h"
+#include "c3_decode.h"
+#include "c3_lstm_fused.h"
+#include "c3_host.h"
+#include "c3_conv3.h"
+#include "c3_dense.h"
+
+using namespace c3;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define TRY(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ model
+static const int kHeadN[4] = {21, 3, 33, 33};
+static const char *kHeadName[4] = {"Y_gt21_logits", "Y_genotype_logits", "Y_indel_length_logits_1",
+                                   "Y_indel_length_logits_2"};
+static const char *kConvName[9] = {"conv1.conv",         "res_block1.0.conv1", "res_block1.0.conv2",
+                                   "conv3.conv",         "res_block2.0.conv1", "res_block2.0.conv2",
+                                   "conv5.conv",         "res_block3.0.conv1", "res_block3.0.conv2"};
+static const char *kBnName[9] = {"conv1.bn",         "res_block1.0.bn1", "res_block1.0.bn2",
+                                 "conv3.bn",         "res_block2.0.bn1", "res_block2.0.bn2",
+                                 "conv5.bn",         "res_block3.0.bn1", "res_block3.0.bn2"};
+static const int kConvCout[9] = {64, 64, 64, 128, 128, 128, 256, 256, 256};
+static const int kConvStride[9] = {2, 1, 1, 2, 1, 1, 2, 1, 1};
+static const char *kFaLayerTag[9] = {"fa.conv1", "fa.res1a", "fa.res1b", "fa.conv3", "fa.res2a",
+                                     "fa.res2b", "fa.conv5", "fa.res3a", "fa.res3b"};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+    double flops, bytes;
+    double mfma_flops = 0.0;  // FLOP the matrix instructions of the launch EXECUTE (tile padding, piece products included)
+    double mfma_peak = 0.0;   // dense peak (TFLOP/s) of the matrix instruction the launch issues: 2500 (16-bit) or 157.3 (fp32)
+};
+
+struct HostSlot {
+    void *pin_x = nullptr;
+    float *pin_y = nullptr;
+    void *dev_x = nullptr;
+    float *dev_y = nullptr;
+    size_t cap_x = 0, cap_y = 0;
+    hipEvent_t ev_h2d = nullptr, ev_compute = nullptr, ev_out = nullptr;
+    float *y_host = nullptr;
+    size_t y_bytes = 0;
+    int64_t batch = 0;  // what is in flight (for the fp32 re-run of c3_predict_wait)
+    uint32_t *pin_flag = nullptr;  // pinned copy of the model's range_flag after this batch
+    int x_dtype = 0;
+    bool busy = false;
+    bool used_f16 = false;  // the batch in flight was computed by the fp16x3 kernels (c3_predict_wait then checks its range)
+};
+
+constexpr int kHostSlots = 4;  // batches in flight per handle through c3_predict_submit / _wait (C3_HOST_SLOTS)
+
+struct c3_model {
+    int kind = 0, C = 0, add_indel = 0, device = 0;
+    int depth = 89, positions = 33;
+    int nb = 2, nout = 24;
+    int row = 24;  // floats per output row: nout, + kDecodeCols when c3_model_set_decode_columns is on
+    bool loaded = false;
+    hipStream_t stream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;
+
+    // ---- packed weights (device) ----
+    // pileup
+    float *proj_w[2] = {nullptr, nullptr};  // LSTM input projections [2*4H][Kp] fp32 (layer 1: the fp32 form of the LSTM2 projection)
+    float *proj_b[2] = {nullptr, nullptr};  // [2*4H], b_ih + b_hh
+    float *whh[2] = {nullptr, nullptr};     // W_hh as fp32 matrix-instruction fragments (fp32 forms)
+    float *whh16[2] = {nullptr, nullptr};   // W_hh as two fp16 pieces in the same fragment order (c3_kernels.h, c3_lstm_fused.h)
+    float *l1_wih = nullptr, *l1_bias = nullptr;  // LSTM1 input projection as fragments of the fused kernel (fp32; int32 windows)
+    float *l1_wih16 = nullptr;                    // the same as two fp16 pieces of 128 W_ih (int8 windows)
+    float *proj2_pw = nullptr;   // LSTM2 projection weights as dense_planes_pipe_kernel chunks (c3_dense.h)
+    float *proj2_pwr = nullptr;  // the same in the register-fragment order of dense_planes_wres_kernel
+    float proj2_pwscale = 1.f;
+    // full alignment
+    float *conv_w[9] = {};   // [Cout][9 Cin] fp32, BatchNorm folded (conv1: [64][3][32], /100 folded): the fp32 forms
+    float *conv_b[9] = {};
+    float *conv1_w16 = nullptr;  // conv1 of a window with C != 8 as two fp16 pieces for the tiled contraction (keep mode of the 9-channel model)
+    float conv1_wscale = 1.f;
+    float *conv1_wfrag16 = nullptr;  // conv1 as fragments of conv1_i8_f16_kernel / conv3x3_planes_kernel's SRC8 forms (C = 8 or 9)
+    float *pconv_w[9] = {};  // stride-1 convs: conv3x3_planes_kernel chunks [Cout/64][Cin/64][9][64][16 pieces of 16 B];
+                             // stride-2 convs: dense_planes_pipe_kernel<true> chunks [Cout/128][9 Cin/64][128][16 pieces]
+    float pconv_wscale[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+    // fp16x3: a weight tensor is packed times a power of two (pick_wscale: as close to 256 as keeps max |w| * scale below
+    // 16384, so the low piece is a normal fp16 number and the high piece cannot overflow); undone, exactly, in the epilogues
+    // shared FC tail
+    float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout (fp32 form)
+    float *l4_w16 = nullptr;                 // the same as two fp16 pieces [2][FC][K4]
+    float l4_wscale = 1.f;
+    float *b5 = nullptr;
+    float *w5f = nullptr, *whf = nullptr, *bh48 = nullptr;  // L5 / head weights as fragments of fc_tail_mfma_kernel (c3_tail.h)
+    float *zeros = nullptr;  // 256-byte zero page: padding taps of the conv loaders read from here
+    int FC = 0, K4 = 0;
+
+    // ---- arithmetic ----
+    uint32_t *range_flag = nullptr;  // device word set by the fp16x3 kernels when an activation nears the fp16 range (c3_gemm.h kF16Range)
+    uint32_t *pin_flag = nullptr;    // pinned copy of range_flag for c3_predict_device_checked
+    bool f16_ok = true;              // cleared when a batch came back out of range / non-finite (or by C3HIP_FP32=1): every layer then runs its fp32-MFMA form
+
+    // ---- switches (README) ----
+    bool spp_fused = true;    // PyramidPolling as the epilogue of res3b (c3_conv3.h SPPF; 12 x 5 windows); env C3HIP_SPP_FUSED
+    bool conv1_fused = true;  // conv1 computed inside res1a / res1b (c3_conv3.h SRC8): no conv1 launch, no conv1 planes; env C3HIP_CONV1_FUSED
+    bool half_tiles = true;   // LSTM recurrences on 8-window tiles while 16-window tiles would leave CUs without a workgroup; env C3HIP_HALF_TILES
+    int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
+    int wg_slots = 512;       // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
+
+    void *decode_dev = nullptr;  // scratch of c3_outcome_maxima
+    size_t decode_bytes = 0;
+
+    // ---- workspace ----
+    int64_t cap = 0;    // windows per micro-batch the workspace can hold
+    bool keep = false;  // debug: one buffer per layer instead of the 3-buffer rotation
+    bool last_planes = false;  // the last forward pass left plane activations in act[] / h1 (c3_debug_fetch converts)
+    std::vector<DevBuf> bufs;
+    float *act[9] = {};
+    float *spp = nullptr, *part = nullptr, *l4dbg = nullptr;
+    float *h1 = nullptr, *gx2 = nullptr, *h2 = nullptr;
+    int64_t last_n = 0;  // windows of the last micro-batch (for debug fetch)
+
+    HostSlot slot[kHostSlots];
+
+    // which kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
+    const char *choice_lstm1 = "-", *choice_proj2 = "-", *choice_lstm2 = "-", *choice_fa = "-";
+
+    bool prof = false;
+    std::vector<ProfRec> recs;
+};
+
+static int conv_out(int n, int s) { return (n - 1) / s + 1; }
+
+static void fa_geometry(const c3_model *m, int hh[10], int ww[10]) {
+    hh[0] = m->depth, ww[0] = m->positions;
+    for (int l = 0; l < 9; ++l) hh[l + 1] = conv_out(hh[l], kConvStride[l]), ww[l + 1] = conv_out(ww[l], kConvStride[l]);
+}
+
+// ------------------------------------------------------------------------------------------ profiling scope
+// dense MFMA peaks of MI355X (MI355X_MICROARCH.md): v_mfma_f32_32x32x16_f16 / 16x16x32_f16 and the fp32-input forms
+static constexpr double kPeakF16 = 2500.0, kPeakF32 = 157.3;
+struct ProfScope {
+    c3_model *m;
+    hipStream_t s;
+    ProfRec r;
+    bool on;
+    ProfScope(c3_model *m_, hipStream_t s_, const char *name, double flops, double bytes) : m(m_), s(s_), on(m_->prof) {
+        if (!on) return;
+        r.name = name, r.flops = flops, r.bytes = bytes;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, s);
+    }
+    // executed matrix work of the launch and the roof of the instruction it uses (c3_kernel_stat.mfma_flops / mfma_peak_tflops)
+    void mfma(double flops, bool f16) { r.mfma_flops = flops, r.mfma_peak = f16 ? kPeakF16 : kPeakF32; }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        m->recs.push_back(r);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ launches
+template <class Loader, int EPI, int BM, int BN, int SPLIT = 0>
+static int launch_gemm(hipStream_t s, const typename Loader::Params &lp, const float *bt, int64_t ldb, int M, int N,
+                       int nk, int splits, const EpilogueParams &ep, const float *bt16 = nullptr) {
+    if (N % BN) return fail("internal: N=%d not a multiple of BN=%d", N, BN);
+    if (M <= 0) return 0;
+    GemmParams gp;
+    gp.bt = bt, gp.ldb = ldb, gp.M = M, gp.N = N, gp.nk = nk;
+    gp.bt3 = reinterpret_cast<const uint16_t *>(bt16);
+    gp.tiles_n = N / BN;
+    gp.tiles = ((M + BM - 1) / BM) * gp.tiles_n;
+    dim3 grid(gp.tiles, splits);
+    hipLaunchKernelGGL((gemm_mfma_kernel<Loader, EPI, BM, BN, SPLIT>), grid, dim3(kThreads), 0, s, lp, gp, ep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Split-K factor of the L4 GEMM (K = 10560 / 3584, N = 128 / 256: far too few output tiles to fill 256 CUs).
+// It is a constant of the model, NOT a function of the batch size: the partial sums are added in a fixed
+// order by the reduce kernel, so a window's probabilities are bit-identical whatever batch it travels in.
+static int l4_splits(const c3_model *m) {
+    const int nk = m->K4 / kBK;
+    const int want = m->kind == C3_KIND_PILEUP ? 15 : 28;  // measured against 22 / 30 / 33 (pileup) and 14 / 56 (full alignment)
+    int best = 1;
+    for (int s = 1; s <= nk && s <= want; ++s)
+        if (nk % s == 0) best = s;
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------ memory
+static int dev_alloc(c3_model *m, void **p, size_t bytes) {
+    DevBuf b;
+    b.bytes = bytes;
+    HIP_TRY(hipMalloc(&b.p, std::max<size_t>(bytes, 256)));
+    m->bufs.push_back(b);
+    *p = b.p;
+    return 0;
+}
+static int upload(c3_model *m, float **dst, const std::vector<float> &src) {
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(src.size() * sizeof(float), 256)));
+    HIP_TRY(hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (*dst) (void)hipFree(*dst);
+    *dst = (float *)p;
+    (void)m;
+    return 0;
+}
+
+static void free_workspace(c3_model *m) {
+    for (auto &b : m->bufs) (void)hipFree(b.p);
+    m->bufs.clear();
+    m->cap = 0;
+}
+
+static int64_t max_microbatch(const c3_model *m) { return m->kind == C3_KIND_PILEUP ? 16384 : 2048; }
+
+static int ensure_workspace(c3_model *m, int64_t n) {
+    n = std::min<int64_t>(n, max_microbatch(m));
+    if (n <= m->cap) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    free_workspace(m);
+    if (m->kind == C3_KIND_FULL_ALIGNMENT) {
+        int hh[10], ww[10];
+        fa_geometry(m, hh, ww);
+        size_t act_elems[9];
+        size_t biggest = 0;
+        for (int l = 0; l < 9; ++l) {
+            act_elems[l] = (size_t)hh[l + 1] * ww[l + 1] * kConvCout[l];
+            biggest = std::max(biggest, act_elems[l]);
+        }
+        if (m->keep) {
+            for (int l = 0; l < 9; ++l) TRY(dev_alloc(m, (void **)&m->act[l], act_elems[l] * n * sizeof(float)));
+        } else {
+            float *rot[3];
+            for (int i = 0; i < 3; ++i) TRY(dev_alloc(m, (void **)&rot[i], biggest * n * sizeof(float)));
+            for (int l = 0; l < 9; ++l) m->act[l] = rot[l % 3];
+        }
+        TRY(dev_alloc(m, (void **)&m->spp, (size_t)n * m->K4 * sizeof(float)));
+    } else {
+        const int T = m->positions;
+        TRY(dev_alloc(m, (void **)&m->h1, (size_t)n * T * 256 * sizeof(float)));
+        TRY(dev_alloc(m, (void **)&m->gx2, (size_t)n * T * 1280 * sizeof(float)));
+        TRY(dev_alloc(m, (void **)&m->h2, (size_t)n * T * 320 * sizeof(float)));
+    }
+    TRY(dev_alloc(m, (void **)&m->part, (size_t)l4_splits(m) * n * m->FC * sizeof(float)));  // [S][n][FC]
+    TRY(dev_alloc(m, (void **)&m->l4dbg, (size_t)n * m->FC * sizeof(float)));
+    m->cap = n;
+    return 0;
+}

@@ -1,0 +1,431 @@
+// c3_pack.h -- c3_model_load: the state_dict of the reference modules (clair3/model.py:96-125, :317-365) packed once into
+// the layouts the kernels read.  Host arithmetic in double precision, rounded once to fp32; every tensor a fp16x3 kernel
+// consumes exists a second time as two fp16 pieces (w * 2^s = h0 + h1, round to nearest even, subnormals kept) in that
+// kernel's fragment / chunk order.
+#pragma once
+#include "c3_model.h"
+
+// fp16x3: a weight tensor is packed times a power of two: as close to 256 as keeps max |w| * scale below 16384 -- the low
+// piece of a small weight then stays a normal fp16 number and the high piece of a large one cannot overflow; the factor is
+// undone, exactly, inside the bias FMA of the consuming kernel's epilogue (post_scale).
+static float pick_wscale(const float *w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    float s = 256.f;
+    while (s > 1.f / 65536.f && mx * s >= 16384.f) s *= 0.5f;
+    return s;
+}
+
+// A weight matrix as fp16 pieces for the SPLIT form of gemm_mfma_kernel, layout [2][n] (uint16 payload carried in a float
+// allocation): w * scale = h0 + h1.
+static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float> &w, float *scale_out) {
+    const float wscale = pick_wscale(w.data(), w.size());
+    *scale_out = wscale;
+    const size_t n = w.size();
+    std::vector<float> pieces(n);  // 2 pieces x n x 2 bytes
+    uint16_t *q = reinterpret_cast<uint16_t *>(pieces.data());
+    for (size_t i = 0; i < n; ++i) {
+        const float r = w[i] * wscale;  // exact; undone by post_scale in the kernels' epilogues
+        const _Float16 h0 = (_Float16)r, h1 = (_Float16)(r - (float)h0);
+        memcpy(&q[i], &h0, 2);
+        memcpy(&q[n + i], &h1, 2);
+    }
+    return upload(m, dst, pieces);
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+struct TensorView {
+    const float *d;
+    std::vector<int64_t> shape;
+};
+typedef std::map<std::string, TensorView> TensorMap;
+
+static int want(const TensorMap &tm, const std::string &name, std::initializer_list<int64_t> shape, const float **out) {
+    auto it = tm.find(name);
+    if (it == tm.end()) return fail("Missing key in state_dict: \"%s\"", name.c_str());
+    std::vector<int64_t> s(shape);
+    if (it->second.shape != s) {
+        std::string got, exp;
+        for (auto v : it->second.shape) got += std::to_string(v) + ",";
+        for (auto v : s) exp += std::to_string(v) + ",";
+        return fail("size mismatch for %s: got (%s) expected (%s)", name.c_str(), got.c_str(), exp.c_str());
+    }
+    *out = it->second.d;
+    return 0;
+}
+
+static int pack_tail(c3_model *m, const TensorMap &tm) {
+    const int FC = m->FC, K4 = m->K4, nb = m->nb;
+    const float *w, *b;
+    TRY(want(tm, "L4.weight", {FC, K4}, &w));
+    TRY(want(tm, "L4.bias", {FC}, &b));
+    TRY(upload(m, &m->l4_w, std::vector<float>(w, w + (size_t)FC * K4)));
+    TRY(upload_split_pieces(m, &m->l4_w16, std::vector<float>(w, w + (size_t)FC * K4), &m->l4_wscale));
+    TRY(upload(m, &m->l4_b, std::vector<float>(b, b + FC)));
+    std::vector<float> w5t((size_t)FC * nb * 128), b5((size_t)nb * 128), wh((size_t)nb * 128 * 64, 0.f), bh((size_t)nb * 64, 0.f);
+    for (int br = 0; br < nb; ++br) {
+        const std::string l5 = "L5_" + std::to_string(br + 1);
+        TRY(want(tm, l5 + ".weight", {128, FC}, &w));
+        TRY(want(tm, l5 + ".bias", {128}, &b));
+        for (int j = 0; j < 128; ++j) {
+            b5[br * 128 + j] = b[j];
+            for (int k = 0; k < FC; ++k) w5t[(size_t)k * nb * 128 + br * 128 + j] = w[(size_t)j * FC + k];
+        }
+        const std::string hd = kHeadName[br];
+        TRY(want(tm, hd + ".weight", {kHeadN[br], 128}, &w));
+        TRY(want(tm, hd + ".bias", {kHeadN[br]}, &b));
+        for (int i = 0; i < kHeadN[br]; ++i) {
+            bh[br * 64 + i] = b[i];
+            for (int k = 0; k < 128; ++k) wh[((size_t)br * 128 + k) * 64 + i] = w[(size_t)i * 128 + k];
+        }
+    }
+    {
+        // fc_tail_mfma_kernel fragments: [br][wave][cb][q][lane][e] = L5_br[32 wave + 16 cb + (lane&15)][16 q + 4 (lane>>4) + e]
+        //                                [br][cb][q][lane][e]       = head_br[16 cb + (lane&15)][16 q + 4 (lane>>4) + e]
+        const int NQ = FC / 16;
+        std::vector<float> w5f((size_t)nb * 128 * FC), whf((size_t)nb * 3 * 8 * 64 * 4, 0.f), bh48((size_t)nb * 48, 0.f);
+        for (int br = 0; br < nb; ++br) {
+            for (int wv = 0; wv < 4; ++wv)
+                for (int cb = 0; cb < 2; ++cb)
+                    for (int q = 0; q < NQ; ++q)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int j = 32 * wv + 16 * cb + (lane & 15), k = 16 * q + 4 * (lane >> 4) + e;
+                                w5f[(((((size_t)br * 4 + wv) * 2 + cb) * NQ + q) * 64 + lane) * 4 + e] =
+                                    w5t[(size_t)k * nb * 128 + br * 128 + j];
+                            }
+            for (int cb = 0; cb < 3; ++cb)
+                for (int q = 0; q < 8; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 16 * cb + (lane & 15), k = 16 * q + 4 * (lane >> 4) + e;
+                            whf[((((size_t)br * 3 + cb) * 8 + q) * 64 + lane) * 4 + e] = wh[((size_t)br * 128 + k) * 64 + i];
+                        }
+            for (int i = 0; i < 48; ++i) bh48[br * 48 + i] = bh[br * 64 + i];
+        }
+        TRY(upload(m, &m->w5f, w5f));
+        TRY(upload(m, &m->whf, whf));
+        TRY(upload(m, &m->bh48, bh48));
+    }
+    TRY(upload(m, &m->b5, b5));
+    return 0;
+}
+
+// LSTM layer `layer` (0/1): hidden H, input size `in`.
+//   proj_w row n = dir*4H + wave*64 + gate*16 + unit  <->  PyTorch gate row gate*H + wave*16 + unit
+//   whh fragments: [dir][wave][gate][q][lane][e] = W_hh[gate*H + wave*16 + (lane&15)][16q + 4*(lane>>4) + e]
+// LSTM layer `layer` (0 = LSTM1: fused projection + recurrence, c3_lstm_fused.h; 1 = LSTM2: hoisted projection on c3_dense.h,
+// recurrence lstm_recurrent_kernel_v2): hidden H, input size `in`, PyTorch gate row order i, f, g, o (gate*H + unit).
+//   LSTM1 whh fragments: [dir][wave][gate][q][lane][e] = W_hh[gate*H + wave*16 + (lane&15)][16q + 4*(lane>>4) + e]
+static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in, int Kp) {
+    const bool v2 = layer == 1;
+    const std::string base = layer == 0 ? "LSTM1" : "LSTM2";
+    const int NW = H / 16, NQ = H / 16;
+    if (v2) {
+        // lstm_recurrent_kernel_v2: projection rows in PyTorch order (n = dir*4H + gate*H + unit); W_hh fragments
+        // [dir][block = n/16][q][lane][e] = W_hh[block*16 + (lane&15)][16q + 4*(lane>>4) + e]
+        std::vector<float> pw((size_t)2 * 4 * H * Kp, 0.f), pb((size_t)2 * 4 * H), wf((size_t)2 * 4 * H * H);
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = dir ? "_reverse" : "";
+            const float *wih, *whh, *bih, *bhh;
+            TRY(want(tm, base + ".weight_ih_l0" + sfx, {4 * H, in}, &wih));
+            TRY(want(tm, base + ".weight_hh_l0" + sfx, {4 * H, H}, &whh));
+            TRY(want(tm, base + ".bias_ih_l0" + sfx, {4 * H}, &bih));
+            TRY(want(tm, base + ".bias_hh_l0" + sfx, {4 * H}, &bhh));
+            for (int r = 0; r < 4 * H; ++r) {
+                const size_t n = (size_t)dir * 4 * H + r;
+                pb[n] = (float)((double)bih[r] + (double)bhh[r]);
+                for (int k = 0; k < in; ++k) pw[n * Kp + k] = wih[(size_t)r * in + k];
+            }
+            for (int blk = 0; blk < 4 * H / 16; ++blk)
+                for (int q = 0; q < NQ; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = blk * 16 + (lane & 15);
+                            const int k = 16 * q + 4 * (lane >> 4) + e;
+                            wf[((((size_t)dir * (4 * H / 16) + blk) * NQ + q) * 64 + lane) * 4 + e] = whh[(size_t)r * H + k];
+                        }
+        }
+        {
+            // lstm_recurrent_kernel_v2<H, true>: slot q = 2 ks + piece of [dir][block][q][lane][8 fp16]:
+            // piece of W_hh[block*16 + (lane&15)][32 ks + 8 (lane>>4) + j]   (the fp32 fragments' bytes and addressing)
+            std::vector<float> wf16(wf.size());
+            uint16_t *q16 = reinterpret_cast<uint16_t *>(wf16.data());
+            for (int dir = 0; dir < 2; ++dir) {
+                const float *whh;
+                TRY(want(tm, base + ".weight_hh_l0" + (dir ? "_reverse" : ""), {4 * H, H}, &whh));
+                for (int blk = 0; blk < 4 * H / 16; ++blk)
+                    for (int ks = 0; ks < H / 32; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = whh[(size_t)(blk * 16 + (lane & 15)) * H + 32 * ks + 8 * (lane >> 4) + j];
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const size_t slot = (((size_t)dir * (4 * H / 16) + blk) * NQ + 2 * ks) * 64 * 8;
+                                memcpy(&q16[slot + (size_t)lane * 8 + j], &h0, 2);
+                                memcpy(&q16[slot + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                            }
+            }
+            TRY(upload(m, &m->whh16[layer], wf16));
+        }
+        if (Kp == 256) {
+            const int N = 2 * 4 * H;
+            if (N % kDnBN == 0) {
+                // dense_planes_pipe_kernel: chunk (column tile of 128, k chunk of 64) = 128 rows x 256 B; piece g < 8 = hi of
+                // k 64 kc + 8 g .. + 7, g >= 8 = lo of the same k; times a power of two (pick_wscale)
+                const float sc = pick_wscale(pw.data(), pw.size());
+                m->proj2_pwscale = sc;
+                const int NKc = 256 / 64;
+                std::vector<float> pk((size_t)N * 256);
+                uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
+                for (int tn = 0; tn < N / kDnBN; ++tn)
+                    for (int kc = 0; kc < NKc; ++kc)
+                        for (int r = 0; r < kDnBN; ++r)
+                            for (int g = 0; g < 16; ++g)
+                                for (int j = 0; j < 8; ++j) {
+                                    const float v = pw[(size_t)(tn * kDnBN + r) * Kp + kc * 64 + 8 * (g & 7) + j] * sc;  // exact
+                                    const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                    const _Float16 piece = g < 8 ? h0 : h1;
+                                    memcpy(&q16[(((((size_t)tn * NKc + kc) * kDnBN + r) * 16 + g) * 8) + j], &piece, 2);
+                                }
+                TRY(upload(m, &m->proj2_pw, pk));
+                if (N % kWrBN == 0 && Kp == kWrK) {
+                    // dense_planes_wres_kernel: the weights of wave w of column tile tn in fragment order, [tn][w][k-step][piece][lane][8 fp16]:
+                    // lane (n = lane & 31, kh = lane >> 5) holds k = 16 ks + 8 kh .. + 7 of row 256 tn + 32 w + n; the same power of two
+                    std::vector<float> pr((size_t)N * 256);
+                    uint16_t *r16 = reinterpret_cast<uint16_t *>(pr.data());
+                    for (int tn = 0; tn < N / kWrBN; ++tn)
+                        for (int w = 0; w < 8; ++w)
+                            for (int ks = 0; ks < kWrKS; ++ks)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int j = 0; j < 8; ++j) {
+                                        const float v = pw[(size_t)(tn * kWrBN + 32 * w + (lane & 31)) * Kp + 16 * ks + 8 * (lane >> 5) + j] * sc;  // exact
+                                        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                        const size_t base = ((((size_t)tn * 8 + w) * kWrKS + ks) * 2) * 64 * 8;
+                                        memcpy(&r16[base + (size_t)lane * 8 + j], &h0, 2);
+                                        memcpy(&r16[base + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                                    }
+                    TRY(upload(m, &m->proj2_pwr, pr));
+                }
+            }
+        }
+        TRY(upload(m, &m->proj_w[layer], pw));
+        TRY(upload(m, &m->proj_b[layer], pb));
+        TRY(upload(m, &m->whh[layer], wf));
+        return 0;
+    }
+    std::vector<float> wf((size_t)2 * 4 * H * H);
+    for (int dir = 0; dir < 2; ++dir) {
+        const std::string sfx = dir ? "_reverse" : "";
+        const float *whh;
+        TRY(want(tm, base + ".weight_hh_l0" + sfx, {4 * H, H}, &whh));
+        for (int w = 0; w < NW; ++w)
+            for (int g = 0; g < 4; ++g)
+                for (int q = 0; q < NQ; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = g * H + w * 16 + (lane & 15);
+                            const int k = 16 * q + 4 * (lane >> 4) + e;
+                            wf[(((((size_t)dir * NW + w) * 4 + g) * NQ + q) * 64 + lane) * 4 + e] = whh[(size_t)r * H + k];
+                        }
+    }
+    TRY(upload(m, &m->whh[layer], wf));
+    {
+        // lstm1_fused_kernel<TX, true>: slot q = 2 ks + piece of [dir][wave][gate][q][lane][8 fp16]:
+        // piece of W_hh[gate*H + wave*16 + (lane&15)][32 ks + 8 (lane>>4) + j]
+        std::vector<float> wf16(wf.size());
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(wf16.data());
+        for (int dir = 0; dir < 2; ++dir) {
+            const float *whh;
+            TRY(want(tm, base + ".weight_hh_l0" + (dir ? "_reverse" : ""), {4 * H, H}, &whh));
+            for (int w = 0; w < NW; ++w)
+                for (int g = 0; g < 4; ++g)
+                    for (int ks = 0; ks < H / 32; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = whh[(size_t)(g * H + w * 16 + (lane & 15)) * H + 32 * ks + 8 * (lane >> 4) + j];
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const size_t slot = ((((size_t)dir * NW + w) * 4 + g) * NQ + 2 * ks) * 64 * 8;
+                                memcpy(&q16[slot + (size_t)lane * 8 + j], &h0, 2);
+                                memcpy(&q16[slot + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                            }
+        }
+        TRY(upload(m, &m->whh16[layer], wf16));
+    }
+    {
+        // fused kernel: W_ih as 16x16x4 B fragments [dir][wave][gate][ks][lane] = W_ih[g*H + w*16 + (lane&15)][4ks + (lane>>4)]
+        std::vector<float> fw((size_t)2 * NW * 4 * kFusedKS * 64, 0.f), fb((size_t)2 * NW * 4 * 16);
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = dir ? "_reverse" : "";
+            const float *wih, *bih, *bhh;
+            TRY(want(tm, base + ".weight_ih_l0" + sfx, {4 * H, in}, &wih));
+            TRY(want(tm, base + ".bias_ih_l0" + sfx, {4 * H}, &bih));
+            TRY(want(tm, base + ".bias_hh_l0" + sfx, {4 * H}, &bhh));
+            for (int w = 0; w < NW; ++w)
+                for (int g = 0; g < 4; ++g) {
+                    for (int u = 0; u < 16; ++u) {
+                        const int r = g * H + w * 16 + u;
+                        fb[(((size_t)dir * NW + w) * 4 + g) * 16 + u] = (float)((double)bih[r] + (double)bhh[r]);
+                    }
+                    for (int ks = 0; ks < kFusedKS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int r = g * H + w * 16 + (lane & 15), k = 4 * ks + (lane >> 4);
+                            if (k < in) fw[((((size_t)dir * NW + w) * 4 + g) * kFusedKS + ks) * 64 + lane] = wih[(size_t)r * in + k];
+                        }
+                }
+        }
+        TRY(upload(m, &m->l1_wih, fw));
+        TRY(upload(m, &m->l1_bias, fb));
+        if (in % 2 == 0) {
+            // [dir][wave][gate][piece][lane][8 fp16]: piece of 128 W_ih[g*H + w*16 + (lane&15)][8 (lane>>4) + j]
+            std::vector<float> fw16((size_t)2 * NW * 4 * 2 * 64 * 4, 0.f);
+            uint16_t *q16 = reinterpret_cast<uint16_t *>(fw16.data());
+            for (int dir = 0; dir < 2; ++dir) {
+                const float *wih;
+                TRY(want(tm, base + ".weight_ih_l0" + (dir ? "_reverse" : ""), {4 * H, in}, &wih));
+                for (int w = 0; w < NW; ++w)
+                    for (int g = 0; g < 4; ++g)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int r = g * H + w * 16 + (lane & 15), k = 8 * (lane >> 4) + j;
+                                const float v = k < in ? 128.f * wih[(size_t)r * in + k] : 0.f;
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const size_t slot = ((((size_t)dir * NW + w) * 4 + g) * 2) * 64 * 8;
+                                memcpy(&q16[slot + (size_t)lane * 8 + j], &h0, 2);
+                                memcpy(&q16[slot + 64 * 8 + (size_t)lane * 8 + j], &h1, 2);
+                            }
+            }
+            TRY(upload(m, &m->l1_wih16, fw16));
+        }
+    }
+    return 0;
+}
+
+// conv layer l: fold BatchNorm2d(eval, eps=1e-3) into weight and bias (clair3/model.py:191,195-197):
+//   scale = gamma / sqrt(var + eps);  w' = w * scale;  b' = (b - mean) * scale + beta
+// layout [Cout][kh][kw][Cin]; conv1 additionally folds x/100 (model.py:378) and pads each kh to 32 slots.
+static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
+    const int Cout = kConvCout[l];
+    const float *w, *b, *g, *beta, *mean, *var;
+    const std::string cv = kConvName[l], bn = kBnName[l];
+    TRY(want(tm, cv + ".weight", {Cout, Cin, 3, 3}, &w));
+    TRY(want(tm, cv + ".bias", {Cout}, &b));
+    TRY(want(tm, bn + ".weight", {Cout}, &g));
+    TRY(want(tm, bn + ".bias", {Cout}, &beta));
+    TRY(want(tm, bn + ".running_mean", {Cout}, &mean));
+    TRY(want(tm, bn + ".running_var", {Cout}, &var));
+    const int ldb = l == 0 ? 96 : 9 * Cin;
+    std::vector<float> pw((size_t)Cout * ldb, 0.f), pb(Cout);
+    for (int co = 0; co < Cout; ++co) {
+        const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+        pb[co] = (float)(((double)b[co] - (double)mean[co]) * scale + (double)beta[co]);
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const double v = (double)w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] * scale;
+                    if (l == 0)
+                        pw[(size_t)co * ldb + kh * 32 + kw * Cin + ci] = (float)(v / 100.0);
+                    else
+                        pw[(size_t)co * ldb + (size_t)(kh * 3 + kw) * Cin + ci] = (float)v;
+                }
+    }
+    TRY(upload(m, &m->conv_w[l], pw));
+    TRY(upload(m, &m->conv_b[l], pb));
+    if (l == 0 && Cin != 8)  // conv1 as its own launch runs on the tiled contraction unless the window has 8 channels
+        TRY(upload_split_pieces(m, &m->conv1_w16, pw, &m->conv1_wscale));
+    if (l == 0 && Cin == 8) {
+        {
+            // conv1_i8_f16_kernel: lane (n = lane & 31, kh = lane >> 5) of k-step t holds channel j of tap 2 t + kh
+            std::vector<float> pf16((size_t)5 * 2 * 2 * 64 * 4, 0.f);
+            uint16_t *q16 = reinterpret_cast<uint16_t *>(pf16.data());
+            for (int t = 0; t < 5; ++t)
+                for (int cb = 0; cb < 2; ++cb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 32 * cb + (lane & 31), tap = 2 * t + (lane >> 5);
+                            float v = 0.f;
+                            if (tap < 9) {
+                                const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+                                v = (float)((double)w[(((size_t)co * Cin + j) * 3 + tap / 3) * 3 + tap % 3] * scale * (128.0 / 100.0));  // the kernel feeds x / 128
+                            }
+                            const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                            memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 0) * 64 + lane) * 8 + j], &h0, 2);
+                            memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 1) * 64 + lane) * 8 + j], &h1, 2);
+                        }
+            float mx = 0.f;  // the fp16 form needs its weights inside the fp16 range; a checkpoint with a degenerate BatchNorm stays on fp32
+            for (size_t i = 0; i < pf16.size() * 2; ++i) {
+                _Float16 h;
+                memcpy(&h, &q16[i], 2);
+                mx = std::max(mx, std::fabs((float)h));
+            }
+            if (mx < 16384.f) TRY(upload(m, &m->conv1_wfrag16, pf16));
+        }
+    }
+    if (l == 0 && Cin == 9) {
+        // conv1 inside conv3x3_planes_kernel<.., C1 = 9> (c3_conv3.h): k-step t = (patch row ky = t >> 1, half u = t & 1); lane
+        // (n = lane & 31, kh = lane >> 5) holds the weights of bytes q = 16 u + 8 kh + j of the row's three 9-byte pixels
+        // (pixel q / 9, channel q % 9; q >= 27: padding, zero), times 1.28 (the kernel feeds x / 128), as two fp16 pieces
+        std::vector<float> pf16((size_t)6 * 2 * 2 * 64 * 4, 0.f);
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(pf16.data());
+        float mx = 0.f;
+        for (int t = 0; t < 6; ++t)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * cb + (lane & 31), q = 16 * (t & 1) + 8 * (lane >> 5) + j, ky = t >> 1;
+                        float v = 0.f;
+                        if (q < 27) {
+                            const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+                            v = (float)((double)w[(((size_t)co * Cin + q % 9) * 3 + ky) * 3 + q / 9] * scale * (128.0 / 100.0));
+                        }
+                        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                        memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 0) * 64 + lane) * 8 + j], &h0, 2);
+                        memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 1) * 64 + lane) * 8 + j], &h1, 2);
+                        mx = std::max(mx, std::fabs(v));
+                    }
+        if (mx < 16384.f) TRY(upload(m, &m->conv1_wfrag16, pf16));  // else: conv1 stays on the tiled GEMM
+    }
+    if (kConvStride[l] == 1 && Cin == Cout && Cin % 64 == 0) {
+        // conv3x3_planes_kernel: chunk (column tile tn, input slab, tap) = 64 couts x 256 B; piece g < 8 = hi of channels
+        // 64 slab + 8 g .. + 7, g >= 8 = lo of channels 8 (g - 8) ..; times a power of two (pick_wscale), undone by post_scale
+        const int NS = Cin / 64;
+        const float sc = pick_wscale(pw.data(), pw.size());
+        m->pconv_wscale[l] = sc;
+        std::vector<float> pk((size_t)NS * NS * 9 * 64 * 64);  // 16 KB per chunk
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
+        for (int tn = 0; tn < NS; ++tn)
+            for (int slab = 0; slab < NS; ++slab)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int n = 0; n < 64; ++n)
+                        for (int g = 0; g < 16; ++g)
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = tn * 64 + n, ci = slab * 64 + 8 * (g & 7) + j;
+                                const float v = pw[(size_t)co * ldb + (size_t)tap * Cin + ci] * sc;  // exact
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const _Float16 piece = g < 8 ? h0 : h1;
+                                memcpy(&q16[((((((size_t)tn * NS + slab) * 9 + tap) * 64 + n) * 16 + g) * 8) + j], &piece, 2);
+                            }
+        TRY(upload(m, &m->pconv_w[l], pk));
+    }
+    if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kDnBN == 0) {
+        // dense_planes_pipe_kernel<true>: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
+        const int NS = Cin / 64, NKc = 9 * NS;
+        const float sc = pick_wscale(pw.data(), pw.size());
+        m->pconv_wscale[l] = sc;
+        std::vector<float> pk((size_t)Cout * NKc * 64);
+        uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
+        for (int tn = 0; tn < Cout / kDnBN; ++tn)
+            for (int kc = 0; kc < NKc; ++kc)
+                for (int r = 0; r < kDnBN; ++r)
+                    for (int g = 0; g < 16; ++g)
+                        for (int j = 0; j < 8; ++j) {
+                            const int tap = kc / NS, slab = kc % NS;
+                            const float v = pw[(size_t)(tn * kDnBN + r) * ldb + (size_t)tap * Cin + slab * 64 + 8 * (g & 7) + j] * sc;  // exact
+                            const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                            const _Float16 piece = g < 8 ? h0 : h1;
+                            memcpy(&q16[(((((size_t)tn * NKc + kc) * kDnBN + r) * 16 + g) * 8) + j], &piece, 2);
+                        }
+        TRY(upload(m, &m->pconv_w[l], pk));
+    }
+    return 0;
+}
+

@@ -83,4 +83,4 @@ def test_describe_names_the_kernel_forms():
     assert _lib.lib().c3_model_describe(m._handle, buf, 256) == 0
     text = buf.value.decode()
     assert "lstm1=fused-f16x3-half-tiles" in text and "proj2=weights-resident" in text and "lstm2=f16x3-half-tiles" in text, text
-    assert "other_handles_active=0" in text and "on_fp32_fallback=0" in text
+    assert "on_fp32=0" in text

@@ -320,75 +320,18 @@ def test_model_handles_release_their_device_memory():
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of HBM lost over 12 create/predict/destroy cycles"
 
 
-def test_split_bf16_convolutions_are_as_close_to_the_oracle_as_the_fp32_ones(monkeypatch, oracle_mod):
-    """conv3 / conv5 run on 16-bit matrix instructions with every fp32 operand split into pieces (c3_gemm.h SPLIT:
-    fp16x3 = two fp16 pieces, three piece products, the default; bf16x6 = three bf16 pieces, six products).  Their
-    outputs (act3, act6) and the final rows must sit as close to the fp64 oracle as the fp32-MFMA kernels do -- not
-    merely inside the 1e-4 gate."""
-    monkeypatch.setenv("C3HIP_FA_PLANES", "0")  # the fp32-activation kernels of round 1 (the plane pipeline is the default)
-    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=31, peaked=True)
-    x = syn.make_fa_windows(9, seed=32)
-    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
-    errs = {}
-    for mask, kind in (("0x48", "2"), ("0x48", "1"), ("0", "2")):
-        monkeypatch.setenv("C3HIP_CONV_SPLITMASK", mask)
-        monkeypatch.setenv("C3HIP_SPLIT_KIND", kind)
-        m = make_model(syn.FULL_ALIGNMENT, 8, True, sd, keep=True)
-        y = m.predict_numpy(x)
-        e = {}
-        for name in ("act3", "act6"):
-            a = m.debug_fetch(name, d[name].shape)
-            e[name] = float(np.abs(a - d[name]).max()) / max(1.0, float(np.abs(d[name]).max()))
-        e["y"] = util.assert_rows_match(y, y_o, what=f"split mask {mask} kind {kind}")
-        errs["fp32" if mask == "0" else ("fp16x3" if kind == "2" else "bf16x6")] = e
-    monkeypatch.delenv("C3HIP_CONV_SPLITMASK")
-    monkeypatch.delenv("C3HIP_SPLIT_KIND")
-    print(errs)
-    for mode in ("fp16x3", "bf16x6"):
-        for k in ("act3", "act6", "y"):
-            assert errs[mode][k] < 2e-5
-            assert errs[mode][k] <= 3 * errs["fp32"][k] + 1e-7, (mode, k, errs)
-
-
-def test_fp16x3_winograd_stays_at_fp32_level(monkeypatch, oracle_mod):
-    """the six stride-1 convolutions form their Winograd-domain products from two fp16 pieces per operand (c3_wino_p.h
-    F16).  Every layer output against the fp64 oracle, next to the same kernels on fp32 MFMAs: the split products may
-    cost a small factor in rounding noise (both are ~1e-6 of the layer's range, 100x inside the 1e-4 gate on the
-    probabilities), never more."""
-    monkeypatch.setenv("C3HIP_FA_PLANES", "0")  # the fp32-activation kernels of round 1 (the plane pipeline is the default)
-    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=41, peaked=True)
-    x = syn.make_fa_windows(7, seed=42)
-    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
-    errs = {}
-    for mask in ("0x1b6", "0"):
-        monkeypatch.setenv("C3HIP_WINOGRAD_F16MASK", mask)
-        m = make_model(syn.FULL_ALIGNMENT, 8, True, sd, keep=True)
-        y = m.predict_numpy(x)
-        e = {}
-        for l in range(9):
-            a = m.debug_fetch(f"act{l}", d[f"act{l}"].shape)
-            e[f"act{l}"] = float(np.abs(a - d[f"act{l}"]).max()) / max(1.0, float(np.abs(d[f"act{l}"]).max()))
-        e["y"] = util.assert_rows_match(y, y_o, what=f"winograd f16 mask {mask}")
-        errs[mask] = e
-    monkeypatch.delenv("C3HIP_WINOGRAD_F16MASK")
-    print({k: (round(errs["0x1b6"][k] * 1e6, 2), round(errs["0"][k] * 1e6, 2)) for k in errs["0"]}, "(x1e-6: fp16x3, fp32)")
-    for k, v in errs["0x1b6"].items():
-        assert v < 1e-5, (k, v)
-        assert v <= 5 * errs["0"][k] + 3e-7, (k, errs)
-
-
 def test_plane_pipeline_stays_at_fp32_level(monkeypatch, oracle_mod):
     """the default full-alignment path: plane activations (every value kept as its two fp16 pieces) and direct fp16x3
     convolutions (c3_conv3.h).  Every layer output against the fp64 oracle, next to the all-fp32-MFMA kernels on fp32
-    activations: the same order of rounding noise, 100x inside the 1e-4 gate on the probabilities.  Also the dwell model
-    (conv1 through the tiled GEMM with the plane epilogue) and a batch that is not a multiple of any tile."""
+    activations (C3HIP_FP32=1: the forms the range guard falls back to): the same order of rounding noise, 100x inside the
+    1e-4 gate on the probabilities.  Also the dwell model (conv1 through the tiled contraction with the plane epilogue) and a
+    batch that is not a multiple of any tile."""
     errs = {}
     for ch, seed in ((8, 41), (9, 43)):
         sd = syn.make_state_dict(syn.FULL_ALIGNMENT, ch, True, seed=seed, peaked=True)
         x = syn.make_fa_windows(7, seed=42, channels=ch)
         y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
-        for mode, env in (("planes", {}), ("fp32", {"C3HIP_FA_PLANES": "0", "C3HIP_WINOGRAD_F16MASK": "0", "C3HIP_CONV_SPLITMASK": "0",
-                                                    "C3HIP_CONV1_F16": "0", "C3HIP_L4_SPLIT": "0"})):
+        for mode, env in (("planes", {}), ("fp32", {"C3HIP_FP32": "1"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             m = make_model(syn.FULL_ALIGNMENT, ch, True, sd, keep=True)
@@ -534,81 +477,78 @@ def test_range_guard_is_silent_on_ordinary_models(capfd):
     assert "continues on fp32" not in capfd.readouterr().err
 
 
-def test_every_fallback_kernel_selection_gives_the_same_calls(monkeypatch, oracle_mod):
-    """the A/B switches of README.md select older kernels for the same layers: each selection stays within the parity
-    gate (they are what a regression is bisected with, so they must keep working)"""
+def test_every_switch_keeps_the_calls(monkeypatch, oracle_mod):
+    """the switches of README.md: each selection stays within the parity gate.  C3HIP_FP32=1 is every layer's fp32-MFMA form --
+    what the range guard falls back to -- for both networks and both pileup input types"""
     sd_f = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=21)
     x_f = syn.make_fa_windows(37, seed=22)
     y_f = oracle_mod.fa_forward(sd_f, x_f, True)
     sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=23)
     x_p = syn.make_pileup_windows(70, seed=24)
     y_p = oracle_mod.pileup_forward(sd_p, x_p, False)
-    fa_sets = [{"C3HIP_CONV1_FUSED": "0"},  # conv1 as its own launch, its planes read by res1a / res1b
-               {"C3HIP_SPP_FUSED": "0"},  # res3b writes its planes, pyramid pooling as its own launch
-               {"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "4"},  # stride-2 convs on the round-2 / the role-split dense kernel
-               {"C3HIP_FA_PLANES": "0"}, {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0"},
-               {"C3HIP_CONV_S2_PLANES": "0", "C3HIP_CONV_BN64MASK": "0x48"},  # stride-2 convs of the plane path on the tiled GEMM
-               {"C3HIP_WINOGRAD_PMASK": "0"}, {"C3HIP_WINOGRAD_PMASK": "0", "C3HIP_WINOGRAD_N64MASK": "0"},
-               {"C3HIP_WINOGRAD": "0"}, {"C3HIP_CONV1_DIRECT": "0", "C3HIP_TAIL_MFMA": "0", "C3HIP_CONV_BN64MASK": "0"},
-               {"C3HIP_CONV_SPLITMASK": "0"}, {"C3HIP_CONV_SPLITMASK": "0", "C3HIP_WINOGRAD": "0", "C3HIP_L4_SPLIT": "0"},
-               {"C3HIP_SPLIT_KIND": "1"}, {"C3HIP_WINOGRAD_F16MASK": "0"}, {"C3HIP_WINOGRAD_F16MASK": "0x24"}]
-    for i, env in enumerate(fa_sets):
-        if i >= 7:
-            env = dict(env, C3HIP_FA_PLANES="0")  # switches of the fp32-activation kernels
+    for env in [{"C3HIP_CONV1_FUSED": "0"},  # conv1 as its own launch, its planes read by res1a / res1b
+                {"C3HIP_SPP_FUSED": "0"},    # res3b writes its planes, pyramid pooling as its own launch
+                {"C3HIP_FP32": "1"}, {"C3HIP_HOST_COPY_KERNEL": "0"}]:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f, what=f"FA {env}")
+        m = make_model(syn.FULL_ALIGNMENT, 8, True, sd_f)
+        util.assert_rows_match(m.predict_numpy(x_f), y_f, what=f"FA {env}")
+        assert m.range_status()[1] == ("C3HIP_FP32" in env)
         for k in env:
             monkeypatch.delenv(k)
-    for env in [{"C3HIP_DENSE_MODE": "0"}, {"C3HIP_DENSE_MODE": "1"}, {"C3HIP_DENSE_MODE": "4"}, {"C3HIP_LSTM_OPT": "0"},
-                {"C3HIP_LSTM_OPT": "5"},  # LSTM1 on half tiles (8 windows per workgroup)
-                {"C3HIP_LSTM_OPT": "21"}, {"C3HIP_LSTM2_HALF": "0"},  # both recurrences on half tiles; LSTM2 never
-                {"C3HIP_PROJ2_PLANES": "0"}, {"C3HIP_LSTM1_FUSED": "0"}, {"C3HIP_PROJ2_STREAM": "0", "C3HIP_TAIL_MFMA": "0"}, {"C3HIP_LSTM2_V2": "0"},
-                {"C3HIP_PROJ2_SPLIT": "0"}, {"C3HIP_L4_SPLIT": "0"}, {"C3HIP_PROJ2_SPLIT": "1", "C3HIP_SPLIT_KIND": "1"},
-                {"C3HIP_LSTM1_F16": "0"}, {"C3HIP_LSTM2_F16": "0"},
-                {"C3HIP_LSTM1_F16": "0", "C3HIP_LSTM2_F16": "0", "C3HIP_PROJ2_SPLIT": "0", "C3HIP_L4_SPLIT": "0"}]:
+    for env in [{"C3HIP_HALF_TILES": "0"}, {"C3HIP_FP32": "1"}, {"C3HIP_HOST_COPY_KERNEL": "0"}]:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         util.assert_rows_match(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p, what=f"pileup {env}")
+        util.assert_rows_match(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p.astype(np.int32)), y_p, what=f"pileup int32 {env}")
         for k in env:
             monkeypatch.delenv(k)
 
 
-def test_dense_kernel_forms_are_bit_identical(monkeypatch, oracle_mod):
-    """c3_dense.h holds six forms of the same contraction (round-2 kernel with staged / direct epilogue, chunk stream spread over
-    the matrix stream = the stride-2 convolutions' default, role-split waves, 256 x 256 tiles, weights resident in registers = the
-    projection's default): same chunk order, same matrix instructions per accumulator, same epilogue arithmetic -- the rows must
-    be EQUAL, also when a workgroup walks several tiles (607 pileup windows: 313 row tiles of 64 on 48 lanes, 1550 tiles of
-    128 x 128 on 256 workgroups; 96 full-alignment windows: 156 + 90 stride-2 tiles) and on ragged last tiles"""
+def test_projection_kernels_are_bit_identical(oracle_mod):
+    """the LSTM2 projection runs with its weights resident in registers (c3_dense.h dense_planes_wres_kernel) from ~190 windows
+    on and on the 128 x 128 chunk stream (dense_planes_pipe_kernel) below: same chunk order, same matrix instructions per
+    accumulator, same epilogue arithmetic -- a window's row must not depend on which of the two its batch selected; also when a
+    workgroup walks several row tiles (607 windows: 313 row tiles of 64 on 48 lanes) and on ragged last tiles"""
     sd_p = syn.make_state_dict(syn.PILEUP, 18, False, seed=61)
     x_p = syn.make_pileup_windows(600 + 7, seed=62)
-    sd_f = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=63)
-    x_f = syn.make_fa_windows(96 + 3, seed=64)
-    y_p = make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p)
-    y_f = make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f)
-    util.assert_rows_match(y_p[:40], oracle_mod.pileup_forward(sd_p, x_p[:40], False), what="pileup, default dense kernel")
-    util.assert_rows_match(y_f[-24:], oracle_mod.fa_forward(sd_f, x_f[-24:], True), what="full alignment, default dense kernel")
-    for mode in ("0", "1", "3", "4", "5", "6"):
-        monkeypatch.setenv("C3HIP_DENSE_MODE", mode)
-        assert np.array_equal(make_model(syn.PILEUP, 18, False, sd_p).predict_numpy(x_p), y_p), f"pileup rows differ with C3HIP_DENSE_MODE={mode}"
-        assert np.array_equal(make_model(syn.FULL_ALIGNMENT, 8, True, sd_f).predict_numpy(x_f), y_f), f"full-alignment rows differ with C3HIP_DENSE_MODE={mode}"
-        monkeypatch.delenv("C3HIP_DENSE_MODE")
+    m = make_model(syn.PILEUP, 18, False, sd_p)
+    y_p = m.predict_numpy(x_p)
+    assert "proj2=weights-resident" in describe(m)
+    util.assert_rows_match(y_p[:40], oracle_mod.pileup_forward(sd_p, x_p[:40], False), what="pileup, weights-resident projection")
+    for lo, n in ((0, 100), (100, 137), (500, 107), (300, 1)):
+        y_small = m.predict_numpy(x_p[lo:lo + n])
+        assert "proj2=128x128-chunk-stream" in describe(m)
+        assert np.array_equal(y_small, y_p[lo:lo + n]), f"rows {lo}..{lo + n} differ between the two projection kernels"
+
+
+def describe(m):
+    import ctypes as C
+    buf = C.create_string_buffer(256)
+    assert _lib.lib().c3_model_describe(m._handle, buf, 256) == 0
+    return buf.value.decode()
 
 
 def test_lstm_tile_shapes_are_bit_identical(monkeypatch, oracle_mod):
     """both recurrences run 16 windows per workgroup or, while that leaves CUs without a workgroup, 8 (on rows {0,1,4,5,...} of the
     matrix tile; c3_lstm_fused.h / c3_kernels.h OPT bit 2): same matrix instructions per window, same cell arithmetic per unit --
-    the rows must be EQUAL whichever shapes are pinned, ragged last tile included"""
+    the rows must be EQUAL whichever shape runs, ragged last tile included"""
     sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=111)
     x = syn.make_pileup_windows(200 + 3, seed=112)
-    monkeypatch.setenv("C3HIP_LSTM_OPT", "1")  # full tiles for both
-    y = make_model(syn.PILEUP, 18, False, sd).predict_numpy(x)
+    monkeypatch.setenv("C3HIP_HALF_TILES", "0")
+    m = make_model(syn.PILEUP, 18, False, sd)
+    y = m.predict_numpy(x)
+    assert "lstm1=fused-f16x3-full-tiles" in describe(m) and "lstm2=f16x3-full-tiles" in describe(m)
     util.assert_rows_match(y[:32], oracle_mod.pileup_forward(sd, x[:32], False), what="pileup, full tiles")
-    for opt in ("5", "17", "21"):  # LSTM1 half, LSTM2 half, both
-        monkeypatch.setenv("C3HIP_LSTM_OPT", opt)
-        assert np.array_equal(make_model(syn.PILEUP, 18, False, sd).predict_numpy(x), y), f"rows differ with C3HIP_LSTM_OPT={opt}"
-    monkeypatch.delenv("C3HIP_LSTM_OPT")
-    assert np.array_equal(make_model(syn.PILEUP, 18, False, sd).predict_numpy(x), y), "rows differ with the run-time choice"
+    monkeypatch.delenv("C3HIP_HALF_TILES")
+    m = make_model(syn.PILEUP, 18, False, sd)
+    assert np.array_equal(m.predict_numpy(x), y), "rows differ between tile shapes"
+    assert "lstm1=fused-f16x3-half-tiles" in describe(m) and "lstm2=f16x3-half-tiles" in describe(m)
+    # 8192 windows: 512 full tiles per direction fill the chip, so the full tiles run whatever the switch says
+    xb = np.concatenate([x] * 41)[:8192]
+    yb = m.wait(m.submit(xb, slot=0))  # one forward pass over all of them (the blocking call would cut the batch into chunks)
+    assert "lstm1=fused-f16x3-full-tiles" in describe(m) and "lstm2=f16x3-full-tiles" in describe(m)
+    assert np.array_equal(yb[:203], y) and np.array_equal(yb[203:406], y)
 
 
 def test_blocking_call_cut_into_chunks_gives_the_same_rows(oracle_mod):
@@ -676,22 +616,20 @@ def test_pyramid_pooling_inside_the_last_convolution(monkeypatch, oracle_mod):
         assert np.abs(y - y0).max() < 2e-6
 
 
-def test_kernel_choice_beside_other_handles_gives_the_same_rows(oracle_mod):
-    """a pileup handle picks its LSTM tile sizes and the shape of its projection launch by whether other handles of the process are
-    feeding the GPU (others_active()): rows computed beside a busy second handle (full LSTM tiles, 120 workgroups
-    of the weights-resident projection) equal the rows of the same windows computed alone (half tiles, 240 workgroups) bit for bit"""
+def test_two_handles_side_by_side_give_the_same_rows(oracle_mod):
+    """two handles of one process feeding the GPU alternately (own workspace and streams each): the rows equal those of a
+    handle alone on the chip, bit for bit -- kernel forms are a function of the batch, never of what else is running"""
     sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=101)
     x = syn.make_pileup_windows(1024 + 5, seed=102)
     m1 = make_model(syn.PILEUP, 18, False, sd)
     m2 = make_model(syn.PILEUP, 18, False, sd)
-    time.sleep(0.01)
     y_alone = m1.predict_numpy(x)
     util.assert_rows_match(y_alone[:32], oracle_mod.pileup_forward(sd, x[:32], False), what="pileup, alone on the chip")
     ys = []
-    for i in range(6):  # the two handles alternate without a pause: each sees the other's forward pass a few 100 us old
+    for i in range(6):
         t2 = m2.submit(x, slot=i % 2)
         t1 = m1.submit(x, slot=i % 2)
         ys.append(m1.wait(t1))
-        m2.wait(t2)
-    for y in ys[1:]:
+        assert np.array_equal(m2.wait(t2), y_alone)
+    for y in ys:
         assert np.array_equal(y, y_alone)

@@ -1,5 +1,5 @@
 // dense_probe.hip -- where the time of dense_planes_pipe_kernel goes on the LSTM2 projection shape (M = 33 * 1024, N = 1280,
-// K = 256): the kernel with parts switched off (ABL bits, c3_dense.h) and the round-2 kernel next to it.
+// K = 256): both kernels of c3_dense.h with parts switched off (ABL bits).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/dense_probe.hip -o tools/bin/dense_probe
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,8 +52,6 @@ int main(int argc, char **argv) {
     const double gflop = 2.0 * M * N * K * 3 * 1e-9;
     printf("proj2 shape M=%d N=%d K=%d: %d tiles on %d workgroups, %.1f GFLOP executed (three piece products)\n", M, N, K, dp.tiles, grid, gflop);
     auto report = [&](const char *name, float us) { printf("  %-58s %7.1f us  %6.0f TF executed\n", name, us, gflop / us * 1e-3); };
-    report("round-2 kernel, staged epilogue", time_us([&] { hipLaunchKernelGGL(dense_planes_kernel<false>, dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20));
-    report("round-2 kernel, direct epilogue", time_us([&] { hipLaunchKernelGGL((dense_planes_kernel<false, true>), dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20));
 #define RUN(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_pipe_kernel<false, false, abl>), dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20))
     RUN(0, "pipe kernel");
     RUN(16, "  - result stores");
@@ -69,25 +67,6 @@ int main(int argc, char **argv) {
     RUN(23, "  fragment reads + barriers only");
     RUN(28, "  loads + staging + barriers only");
     RUN(15, "  stores + barriers only");
-#define RUNW(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_ws_kernel<false, abl>), dim3(grid), dim3(kWsThreads), 0, 0, dp); }, 20))
-    RUNW(0, "role-split kernel (8 multiplying + 4 moving waves)");
-    RUNW(16, "  - result stores");
-    RUNW(1, "  - operand loads");
-    RUNW(2, "  - LDS staging writes");
-    RUNW(3, "  - loads - staging");
-    RUNW(8, "  - fragment reads");
-    RUNW(4, "  - matrix instructions");
-    RUNW(12, "  - fragment reads - matrix instructions (move + store)");
-    RUNW(28, "  move only");
-    RUNW(19, "  multiply only (fragment reads + matrix instructions)");
-    RUNW(27, "  matrix instructions + barriers only");
-    {   // 256 x 256 tiles (weights in 32-channel chunks: any bytes do for timing)
-        DenseBigParams bp;
-        bp.a = da, bp.w = dw, bp.bias = dbias, bp.c = dc, bp.post_scale = 1.f / 256.f;
-        bp.M = M, bp.N = N, bp.K = K, bp.tiles_n = N / kBgBN, bp.tiles = ((M + kBgBM - 1) / kBgBM) * bp.tiles_n;
-        const int gb = bp.tiles < 256 ? bp.tiles : 256;
-        report("256 x 256 tile kernel", time_us([&] { hipLaunchKernelGGL(dense_planes_big_kernel, dim3(gb), dim3(kDnThreads), 0, 0, bp); }, 20));
-    }
     {   // weights resident in registers (fragment order: any bytes do for timing)
         DenseWresParams wp;
         wp.a = da, wp.w = dw, wp.bias = dbias, wp.c = dc, wp.post_scale = 1.f / 256.f;
