@@ -194,18 +194,17 @@ def run_workload(name, args, rank, world, local):
         return {"median": r[len(r) // 2] if len(r) % 2 else 0.5 * (r[len(r) // 2 - 1] + r[len(r) // 2]), "min": r[0], "max": r[-1],
                 "repeats": len(r), "steps_per_repeat": args.steps}
 
-    def describe(mi):
-        import ctypes as C
-        from clair3_amd import _lib
-        buf = C.create_string_buffer(256)
-        _lib.check(_lib.lib().c3_model_describe(mi._handle, buf, 256), "c3_model_describe")
-        return buf.value.decode()
-
+    describe = lambda mi: mi.describe()
     single_blocks, single_own = timed(1)
     variants = {"one_batch_in_flight": describe(model)}
+    if S > 1:
+        for mi in models:
+            mi.sharing(S)  # the caller's hint: S handles feed this GPU side by side (tile shapes of the pileup kernels follow it)
     multi_blocks, multi_own = timed(S) if S > 1 else (single_blocks, single_own)
     if S > 1:
         variants[f"{S}_batches_in_flight"] = describe(models[-1])
+        for mi in models:
+            mi.sharing(1)
     med = lambda b: float(np.median(b))
     single, multi = med(single_blocks), med(multi_blocks)
     elapsed, in_flight, own = (multi, S, multi_own) if multi <= single else (single, 1, single_own)

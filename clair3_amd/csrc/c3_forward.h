@@ -281,7 +281,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
         // half tiles (8 windows per workgroup, c3_lstm_fused.h OPT bit 2) while the full tiles would leave CUs without a workgroup
-        const bool half1 = l1_f16 && m->half_tiles && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 2;
+        const bool half1 = l1_f16 && m->half_tiles && m->sharing <= 1 && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 2;
         const double tiles = (double)(half1 ? (n + 7) / 8 * 16 : (n + 15) / 16 * 16) * Tn * 2;  // (window, step, direction) rows of the 16-row tiles
         // recurrent part 512 x 128 as fp16x3 (or fp32); input part: int8 windows 512 x 32 against two weight pieces, else 512 x 20 fp32
         ps.mfma(l1_f16 ? tiles * 2.0 * 512 * (128 * 3 + (sizeof(T) == 1 ? 32 * 2 : 0)) : tiles * 2.0 * 512 * (128 + 20), l1_f16);
@@ -317,7 +317,10 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             wp.a = m->h1, wp.w = m->proj2_pwr, wp.bias = m->proj_b[1], wp.c = m->gx2, wp.post_scale = 1.f / m->proj2_pwscale;
             wp.M = M, wp.N = 1280, wp.tiles_m = (M + kWrBM - 1) / kWrBM, wp.tiles_n = 1280 / kWrBN;
             wp.lanes_per_xcd = std::max(1, m->wg_slots / 16 / wp.tiles_n);  // CUs per XCD / column tiles (32 / 5 = 6)
-            m->choice_proj2 = "weights-resident";
+            // beside other handles half as many, twice as long workgroups: 120 of them leave room for the 128 of another batch's
+            // LSTM launch (three batches in flight 5.46 M -> 5.59 M windows/s; alone 4.9 M -> 4.3 M, hence the caller's hint)
+            if (m->sharing > 1) wp.lanes_per_xcd = std::max(1, wp.lanes_per_xcd / 2);
+            m->choice_proj2 = m->sharing > 1 ? "weights-resident-half-grid" : "weights-resident";
             hipLaunchKernelGGL(dense_planes_wres_kernel<0>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
             HIP_TRY(hipGetLastError());
         } else if (h1_planes) {  // batches below ~190 windows: fewer than two row tiles per lane
@@ -337,7 +340,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
         const bool l2_f16 = m->f16_ok && m->whh16[1];
-        const bool half2 = l2_f16 && m->half_tiles && 2 * ((n + 15) / 16) <= m->wg_slots / 4;
+        const bool half2 = l2_f16 && m->half_tiles && m->sharing <= 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 4;
         ps.mfma((double)(half2 ? (n + 7) / 8 * 16 : (n + 15) / 16 * 16) * Tn * 2 * 2.0 * 640 * 160 * (l2_f16 ? 3 : 1), l2_f16);
         Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
         if (l2_f16) {

@@ -156,6 +156,8 @@ struct c3_model {
     bool spp_fused = true;    // PyramidPolling as the epilogue of res3b (c3_conv3.h SPPF; 12 x 5 windows); env C3HIP_SPP_FUSED
     bool conv1_fused = true;  // conv1 computed inside res1a / res1b (c3_conv3.h SRC8): no conv1 launch, no conv1 planes; env C3HIP_CONV1_FUSED
     bool half_tiles = true;   // LSTM recurrences on 8-window tiles while 16-window tiles would leave CUs without a workgroup; env C3HIP_HALF_TILES
+    int sharing = 1;          // handles the CALLER says feed this GPU side by side (c3_model_set_sharing): beside other batches the chip is
+                              // full, so the recurrences stay on full tiles and the projection launches half as many, twice as long workgroups
     int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
     int wg_slots = 512;       // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
 

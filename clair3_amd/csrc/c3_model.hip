@@ -220,12 +220,19 @@ int c3_model_range_status(c3_model *m, int *flag_out, int *on_fp32_out) {
     return 0;
 }
 
+int c3_model_set_sharing(c3_model *m, int handles) {
+    if (!m) return fail("null model");
+    if (handles < 1) return fail("handles must be >= 1");
+    m->sharing = handles;
+    return 0;
+}
+
 int c3_model_describe(c3_model *m, char *buf, int n) {
     if (!m || !buf || n <= 0) return fail("null argument");
     if (m->kind == C3_KIND_PILEUP)
-        snprintf(buf, (size_t)n, "lstm1=%s proj2=%s lstm2=%s on_fp32=%d", m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d", m->sharing, m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok);
     else
-        snprintf(buf, (size_t)n, "conv_stack=%s on_fp32=%d", m->choice_fa, (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d conv_stack=%s on_fp32=%d", m->sharing, m->choice_fa, (int)!m->f16_ok);
     return 0;
 }
 

@@ -219,6 +219,17 @@ class _HipModel:
         _lib.check(_lib.lib().c3_predict_wait(self._handle, slot), "c3_predict_wait")
         return y
 
+    def sharing(self, handles=1):
+        """Tell the handle how many handles feed its GPU side by side (c3_model_set_sharing; a speed hint only)."""
+        _lib.check(_lib.lib().c3_model_set_sharing(self._handle, int(handles)), "c3_model_set_sharing")
+        return self
+
+    def describe(self):
+        """which kernel forms the last forward pass took (c3_model_describe)"""
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.lib().c3_model_describe(self._handle, buf, 256), "c3_model_describe")
+        return buf.value.decode()
+
     def range_status(self):
         """(flag, on_fp32): flag != 0 when an fp16x3 batch of this handle produced an activation near the fp16 range
         (or a non-finite row under the checked entry); on_fp32 when the handle has switched to fp32 matrix

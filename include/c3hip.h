@@ -185,8 +185,12 @@ int c3_comm_abort(c3_comm *c);
 /* watchdog for work queued on `stream` of `device` (hipStreamQuery polled every 50 us): 0 = finished, 1 = still running after
  * timeout_ms (c3_last_error() == "timeout"; timeout_ms < 0 waits for ever), other = error */
 int c3_stream_wait(void *stream, int device, int timeout_ms);
-/* which of the bit-identical kernel forms the handle's last forward pass took (tile shapes that depend on whether other
- * handles of the process are feeding the GPU), as "key=value ..." text; bench.py reports it next to its rates */
+/* A hint, not a requirement: how many handles the CALLER keeps feeding this GPU side by side (default 1 -- the worker of
+ * clair3/CallVariantsFromCffiGPU.py:163-199 after callvar.install(): one process, one handle per GPU).  Tile shapes of the pileup
+ * kernels follow it (alone: 8-window LSTM tiles and 240 projection workgroups so that a 1024-window batch reaches every CU;
+ * sharing: 16-window tiles and 120 workgroups, because the other batches fill the rest).  Rows are bit-identical either way. */
+int c3_model_set_sharing(c3_model *m, int handles);
+/* which kernel forms the handle's last forward pass took, as "key=value ..." text; bench.py reports it next to its rates */
 int c3_model_describe(c3_model *m, char *buf, int buf_bytes);
 /* blocks until everything enqueued on the model's own stream has finished */
 int c3_model_synchronize(c3_model *m);

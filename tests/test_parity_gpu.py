@@ -618,18 +618,24 @@ def test_pyramid_pooling_inside_the_last_convolution(monkeypatch, oracle_mod):
 
 def test_two_handles_side_by_side_give_the_same_rows(oracle_mod):
     """two handles of one process feeding the GPU alternately (own workspace and streams each): the rows equal those of a
-    handle alone on the chip, bit for bit -- kernel forms are a function of the batch, never of what else is running"""
+    handle alone on the chip, bit for bit -- kernel forms are a function of the batch and of the caller's sharing hint
+    (c3_model_set_sharing: full LSTM tiles, half as many projection workgroups), never of what else happens to be running"""
     sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=101)
     x = syn.make_pileup_windows(1024 + 5, seed=102)
     m1 = make_model(syn.PILEUP, 18, False, sd)
     m2 = make_model(syn.PILEUP, 18, False, sd)
     y_alone = m1.predict_numpy(x)
     util.assert_rows_match(y_alone[:32], oracle_mod.pileup_forward(sd, x[:32], False), what="pileup, alone on the chip")
-    ys = []
-    for i in range(6):
-        t2 = m2.submit(x, slot=i % 2)
-        t1 = m1.submit(x, slot=i % 2)
-        ys.append(m1.wait(t1))
-        assert np.array_equal(m2.wait(t2), y_alone)
-    for y in ys:
-        assert np.array_equal(y, y_alone)
+    assert "sharing=1" in m1.describe() and "lstm1=fused-f16x3-half-tiles" in m1.describe() and "proj2=weights-resident " in m1.describe()
+    for hint in (1, 2):
+        m1.sharing(hint), m2.sharing(hint)
+        ys = []
+        for i in range(6):
+            t2 = m2.submit(x, slot=i % 2)
+            t1 = m1.submit(x, slot=i % 2)
+            ys.append(m1.wait(t1))
+            assert np.array_equal(m2.wait(t2), y_alone)
+        for y in ys:
+            assert np.array_equal(y, y_alone)
+    d = m1.describe()
+    assert "sharing=2" in d and "lstm1=fused-f16x3-full-tiles" in d and "proj2=weights-resident-half-grid" in d and "lstm2=f16x3-full-tiles" in d
