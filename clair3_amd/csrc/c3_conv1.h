@@ -36,6 +36,7 @@ struct Conv1F16Params {
     const uint32_t *wfrag;  // [5 k-steps][2 column blocks][2 pieces][64 lanes][4 dwords = 8 fp16]: piece of
                             // 1.28 W'[cout = 32 cb + (lane & 31)][tap = 2 t + (lane >> 5)][channel j]  (W' has BN and /100 folded)
     const float *bias;      // [64]
+    const float *post;      // [64] 2^-k of the output channel: the fragments are packed times 2^k (c3_pack.h row_scales)
     float *out;             // [B][OH][OW][64]
     uint32_t *range_flag;   // set to 1 when an output reaches kF16Range (c3_gemm.h)
     int B, H, W, OH, OW, M, groups;
@@ -43,15 +44,17 @@ struct Conv1F16Params {
 
 // PLANES: the output leaves as plane activations (c3_conv3.h).  The two matrix operands swap places, so the accumulators
 // hold the block transposed -- lane = pixel, four consecutive channels per v >> 2.
-template <bool PLANES = false>
+template <bool PLANES = true>
 __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) {
+    static_assert(PLANES, "the product writes plane activations (the fp32-activation form of conv1 is the tiled contraction)");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, kh = lane >> 5;
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    __shared__ __attribute__((aligned(16))) float bias_lds[PLANES ? 64 : 4];
+    __shared__ __attribute__((aligned(16))) float bias_lds[PLANES ? 128 : 4];
+    float *const post_lds = bias_lds + 64;
     if constexpr (PLANES) {  // before any wave leaves
-        if (tid < 64) bias_lds[tid] = p.bias[tid];
+        if (tid < 64) bias_lds[tid] = p.bias[tid], post_lds[tid] = p.post[tid];
         __syncthreads();
     }
     if (gw >= p.groups) return;
@@ -130,10 +133,11 @@ __global__ __launch_bounds__(256, 2) void conv1_i8_f16_kernel(Conv1F16Params p) 
     auto store_group = [&](const f32x16 (&r)[2], int idx) __attribute__((always_inline)) {
         const int cb = idx >> 2, q = idx & 3;
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_lds + 32 * cb + 8 * q + 4 * kh);
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(post_lds + 32 * cb + 8 * q + 4 * kh);
         f32x4 val;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int relu = max(__float_as_int(r[cb][4 * q + e] + b4[e]), 0);
+            const int relu = max(__float_as_int(__builtin_fmaf(r[cb][4 * q + e], s4[e], b4[e])), 0);
             omax_i = max(omax_i, relu);
             val[e] = __int_as_float(relu);
         }

@@ -62,7 +62,9 @@ struct PlaneConvParams {
     const void *res;      // residual, plane layout of the output (RES)
     void *out;            // plane activations [M][Cout/64][2][64]
     uint32_t *range_flag;
-    float post_scale;     // the weights are packed times a power of two (pick_wscale); undone here, exactly
+    const float *post;    // [Cout] 2^-k: every output channel's weights are packed times its own power of two 2^k (c3_pack.h
+                          // row_scales); undone here, exactly, inside the bias FMA
+    const float *pre;     // [Cout] 2^k (SRC8 = 2: the residual enters the accumulators times it)
     int M, H, W;
     int tiles;            // ceil(M / 256) * (C / 64)
     // SRC8 (first residual block of Clair3_F, 8-channel windows): conv1 (clair3/model.py:316-317,391) is computed in here
@@ -71,6 +73,7 @@ struct PlaneConvParams {
     const int8_t *x8 = nullptr;      // [B][Hin][Win][8] windows
     const uint32_t *c1w = nullptr;   // conv1_i8_f16_kernel's weight fragments (c3_conv1.h): [5 k-steps][2 column blocks][2 pieces][64 lanes][16 B]
     const float *c1b = nullptr;      // conv1 bias [64] (BatchNorm folded)
+    const float *c1post = nullptr;   // conv1's [64] per-channel 2^-k (its fragments are packed times 2^k)
     int Hin = 0, Win = 0;
     uint32_t mg_hw = 0, mg_w = 0;    // fast_div magics of H * W and W (c3_gemm.h)
 };
@@ -101,7 +104,7 @@ __device__ __forceinline__ f32x4 load_planes4(const __amdgpu_buffer_rsrc_t rsrc,
 //      during the previous tile's last chunk;
 //   2  the RESIDUAL (= conv1's output at the tile's own pixels) is computed in the accumulators' own layout -- conv1 with the
 //      weights as first operand leaves a lane the same 4 consecutive channels of the same pixel as this kernel -- and is the
-//      value the accumulators start from (times 1 / post_scale, a power of two), 10 matrix instructions per 32 x 32 block.
+//      value the accumulators start from (times the channel's 2^k of this layer), 10 matrix instructions per 32 x 32 block.
 // conv1 costs 7 MFLOP per window against 56 for each of these layers; what it saves is its own launch (16 us, store-bound) and
 // 150 MB of HBM traffic per 256 windows (its output written once and read twice).
 // SPPF (last convolution of the network, 12 x 5 windows): PyramidPolling (clair3/model.py:245-279: 3x3, 2x2 and 1x1 max-pooling
@@ -127,14 +130,16 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     constexpr int PIXB = 4 * C;    // bytes per pixel
     constexpr int NCH = 9 * NS;    // weight chunks per tile
     constexpr int kC1WBytes = NT1 * 2 * 2 * 64 * 16;
-    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes + 256 + (SRC8 ? kC1WBytes + 256 : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes + 768 + (SRC8 ? kC1WBytes + 512 : 0)];
     char *const halo = smem;
     char *const bbuf = smem + kPlHaloBytes;
     // this workgroup's 64 bias values (it keeps its column tile): read from LDS in the epilogue.  As global loads there they were
     // waited for at once -- and with them, the counter being in-order, the halo rows and residual pieces requested just before
     float *const bias_lds = reinterpret_cast<float *>(smem + kPlHaloBytes + 3 * kPlBBytes);
-    char *const c1w_lds = smem + kPlHaloBytes + 3 * kPlBBytes + 256;
+    float *const post_lds = bias_lds + 64, *const pre_lds = bias_lds + 128;  // this column tile's 64 powers of two 2^-k / 2^k
+    char *const c1w_lds = smem + kPlHaloBytes + 3 * kPlBBytes + 768;
     float *const c1b_lds = reinterpret_cast<float *>(c1w_lds + kC1WBytes);
+    float *const c1post_lds = c1b_lds + 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,9 +313,10 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(c1b_lds + 32 * cb + 8 * q + 4 * kh);
+                    const f32x4 s4 = *reinterpret_cast<const f32x4 *>(c1post_lds + 32 * cb + 8 * q + 4 * kh);
                     f32x4 val;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __int_as_float(max(__float_as_int(c[4 * q + e] + b4[e]), 0));
+                    for (int e = 0; e < 4; ++e) val[e] = __int_as_float(max(__float_as_int(__builtin_fmaf(c[4 * q + e], s4[e], b4[e])), 0));
                     omax = fmaxf(omax, fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3])));
                     u32x2 pc[2];
                     split2_f16(val, pc);
@@ -350,11 +356,14 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     // for 1536 cycles of matrix work on the two waves of a SIMD.)
     pl_u32x4 hreg[SRC8 == 1 ? 1 : kPlHaloLoads];
     pl_u32x4 rb[3][NBP];
-    if (tid < 64) bias_lds[tid] = p.bias[tn * 64 + tid];  // visible behind the prologue's barrier
+    if (tid < 64) {  // visible behind the prologue's barrier
+        bias_lds[tid] = p.bias[tn * 64 + tid], post_lds[tid] = p.post[tn * 64 + tid];
+        if constexpr (SRC8 == 2) pre_lds[tid] = p.pre[tn * 64 + tid];
+    }
     if constexpr (SRC8) {
         for (int i = tid; i < kC1WBytes / 16; i += kPlThreads)
             *reinterpret_cast<pl_u32x4 *>(c1w_lds + i * 16) = *reinterpret_cast<const pl_u32x4 *>(reinterpret_cast<const char *>(p.c1w) + i * 16);
-        if (tid < 64) c1b_lds[tid] = p.c1b[tid];
+        if (tid < 64) c1b_lds[tid] = p.c1b[tid], c1post_lds[tid] = p.c1post[tid];
     }
     if constexpr (SRC8 == 1) c1_halo_request(m0);
     else halo_issue(hreg, m0, 0);
@@ -420,17 +429,19 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 
         f32x16 acc[2];
         if constexpr (SRC8 == 2) {
-            // the accumulators start from the residual: relu(conv1 + bias) / post_scale, same (pixel, channel) per element
-            const float inv_post = 1.f / p.post_scale;
+            // the accumulators start from the residual: relu(conv1 + bias) times THIS layer's 2^k of the channel (undone with
+            // the rest of the sum by `post` in the epilogue), same (pixel, channel) per element
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f32x16 c = c1_block(c1d[i], wn);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(c1b_lds + 32 * wn + 8 * q + 4 * kh);
+                    const f32x4 s4 = *reinterpret_cast<const f32x4 *>(c1post_lds + 32 * wn + 8 * q + 4 * kh);
+                    const f32x4 k4 = *reinterpret_cast<const f32x4 *>(pre_lds + 32 * wn + 8 * q + 4 * kh);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[i][4 * q + e] = __int_as_float(max(__float_as_int(c[4 * q + e] + b4[e]), 0)) * inv_post;
+                        acc[i][4 * q + e] = __int_as_float(max(__float_as_int(__builtin_fmaf(c[4 * q + e], s4[e], b4[e])), 0)) * k4[e];
                 }
             }
         } else {
@@ -544,9 +555,10 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + cb0 + 8 * q);
+                const f32x4 sv = *reinterpret_cast<const f32x4 *>(post_lds + cb0 + 8 * q);
                 f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], sv[e], bv[e]);
                 *reinterpret_cast<f32x4 *>(halo + lrow[i] * kPlRowB + (cb0 + 8 * q) * 4) = val;
             }
         lds_barrier();

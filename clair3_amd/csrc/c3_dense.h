@@ -30,7 +30,7 @@ struct DensePlanesParams {
                         // (CONV: k chunk kc = tap * (Cin/64) + slab, tap = kh * 3 + kw)
     const float *bias;  // [N]
     float *c;           // [M][N] fp32   (CONV: plane activations [M][N/64][hi | lo], bias + ReLU)
-    float post_scale;   // 2^-s
+    const float *post;  // [N] 2^-k of every output row / channel: its weights are packed times 2^k (c3_pack.h row_scales)
     int M, N, K;
     int tiles_n, tiles;  // N / 128, ceil(M / 128) * tiles_n
     // CONV: 3x3 / pad 1 / stride `stride` convolution as an implicit GEMM, M = B * Ho * Wo output pixels, K = 9 * Cin
@@ -59,9 +59,10 @@ struct DensePlanesParams {
 // 8 no fragment reads, 16 no result stores, 32 no barriers.
 template <bool CONV = false, bool TR = false, int ABL = 0>
 __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DensePlanesParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + 8192];
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDnStage + 16384];
     float *bias_lds = reinterpret_cast<float *>(smem + 2 * kDnStage);  // the whole bias vector (N <= 2048): no global load in an epilogue
-    for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i];
+    float *post_lds = bias_lds + 2048;                                 // and the per-channel 2^-k next to it
+    for (int i = threadIdx.x; i < p.N && i < 2048; i += kDnThreads) bias_lds[i] = p.bias[i], post_lds[i] = p.post[i];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
@@ -263,9 +264,10 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DenseP
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + ptn * kDnBN + cb0 + 8 * q);
+                    const f32x4 sv = *reinterpret_cast<const f32x4 *>(post_lds + ptn * kDnBN + cb0 + 8 * q);
                     f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], sv[e], bv[e]);
                     if constexpr (ABL & 16) {
                         if (val[0] == 1234.5f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
                     } else {
@@ -283,9 +285,10 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DenseP
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + ptn * kDnBN + cb0 + 8 * q);
+                    const f32x4 sv = *reinterpret_cast<const f32x4 *>(post_lds + ptn * kDnBN + cb0 + 8 * q);
                     f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], sv[e], bv[e]);
                     *reinterpret_cast<f32x4 *>(stg + (wm * 64 + i * 32 + frow) * kRowE + (cb0 + 8 * q) * 4) = val;
                 }
             lds_barrier();
@@ -353,7 +356,8 @@ struct DenseWresParams {
                         // holds k = 16 ks + 8 kh .. + 7 of piece 0 (hi) / 1 (lo) of W[256 tn + 32 wave + n][.], times 2^s
     const float *bias;  // [N]
     float *c;           // [M][N] fp32
-    float post_scale;   // 2^-s
+    float post_scale;   // 2^-k: the projection weights are packed times ONE power of two (the kernel has no register to spare for a vector; LSTM
+                        // weights carry no folded BatchNorm, so their rows do not differ by orders of magnitude the way convolution channels can)
     int M, N;
     int tiles_m, tiles_n, lanes_per_xcd;  // ceil(M / 64), N / 256, row-tile lanes per XCD
 };

@@ -27,7 +27,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
         ps.mfma(2.0 * ((n + 15) / 16 * 16) * m->nb * (FC * 128.0 + 128.0 * 48.0), false);
         ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
-        if (l4_f16) rp.pre = m->l4_wscale, rp.post = 1.f / m->l4_wscale;
+        if (l4_f16) rp.pre = m->l4_pre, rp.post = m->l4_post;
         hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
         HIP_TRY(hipGetLastError());
         Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->row};
@@ -116,7 +116,7 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             ps.mfma(2.0 * ((M + 31) / 32 * 32) * 64.0 * 80.0 * 2, true);
             Conv1F16Params cp;
             cp.x = x, cp.wfrag = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.bias = m->conv_b[0], cp.out = m->act[0];
-            cp.range_flag = m->range_flag;
+            cp.range_flag = m->range_flag, cp.post = m->conv1_post;
             cp.B = (int)n, cp.H = hh[0], cp.W = ww[0], cp.OH = hh[1], cp.OW = ww[1], cp.M = M, cp.groups = (M + 31) / 32;
             const int grid = std::min((cp.groups + 3) / 4, m->wg_slots);
             hipLaunchKernelGGL(conv1_i8_f16_kernel<true>, dim3(grid), dim3(256), 0, s, cp);
@@ -125,11 +125,11 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             ps.mfma(2.0 * ((M + 127) / 128 * 128) * 64.0 * 96.0 * 3, true);
             Conv1LoaderParams lp{x, (const int8_t *)m->zeros, hh[0], ww[0], cin, hh[1], ww[1]};
             EpilogueParams ep{m->act[0], m->conv_b[0], nullptr, Cout, 0};
-            ep.post_scale = 1.f / m->conv1_wscale, ep.range_flag = m->range_flag;
+            ep.post = m->conv1_w16_post, ep.range_flag = m->range_flag;
             TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU_PLANES, 128, 64, 2>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep, m->conv1_w16)));
         } else if (kConvStride[l] == 2) {
             DensePlanesParams dp;
-            dp.a = m->act[l - 1], dp.w = m->pconv_w[l], dp.bias = m->conv_b[l], dp.c = m->act[l], dp.post_scale = 1.f / m->pconv_wscale[l];
+            dp.a = m->act[l - 1], dp.w = m->pconv_w[l], dp.bias = m->conv_b[l], dp.c = m->act[l], dp.post = m->pconv_post[l];
             dp.M = M, dp.N = Cout, dp.K = 9 * cin, dp.tiles_n = Cout / kDnBN, dp.tiles = (M + kDnBM - 1) / kDnBM * dp.tiles_n;
             dp.Hin = hh[l], dp.Win = ww[l], dp.Cin = cin, dp.Ho = hh[l + 1], dp.Wo = ww[l + 1], dp.stride = 2, dp.range_flag = m->range_flag;
             TRY(div_magic(hh[l + 1] * ww[l + 1], (int64_t)M + 2 * kDnBM, &dp.mg_hw));
@@ -142,7 +142,7 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             const bool res = l % 3 == 2;
             PlaneConvParams cp;
             cp.x = m->act[l - 1], cp.w = m->pconv_w[l], cp.bias = m->conv_b[l], cp.res = res ? m->act[l - 2] : nullptr, cp.out = m->act[l];
-            cp.range_flag = m->range_flag, cp.post_scale = 1.f / m->pconv_wscale[l];
+            cp.range_flag = m->range_flag, cp.post = m->pconv_post[l], cp.pre = m->pconv_pre[l];
             cp.M = M, cp.H = hh[l], cp.W = ww[l];
             TRY(div_magic(hh[l] * ww[l], (int64_t)M + 2 * kPlBM, &cp.mg_hw));
             TRY(div_magic(ww[l], hh[l] * ww[l], &cp.mg_w));
@@ -156,7 +156,7 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
                 cp.tiles = (int)((n + 3) / 4) * (Cout / 64);
             }
             if (src8) {
-                cp.x8 = x, cp.c1w = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.c1b = m->conv_b[0], cp.Hin = hh[0], cp.Win = ww[0];
+                cp.x8 = x, cp.c1w = reinterpret_cast<const uint32_t *>(m->conv1_wfrag16), cp.c1b = m->conv_b[0], cp.c1post = m->conv1_post, cp.Hin = hh[0], cp.Win = ww[0];
                 if (l == 1) cp.x = nullptr;
                 else cp.res = nullptr;
             }
@@ -314,7 +314,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         if (h1_planes && m->proj2_pwr && (M + kWrBM - 1) / kWrBM >= 2 * 8 * std::max(1, m->wg_slots / 16 / (1280 / kWrBN))) {
             // weights resident in registers (c3_dense.h): 8 XCDs x lanes x 5 column tiles of workgroups, each walking the row tiles of its lane
             DenseWresParams wp;
-            wp.a = m->h1, wp.w = m->proj2_pwr, wp.bias = m->proj_b[1], wp.c = m->gx2, wp.post_scale = 1.f / m->proj2_pwscale;
+            wp.a = m->h1, wp.w = m->proj2_pwr, wp.bias = m->proj_b[1], wp.c = m->gx2, wp.post_scale = m->proj2_post_scale;
             wp.M = M, wp.N = 1280, wp.tiles_m = (M + kWrBM - 1) / kWrBM, wp.tiles_n = 1280 / kWrBN;
             wp.lanes_per_xcd = std::max(1, m->wg_slots / 16 / wp.tiles_n);  // CUs per XCD / column tiles (32 / 5 = 6)
             // beside other handles half as many, twice as long workgroups: 120 of them leave room for the 128 of another batch's
@@ -325,7 +325,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             HIP_TRY(hipGetLastError());
         } else if (h1_planes) {  // batches below ~190 windows: fewer than two row tiles per lane
             DensePlanesParams dp;
-            dp.a = m->h1, dp.w = m->proj2_pw, dp.bias = m->proj_b[1], dp.c = m->gx2, dp.post_scale = 1.f / m->proj2_pwscale;
+            dp.a = m->h1, dp.w = m->proj2_pw, dp.bias = m->proj_b[1], dp.c = m->gx2, dp.post = m->proj2_post;
             dp.M = M, dp.N = 1280, dp.K = 256, dp.tiles_n = 1280 / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
             m->choice_proj2 = "128x128-chunk-stream";
             hipLaunchKernelGGL(dense_planes_pipe_kernel<false>, dim3(std::min(dp.tiles, m->wg_slots / 2)), dim3(kDnThreads), 0, s, dp);

@@ -253,8 +253,9 @@ struct EpilogueParams {
     int64_t ldc;
     int64_t split_stride;  // M*ldc for EPI_PARTIAL
     uint32_t *range_flag = nullptr;  // SPLIT: set to 1 when an output reaches kF16Range (the consumers split it into fp16 pieces)
-    float post_scale = 1.f;  // SPLIT: the weights are packed times a power of two (so that their low fp16 piece stays a
-                             // normal number) and the sum is scaled back here, exactly, inside the bias FMA
+    const float *post = nullptr;  // SPLIT: [N] 2^-k -- every weight row is packed times its own power of two 2^k (so that its low
+                                  // fp16 pieces stay normal numbers, c3_pack.h row_scales) and the sum is scaled back here,
+                                  // exactly, inside the bias FMA; nullptr = 1
 };
 
 struct GemmParams {
@@ -508,9 +509,10 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
                         for (int q = 0; q < 4; ++q) {
                             const int col = (BN == 64 ? wn * 32 : 0) + c * 32 + 4 * (lane >> 5) + 8 * q;  // inside the slice
                             const f32x4 bv = *reinterpret_cast<const f32x4 *>(ep.bias + n0 + sl * 64 + col);
+                            const f32x4 sv = ep.post ? *reinterpret_cast<const f32x4 *>(ep.post + n0 + sl * 64 + col) : f32x4{1.f, 1.f, 1.f, 1.f};
                             f32x4 val = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], ep.post_scale, bv[e]);
+                            for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], sv[e], bv[e]);
                             *reinterpret_cast<f32x4 *>(smem + (wm * 64 + i * 32 + (lane & 31)) * kRowE + col * 4) = val;
                         }
             }
@@ -561,8 +563,9 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma_kernel(typename Loader::Pa
                 f32x4 val = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
                 if (EPI != EPI_PARTIAL) {
                     const f32x4 bv = *reinterpret_cast<const f32x4 *>(ep.bias + nb + 8 * q);
+                    const f32x4 sv = (SPLIT && ep.post) ? *reinterpret_cast<const f32x4 *>(ep.post + nb + 8 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], ep.post_scale, bv[e]);  // post_scale = 1: the plain add
+                    for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], sv[e], bv[e]);  // 1: the plain add
                 }
                 if (EPI == EPI_BIAS_RES_RELU) val += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off + 32 * q, 0, 0));
                 if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES_RELU || EPI == EPI_BIAS_RELU_PLANES) {

@@ -126,22 +126,22 @@ struct c3_model {
     float *l1_wih16 = nullptr;                    // the same as two fp16 pieces of 128 W_ih (int8 windows)
     float *proj2_pw = nullptr;   // LSTM2 projection weights as dense_planes_pipe_kernel chunks (c3_dense.h)
     float *proj2_pwr = nullptr;  // the same in the register-fragment order of dense_planes_wres_kernel
-    float proj2_pwscale = 1.f;
+    float *proj2_post = nullptr; // [1280] x 2^-k, one power of two for the whole matrix (c3_pack.h), as the vector dense_planes_pipe_kernel reads
+    float proj2_post_scale = 1.f;  // the same 2^-k for dense_planes_wres_kernel
     // full alignment
     float *conv_w[9] = {};   // [Cout][9 Cin] fp32, BatchNorm folded (conv1: [64][3][32], /100 folded): the fp32 forms
     float *conv_b[9] = {};
     float *conv1_w16 = nullptr;  // conv1 of a window with C != 8 as two fp16 pieces for the tiled contraction (keep mode of the 9-channel model)
-    float conv1_wscale = 1.f;
+    float *conv1_w16_post = nullptr;  // its [64] per-channel 2^-k
     float *conv1_wfrag16 = nullptr;  // conv1 as fragments of conv1_i8_f16_kernel / conv3x3_planes_kernel's SRC8 forms (C = 8 or 9)
+    float *conv1_post = nullptr;     // their [64] per-channel 2^-k
     float *pconv_w[9] = {};  // stride-1 convs: conv3x3_planes_kernel chunks [Cout/64][Cin/64][9][64][16 pieces of 16 B];
                              // stride-2 convs: dense_planes_pipe_kernel<true> chunks [Cout/128][9 Cin/64][128][16 pieces]
-    float pconv_wscale[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
-    // fp16x3: a weight tensor is packed times a power of two (pick_wscale: as close to 256 as keeps max |w| * scale below
-    // 16384, so the low piece is a normal fp16 number and the high piece cannot overflow); undone, exactly, in the epilogues
+    float *pconv_pre[9] = {}, *pconv_post[9] = {};  // [Cout] the output channels' powers of two 2^k / 2^-k (c3_pack.h row_scales)
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout (fp32 form)
-    float *l4_w16 = nullptr;                 // the same as two fp16 pieces [2][FC][K4]
-    float l4_wscale = 1.f;
+    float *l4_w16 = nullptr;                 // the same as two fp16 pieces [2][FC][K4], every feature row times its power of two
+    float *l4_pre = nullptr, *l4_post = nullptr;  // [FC] 2^k / 2^-k
     float *b5 = nullptr;
     float *w5f = nullptr, *whf = nullptr, *bh48 = nullptr;  // L5 / head weights as fragments of fc_tail_mfma_kernel (c3_tail.h)
     float *zeros = nullptr;  // 256-byte zero page: padding taps of the conv loaders read from here

@@ -249,7 +249,8 @@ int c3_model_destroy(c3_model *m) {
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
                    m->l4_w, m->l4_b, m->l4_w16, m->b5, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias, m->conv1_w16,
-                   m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_pw, m->proj2_pwr};
+                   m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_pw, m->proj2_pwr, m->proj2_post, m->conv1_post,
+                   m->conv1_w16_post, m->l4_pre, m->l4_post};
     for (float *p : ws)
         if (p) (void)hipFree(p);
     if (m->decode_dev) (void)hipFree(m->decode_dev);
@@ -259,6 +260,8 @@ int c3_model_destroy(c3_model *m) {
         if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);
         if (m->pconv_w[l]) (void)hipFree(m->pconv_w[l]);
+        if (m->pconv_pre[l]) (void)hipFree(m->pconv_pre[l]);
+        if (m->pconv_post[l]) (void)hipFree(m->pconv_post[l]);
     }
     for (auto &sl : m->slot) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);

@@ -5,27 +5,34 @@
 #pragma once
 #include "c3_model.h"
 
-// fp16x3: a weight tensor is packed times a power of two: as close to 256 as keeps max |w| * scale below 16384 -- the low
-// piece of a small weight then stays a normal fp16 number and the high piece of a large one cannot overflow; the factor is
-// undone, exactly, inside the bias FMA of the consuming kernel's epilogue (post_scale).
-static float pick_wscale(const float *w, size_t n) {
-    float mx = 0.f;
-    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
-    float s = 256.f;
-    while (s > 1.f / 65536.f && mx * s >= 16384.f) s *= 0.5f;
-    return s;
+// fp16x3: every OUTPUT ROW of a weight matrix (one output channel of a convolution with its BatchNorm folded in, one gate row
+// of a projection, one L4 feature) is packed times its own power of two 2^k, chosen so that the row's largest weight lands in
+// [4096, 8192): the high fp16 piece cannot overflow, and the low piece of a weight stays a NORMAL fp16 number down to 2^-16 of
+// the row's maximum.  (With one factor per tensor -- rounds 1 and 2 -- a channel whose folded weights were 1e-4 of the tensor's
+// maximum, as a BatchNorm with a small gamma / sigma produces, kept only ~13 bits of its weights: its low pieces were fp16
+// subnormals.)  The factor is undone, exactly, by the per-channel multiplier of the bias FMA in the consuming kernel's
+// epilogue (`post` = 2^-k next to the bias vector).
+static void row_scales(const float *w, int rows, size_t cols, std::vector<float> &scale, std::vector<float> &post) {
+    scale.assign(rows, 1.f), post.assign(rows, 1.f);
+    for (int r = 0; r < rows; ++r) {
+        float mx = 0.f;
+        for (size_t i = 0; i < cols; ++i) mx = std::max(mx, std::fabs(w[(size_t)r * cols + i]));
+        if (!(mx > 0.f) || !std::isfinite(mx)) continue;
+        int e;
+        (void)std::frexp(mx, &e);                         // mx = f * 2^e, f in [0.5, 1)
+        const int k = std::min(100, std::max(-100, 13 - e));  // mx * 2^k in [4096, 8192)
+        scale[r] = std::ldexp(1.f, k), post[r] = std::ldexp(1.f, -k);
+    }
 }
 
-// A weight matrix as fp16 pieces for the SPLIT form of gemm_mfma_kernel, layout [2][n] (uint16 payload carried in a float
-// allocation): w * scale = h0 + h1.
-static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float> &w, float *scale_out) {
-    const float wscale = pick_wscale(w.data(), w.size());
-    *scale_out = wscale;
-    const size_t n = w.size();
+// A weight matrix [rows][cols] as fp16 pieces for the SPLIT form of gemm_mfma_kernel, layout [2][rows * cols] (uint16 payload
+// carried in a float allocation): w * scale[row] = h0 + h1.
+static int upload_split_pieces(c3_model *m, float **dst, const std::vector<float> &w, int rows, const std::vector<float> &scale) {
+    const size_t n = w.size(), cols = n / rows;
     std::vector<float> pieces(n);  // 2 pieces x n x 2 bytes
     uint16_t *q = reinterpret_cast<uint16_t *>(pieces.data());
     for (size_t i = 0; i < n; ++i) {
-        const float r = w[i] * wscale;  // exact; undone by post_scale in the kernels' epilogues
+        const float r = w[i] * scale[i / cols];  // exact
         const _Float16 h0 = (_Float16)r, h1 = (_Float16)(r - (float)h0);
         memcpy(&q[i], &h0, 2);
         memcpy(&q[n + i], &h1, 2);
@@ -60,7 +67,13 @@ static int pack_tail(c3_model *m, const TensorMap &tm) {
     TRY(want(tm, "L4.weight", {FC, K4}, &w));
     TRY(want(tm, "L4.bias", {FC}, &b));
     TRY(upload(m, &m->l4_w, std::vector<float>(w, w + (size_t)FC * K4)));
-    TRY(upload_split_pieces(m, &m->l4_w16, std::vector<float>(w, w + (size_t)FC * K4), &m->l4_wscale));
+    {
+        std::vector<float> sc, post;
+        row_scales(w, FC, (size_t)K4, sc, post);
+        TRY(upload_split_pieces(m, &m->l4_w16, std::vector<float>(w, w + (size_t)FC * K4), FC, sc));
+        TRY(upload(m, &m->l4_pre, sc));
+        TRY(upload(m, &m->l4_post, post));
+    }
     TRY(upload(m, &m->l4_b, std::vector<float>(b, b + FC)));
     std::vector<float> w5t((size_t)FC * nb * 128), b5((size_t)nb * 128), wh((size_t)nb * 128 * 64, 0.f), bh((size_t)nb * 64, 0.f);
     for (int br = 0; br < nb; ++br) {
@@ -171,9 +184,13 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
             const int N = 2 * 4 * H;
             if (N % kDnBN == 0) {
                 // dense_planes_pipe_kernel: chunk (column tile of 128, k chunk of 64) = 128 rows x 256 B; piece g < 8 = hi of
-                // k 64 kc + 8 g .. + 7, g >= 8 = lo of the same k; times a power of two (pick_wscale)
-                const float sc = pick_wscale(pw.data(), pw.size());
-                m->proj2_pwscale = sc;
+                // k 64 kc + 8 g .. + 7, g >= 8 = lo of the same k; times ONE power of two for the whole matrix (its rows are plain LSTM
+                // weights -- no folded BatchNorm -- and dense_planes_wres_kernel has no register left for a per-row vector)
+                std::vector<float> sc1, post1;
+                row_scales(pw.data(), 1, pw.size(), sc1, post1);
+                const std::vector<float> sc(N, sc1[0]), post(N, post1[0]);
+                m->proj2_post_scale = post1[0];
+                TRY(upload(m, &m->proj2_post, post));
                 const int NKc = 256 / 64;
                 std::vector<float> pk((size_t)N * 256);
                 uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
@@ -182,7 +199,7 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                         for (int r = 0; r < kDnBN; ++r)
                             for (int g = 0; g < 16; ++g)
                                 for (int j = 0; j < 8; ++j) {
-                                    const float v = pw[(size_t)(tn * kDnBN + r) * Kp + kc * 64 + 8 * (g & 7) + j] * sc;  // exact
+                                    const float v = pw[(size_t)(tn * kDnBN + r) * Kp + kc * 64 + 8 * (g & 7) + j] * sc[tn * kDnBN + r];  // exact
                                     const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
                                     const _Float16 piece = g < 8 ? h0 : h1;
                                     memcpy(&q16[(((((size_t)tn * NKc + kc) * kDnBN + r) * 16 + g) * 8) + j], &piece, 2);
@@ -198,7 +215,8 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
                             for (int ks = 0; ks < kWrKS; ++ks)
                                 for (int lane = 0; lane < 64; ++lane)
                                     for (int j = 0; j < 8; ++j) {
-                                        const float v = pw[(size_t)(tn * kWrBN + 32 * w + (lane & 31)) * Kp + 16 * ks + 8 * (lane >> 5) + j] * sc;  // exact
+                                        const float v = pw[(size_t)(tn * kWrBN + 32 * w + (lane & 31)) * Kp + 16 * ks + 8 * (lane >> 5) + j] *
+                                                        sc[tn * kWrBN + 32 * w + (lane & 31)];  // exact
                                         const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
                                         const size_t base = ((((size_t)tn * 8 + w) * kWrKS + ks) * 2) * 64 * 8;
                                         memcpy(&r16[base + (size_t)lane * 8 + j], &h0, 2);
@@ -331,7 +349,22 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     TRY(upload(m, &m->conv_w[l], pw));
     TRY(upload(m, &m->conv_b[l], pb));
     if (l == 0 && Cin != 8)  // conv1 as its own launch runs on the tiled contraction unless the window has 8 channels
-        TRY(upload_split_pieces(m, &m->conv1_w16, pw, &m->conv1_wscale));
+    {
+        std::vector<float> sc, post;
+        row_scales(pw.data(), Cout, (size_t)ldb, sc, post);
+        TRY(upload_split_pieces(m, &m->conv1_w16, pw, Cout, sc));
+        TRY(upload(m, &m->conv1_w16_post, post));
+    }
+    std::vector<float> c1s, c1post;  // conv1's fragments carry their output channel's power of two as well (undone by c1post in the kernels)
+    if (l == 0 && (Cin == 8 || Cin == 9)) {
+        std::vector<float> v1((size_t)64 * 9 * Cin);
+        for (int co = 0; co < 64; ++co) {
+            const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+            for (int i = 0; i < 9 * Cin; ++i) v1[(size_t)co * 9 * Cin + i] = (float)((double)w[(size_t)co * 9 * Cin + i] * scale * (128.0 / 100.0));
+        }
+        row_scales(v1.data(), 64, (size_t)9 * Cin, c1s, c1post);
+        TRY(upload(m, &m->conv1_post, c1post));
+    }
     if (l == 0 && Cin == 8) {
         {
             // conv1_i8_f16_kernel: lane (n = lane & 31, kh = lane >> 5) of k-step t holds channel j of tap 2 t + kh
@@ -345,7 +378,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                             float v = 0.f;
                             if (tap < 9) {
                                 const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
-                                v = (float)((double)w[(((size_t)co * Cin + j) * 3 + tap / 3) * 3 + tap % 3] * scale * (128.0 / 100.0));  // the kernel feeds x / 128
+                                v = (float)((double)w[(((size_t)co * Cin + j) * 3 + tap / 3) * 3 + tap % 3] * scale * (128.0 / 100.0)) * c1s[co];  // the kernel feeds x / 128
                             }
                             const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
                             memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 0) * 64 + lane) * 8 + j], &h0, 2);
@@ -375,7 +408,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                         float v = 0.f;
                         if (q < 27) {
                             const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
-                            v = (float)((double)w[(((size_t)co * Cin + q % 9) * 3 + ky) * 3 + q / 9] * scale * (128.0 / 100.0));
+                            v = (float)((double)w[(((size_t)co * Cin + q % 9) * 3 + ky) * 3 + q / 9] * scale * (128.0 / 100.0)) * c1s[co];
                         }
                         const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
                         memcpy(&q16[((((size_t)t * 2 + cb) * 2 + 0) * 64 + lane) * 8 + j], &h0, 2);
@@ -386,10 +419,12 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     }
     if (kConvStride[l] == 1 && Cin == Cout && Cin % 64 == 0) {
         // conv3x3_planes_kernel: chunk (column tile tn, input slab, tap) = 64 couts x 256 B; piece g < 8 = hi of channels
-        // 64 slab + 8 g .. + 7, g >= 8 = lo of channels 8 (g - 8) ..; times a power of two (pick_wscale), undone by post_scale
+        // 64 slab + 8 g .. + 7, g >= 8 = lo of channels 8 (g - 8) ..; times the output channel's power of two (row_scales)
         const int NS = Cin / 64;
-        const float sc = pick_wscale(pw.data(), pw.size());
-        m->pconv_wscale[l] = sc;
+        std::vector<float> sc, post;
+        row_scales(pw.data(), Cout, (size_t)ldb, sc, post);
+        TRY(upload(m, &m->pconv_pre[l], sc));
+        TRY(upload(m, &m->pconv_post[l], post));
         std::vector<float> pk((size_t)NS * NS * 9 * 64 * 64);  // 16 KB per chunk
         uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
         for (int tn = 0; tn < NS; ++tn)
@@ -399,7 +434,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                         for (int g = 0; g < 16; ++g)
                             for (int j = 0; j < 8; ++j) {
                                 const int co = tn * 64 + n, ci = slab * 64 + 8 * (g & 7) + j;
-                                const float v = pw[(size_t)co * ldb + (size_t)tap * Cin + ci] * sc;  // exact
+                                const float v = pw[(size_t)co * ldb + (size_t)tap * Cin + ci] * sc[co];  // exact
                                 const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
                                 const _Float16 piece = g < 8 ? h0 : h1;
                                 memcpy(&q16[((((((size_t)tn * NS + slab) * 9 + tap) * 64 + n) * 16 + g) * 8) + j], &piece, 2);
@@ -409,8 +444,10 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kDnBN == 0) {
         // dense_planes_pipe_kernel<true>: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
         const int NS = Cin / 64, NKc = 9 * NS;
-        const float sc = pick_wscale(pw.data(), pw.size());
-        m->pconv_wscale[l] = sc;
+        std::vector<float> sc, post;
+        row_scales(pw.data(), Cout, (size_t)ldb, sc, post);
+        TRY(upload(m, &m->pconv_pre[l], sc));
+        TRY(upload(m, &m->pconv_post[l], post));
         std::vector<float> pk((size_t)Cout * NKc * 64);
         uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
         for (int tn = 0; tn < Cout / kDnBN; ++tn)
@@ -419,7 +456,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                     for (int g = 0; g < 16; ++g)
                         for (int j = 0; j < 8; ++j) {
                             const int tap = kc / NS, slab = kc % NS;
-                            const float v = pw[(size_t)(tn * kDnBN + r) * ldb + (size_t)tap * Cin + slab * 64 + 8 * (g & 7) + j] * sc;  // exact
+                            const float v = pw[(size_t)(tn * kDnBN + r) * ldb + (size_t)tap * Cin + slab * 64 + 8 * (g & 7) + j] * sc[tn * kDnBN + r];  // exact
                             const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
                             const _Float16 piece = g < 8 ? h0 : h1;
                             memcpy(&q16[(((((size_t)tn * NKc + kc) * kDnBN + r) * 16 + g) * 8) + j], &piece, 2);

@@ -24,8 +24,9 @@ struct ReduceParams {
     const float *bias;  // [FC]
     float *out;         // [n][FC]
     int n, FC, S;
-    float pre = 1.f, post = 1.f;  // the partials carry a power-of-two factor `pre` (SPLIT weights, c3_gemm.h): the bias joins
-                                  // the sum times `pre`, the result leaves times `post` = 1 / pre -- bit-identical to the unscaled sum
+    const float *pre = nullptr, *post = nullptr;  // [FC]: the partials of feature k carry the power of two pre[k] (SPLIT weights,
+                                                  // c3_pack.h row_scales): the bias joins the sum times pre[k], the result leaves
+                                                  // times post[k] = 1 / pre[k] -- bit-identical to the unscaled sum; nullptr = 1
 };
 
 __global__ __launch_bounds__(256) void splitk_reduce_selu_kernel(ReduceParams p) {
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_selu_kernel(ReduceParams p)
     if (i >= total) return;
     const int k = (int)(i % p.FC);
     const float *src = p.part + i;
-    float v = p.bias[k] * p.pre;
+    float v = p.pre ? p.bias[k] * p.pre[k] : p.bias[k];
     int s = 0;
     for (; s < p.S; s += 8) {  // 8 independent loads in flight (the last batch clamps its surplus), summed in order
         float t[8];
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_selu_kernel(ReduceParams p)
         for (int u = 0; u < 8; ++u)
             if (s + u < p.S) v += t[u];
     }
-    p.out[i] = selu_f(v * p.post);
+    p.out[i] = selu_f(p.post ? v * p.post[k] : v);
 }
 
 struct Tail2Params {

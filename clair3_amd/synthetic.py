@@ -70,11 +70,13 @@ def state_dict_spec(kind, in_channels=None, add_indel_length=False):
     return spec
 
 
-def make_state_dict(kind, in_channels=None, add_indel_length=False, seed=0, peaked=False):
+def make_state_dict(kind, in_channels=None, add_indel_length=False, seed=0, peaked=False, trained_like=False):
     """Seeded random float32 state_dict (numpy arrays) that loads strictly into the reference module.
 
     BatchNorm statistics are randomised (default init is an identity and would hide BN-folding bugs);
-    ``peaked=True`` scales the head weights x8 so the soft-max outputs approach 0/1 like a trained model.
+    ``peaked=True`` scales the head weights x8 so the soft-max outputs approach 0/1 like a trained model;
+    ``trained_like=True`` re-parametrises the same network the way training leaves one (``_trained_like``): per-channel
+    scales spread over orders of magnitude, zero ``bias_hh``, a few large LSTM weights.
     """
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
@@ -111,7 +113,62 @@ def make_state_dict(kind, in_channels=None, add_indel_length=False, seed=0, peak
         sd[name] = np.ascontiguousarray(v, dtype=np.float32)
         if leaf == "running_var":
             sd[name[: -len("running_var")] + "num_batches_tracked"] = np.array(0, dtype=np.int64)
+    if trained_like:
+        _trained_like(sd, kind, np.random.default_rng(seed + 7919))
     return sd
+
+
+def _trained_like(sd, kind, rng):
+    """What a TRAINED checkpoint looks like that seeded initialisation does not: per-channel magnitudes spread over orders of
+    magnitude.  Every change below is a re-parametrisation under which the network computes the same function (up to
+    rounding), so activations stay in their ordinary range while the weights do not:
+
+    full alignment
+      * pre-BatchNorm scale t_c = 10^U(-1.5, 1.5) of every convolution output channel: conv weight / bias, running_mean times
+        t_c, running_var times t_c^2 -- gamma / sqrt(running_var) then spreads over 1e-3 .. 1e3 between channels;
+      * post-BatchNorm scale s_c = 10^U(-2.5, 0.3) of every channel (ReLU is positively homogeneous): gamma and beta of its
+        producers times s_c, the weights of its consumers that read it divided by s_c.  Channels of a stage are produced by the
+        stage convolution AND the residual block's second BatchNorm (the identity add) and consumed by the block's first
+        convolution and the next stage (the last stage: by L4 through the pyramid pooling, 14 bins x 256 channels); channels
+        inside a block by bn1 / conv2.  The BatchNorm-folded weights of a channel then scale with s_c: 2.8 decades between
+        the channels of one tensor, and 2.8 decades between the input channels inside every consumer row.
+    pileup (the TF -> torch converter leaves LSTM biases that way, convert_tf_checkpoint_to_torch.py:95-106)
+      * bias_hh = 0 (TF has one bias per gate; it lands in bias_ih);
+      * one weight in a thousand of W_ih / W_hh replaced by +-8.
+    """
+    if kind == PILEUP:
+        for name in list(sd):
+            if name.startswith("LSTM") and ".bias_hh" in name:
+                sd[name][...] = 0.0
+            elif name.startswith("LSTM") and ".weight_" in name:
+                w = sd[name]
+                hit = rng.random(w.shape) < 1e-3
+                w[hit] = np.where(rng.random(int(hit.sum())) < 0.5, -8.0, 8.0).astype(np.float32)
+                if name.startswith("LSTM1.weight_ih"):
+                    w[hit] *= 0.05  # the counts reach +-100 (see make_state_dict)
+        return
+    for conv, bn, _, cout, _ in FA_CONV_LAYERS:
+        t = (10.0 ** rng.uniform(-1.5, 1.5, size=cout)).astype(np.float32)
+        sd[f"{conv}.weight"] *= t[:, None, None, None]
+        sd[f"{conv}.bias"] *= t
+        sd[f"{bn}.running_mean"] *= t
+        sd[f"{bn}.running_var"] *= t * t
+    stages = (("conv1", "res_block1.0", "conv3.conv"), ("conv3", "res_block2.0", "conv5.conv"), ("conv5", "res_block3.0", None))
+    for stage, block, nxt in stages:
+        cout = sd[f"{stage}.bn.weight"].shape[0]
+        s_stage = (10.0 ** rng.uniform(-2.5, 0.3, size=cout)).astype(np.float32)
+        s_inner = (10.0 ** rng.uniform(-2.5, 0.3, size=cout)).astype(np.float32)
+        for bn in (f"{stage}.bn", f"{block}.bn2"):  # producers of the stage's channels
+            sd[f"{bn}.weight"] *= s_stage
+            sd[f"{bn}.bias"] *= s_stage
+        sd[f"{block}.conv1.weight"] /= s_stage[None, :, None, None]
+        if nxt is not None:
+            sd[f"{nxt}.weight"] /= s_stage[None, :, None, None]
+        else:  # PyramidPolling flattens (bin, channel): L4 column bin * 256 + c reads channel c
+            sd["L4.weight"] /= np.tile(s_stage, sd["L4.weight"].shape[1] // cout)[None, :]
+        sd[f"{block}.bn1.weight"] *= s_inner
+        sd[f"{block}.bn1.bias"] *= s_inner
+        sd[f"{block}.conv2.weight"] /= s_inner[None, :, None, None]
 
 
 def make_pileup_windows(batch, seed=0, recipe="realistic", dtype=np.int8, channels=PILEUP_CHANNELS):

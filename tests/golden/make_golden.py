@@ -42,7 +42,13 @@ CASES = [
     ("fa_dwell", syn.FULL_ALIGNMENT, 9, True, 3, False, 3, "realistic", 16, "int8"),
     ("fa_no_indel_heads", syn.FULL_ALIGNMENT, 8, False, 4, False, 4, "realistic", 8, "int8"),
     ("fa_hifi_depth55", syn.FULL_ALIGNMENT, 8, True, 5, False, 5, "realistic", 12, "int8"),
+    # weights re-parametrised the way training leaves them (clair3_amd/synthetic.py _trained_like): per-channel BatchNorm
+    # gamma / sigma over 1e-3 .. 1e3, channel magnitudes over 2.8 decades, zero bias_hh, a few +-8 LSTM weights
+    ("fa_trained_like", syn.FULL_ALIGNMENT, 8, True, 6, True, 6, "realistic", 16, "int8"),
+    ("fa_dwell_trained_like", syn.FULL_ALIGNMENT, 9, True, 7, False, 7, "realistic", 8, "int8"),
+    ("pileup_trained_like", syn.PILEUP, 18, False, 8, True, 8, "realistic", 32, "int8"),
 ]
+TRAINED_LIKE = {"fa_trained_like", "fa_dwell_trained_like", "pileup_trained_like"}
 # matrix depth of the full-alignment cases that are not ONT (shared/param_f.py:11: hifi / ilmn = 55 rows)
 DEPTH = {"fa_hifi_depth55": 55}
 
@@ -61,7 +67,7 @@ def sd_digest(sd):
 
 def case_inputs(case):
     name, kind, ch, indel, wseed, peaked, xseed, recipe, batch, xdt = case
-    sd = syn.make_state_dict(kind, ch, indel, seed=wseed, peaked=peaked)
+    sd = syn.make_state_dict(kind, ch, indel, seed=wseed, peaked=peaked, trained_like=name in TRAINED_LIKE)
     if kind == syn.PILEUP:
         x = syn.make_pileup_windows(batch, xseed, recipe, dtype=np.dtype(xdt), channels=ch)
     else:
@@ -147,6 +153,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
         manifest[name] = dict(kind=kind, channels=ch, add_indel_length=indel, weight_seed=wseed, peaked=peaked,
                               input_seed=xseed, recipe=recipe, batch=batch, x_dtype=xdt, x_sha=digest(x),
+                              trained_like=name in TRAINED_LIKE,
                               depth=(int(x.shape[1]) if kind == syn.FULL_ALIGNMENT else None),
                               sd_sha=sd_digest(sd), y_sha=digest(y), positions=pos, alt_info=alt, vcf_rows=rows,
                               torch=torch.__version__)

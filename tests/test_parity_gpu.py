@@ -352,8 +352,74 @@ def test_plane_pipeline_stays_at_fp32_level(monkeypatch, oracle_mod):
             assert v <= 5 * errs[(ch, "fp32")][k] + 3e-7, (ch, k, errs)
 
 
+def _layer_errors(m, d, names):
+    """per layer: max |a - d| over the tensor relative to the tensor's range, and the worst CHANNEL relative to that channel's own
+    range (a channel whose values are 1e-3 of the tensor's is invisible in the first number and is what the next layer's
+    large weights amplify)"""
+    whole, chan = {}, {}
+    for name in names:
+        a = m.debug_fetch(name, d[name].shape)
+        assert np.isfinite(a).all(), name
+        err = np.abs(a - d[name]).reshape(-1, a.shape[-1]).max(0)
+        rng = np.abs(d[name]).reshape(-1, a.shape[-1]).max(0)
+        whole[name] = float(err.max()) / max(1.0, float(rng.max()))
+        live = rng > 1e-6
+        chan[name] = float((err[live] / rng[live]).max()) if live.any() else 0.0
+    return whole, chan
+
+
+@pytest.mark.parametrize("channels", [8, 9])
+def test_trained_like_weights_layer_by_layer(channels, monkeypatch, oracle_mod):
+    """weights re-parametrised the way training leaves them (synthetic._trained_like: BatchNorm gamma / sigma over 1e-3 .. 1e3,
+    channel magnitudes -- and with them the folded weights of a tensor's channels and the input channels inside every weight
+    row -- over 2.8 decades).  Every layer against the fp64 oracle next to the fp32-MFMA forms: per tensor AND per channel
+    (relative to the channel's own range), where a power of two per TENSOR (rounds 1-2) lost the small channels to fp16
+    subnormals; the power of two is per output channel now (c3_pack.h row_scales)"""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, channels, True, seed=141, peaked=True, trained_like=True)
+    x = syn.make_fa_windows(9, seed=142, channels=channels)
+    y_o, d = oracle_mod.fa_forward(sd, x, True, debug=True)
+    names = [f"act{l}" for l in range(9)]
+    res = {}
+    for mode, env in (("f16x3", {}), ("fp32", {"C3HIP_FP32": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = make_model(syn.FULL_ALIGNMENT, channels, True, sd, keep=True)
+        y = m.predict_numpy(x)
+        assert m.range_status() == (0, mode == "fp32")
+        whole, chan = _layer_errors(m, d, names)
+        whole["y"] = util.assert_rows_match(y, y_o, what=f"trained-like, C={channels}, {mode}")
+        res[mode] = (whole, chan)
+        for k in env:
+            monkeypatch.delenv(k)
+    print(f"C={channels} per tensor (x1e-6: f16x3, fp32):", {k: (round(res['f16x3'][0][k] * 1e6, 2), round(res['fp32'][0][k] * 1e6, 2)) for k in res["fp32"][0]})
+    print(f"C={channels} worst channel (x1e-6: f16x3, fp32):", {k: (round(res['f16x3'][1][k] * 1e6, 2), round(res['fp32'][1][k] * 1e6, 2)) for k in res["fp32"][1]})
+    for k, v in res["f16x3"][0].items():
+        assert v < 2e-5, (k, v)
+        assert v <= 5 * res["fp32"][0][k] + 3e-7, (k, v, res["fp32"][0][k])
+    for k, v in res["f16x3"][1].items():
+        assert v < 1e-4, (k, v)
+        assert v <= 5 * res["fp32"][1][k] + 2e-6, (k, v, res["fp32"][1][k])
+    # the fused product path (conv1 inside res1a / res1b, pooling inside res3b) on the same weights
+    y = make_model(syn.FULL_ALIGNMENT, channels, True, sd).predict_numpy(x)
+    assert util.assert_rows_match(y, y_o, what=f"trained-like, C={channels}, product path") < 2e-5
+
+
+def test_trained_like_pileup_layers(oracle_mod):
+    """zero bias_hh (what the TF -> torch converter leaves) and a few +-8 weights in the LSTMs: layer outputs vs the oracle"""
+    sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=151, peaked=True, trained_like=True)
+    x = syn.make_pileup_windows(70, seed=152)
+    y_o, d = oracle_mod.pileup_forward(sd, x, False, debug=True)
+    m = make_model(syn.PILEUP, 18, False, sd, keep=True)
+    y = m.predict_numpy(x)
+    for name in ("lstm1_out", "lstm2_out"):
+        a = m.debug_fetch(name, d[name].shape)
+        assert float(np.abs(a - d[name]).max()) < 2e-5, name
+    assert util.assert_rows_match(y, y_o, what="trained-like pileup") < 2e-5
+    util.assert_rows_match(m.predict_numpy(x.astype(np.int32)), y_o, what="trained-like pileup, int32 windows")
+
+
 def test_large_folded_weights_keep_their_fp16_pieces_in_range(oracle_mod):
-    """fp16x3 packs a weight tensor times a power of two picked per tensor (c3_model.hip pick_wscale).  A BatchNorm with a
+    """fp16x3 packs every output channel of a weight tensor times its own power of two (c3_pack.h row_scales).  A BatchNorm with a
     large gamma / sigma (folded conv3 weights up to ~600 here, activations of that stage ~1000) must shrink that factor
     instead of overflowing the high fp16 piece; the next stage's BatchNorm brings the range back."""
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=51)

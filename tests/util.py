@@ -23,7 +23,7 @@ def manifest():
 
 def case_inputs(meta):
     sd = syn.make_state_dict(meta["kind"], meta["channels"], meta["add_indel_length"], seed=meta["weight_seed"],
-                             peaked=meta["peaked"])
+                             peaked=meta["peaked"], trained_like=meta.get("trained_like", False))
     if meta["kind"] == syn.PILEUP:
         x = syn.make_pileup_windows(meta["batch"], meta["input_seed"], meta["recipe"], dtype=np.dtype(meta["x_dtype"]),
                                     channels=meta["channels"])

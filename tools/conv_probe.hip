@@ -46,7 +46,7 @@ template <int C> static int shape(const char *name, int B, int H, int W, int slo
     CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, C * 4)); CK(hipMemset(flag, 0, 256));
     PlaneConvParams cp;
-    cp.x = x, cp.w = w, cp.bias = bias, cp.res = r, cp.out = y, cp.range_flag = flag, cp.post_scale = 1.f;
+    cp.x = x, cp.w = w, cp.bias = bias, cp.res = r, cp.out = y, cp.range_flag = flag, cp.post = bias, cp.pre = bias;
     cp.M = B * H * W, cp.H = H, cp.W = W;
     cp.mg_hw = (uint32_t)((1ull << 32) / (uint64_t)(H * W) + 1), cp.mg_w = (uint32_t)((1ull << 32) / (uint64_t)W + 1);  // fast_div magics
     const int tiles_m = (cp.M + kPlBM - 1) / kPlBM;

@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(dbias, 0, N * 4));
     DensePlanesParams dp;
-    dp.a = da, dp.w = dw, dp.bias = dbias, dp.c = dc, dp.post_scale = 1.f / 256.f;
+    dp.a = da, dp.w = dw, dp.bias = dbias, dp.c = dc, dp.post = dbias;
     dp.M = M, dp.N = N, dp.K = K, dp.tiles_n = N / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
     const int grid = dp.tiles < 256 ? dp.tiles : 256;
     const double gflop = 2.0 * M * N * K * 3 * 1e-9;
