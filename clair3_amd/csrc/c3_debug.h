@@ -43,6 +43,16 @@ int c3_debug_fetch(c3_model *m, const char *name, float *host_out, int64_t n_flo
     if (!src) return fail("unknown debug tensor \"%s\"", name);
     if (n != n_floats) return fail("debug tensor %s has %lld floats, caller expects %lld", name, (long long)n, (long long)n_floats);
     HIP_TRY(hipDeviceSynchronize());
+    // activations of the full-alignment network live on the device with every channel times its power of two (channel
+    // equalisation, c3_pack.h): hand the caller the values of the checkpoint as given
+    const std::vector<int> *exps = nullptr;
+    if (m->kind == C3_KIND_FULL_ALIGNMENT && s.compare(0, 3, "act") == 0) exps = &m->act_exp[s[3] - '0'];
+    if (m->kind == C3_KIND_FULL_ALIGNMENT && s == "spp") exps = &m->act_exp[8];
+    auto unscale = [&]() {
+        if (!exps || exps->empty()) return;
+        const size_t C = exps->size();
+        for (int64_t i = 0; i < n; ++i) host_out[i] = std::ldexp(host_out[i], -(*exps)[(size_t)i % C]);
+    };
     if (m->last_planes && ((m->kind == C3_KIND_FULL_ALIGNMENT && s.compare(0, 3, "act") == 0) || (m->kind == C3_KIND_PILEUP && s == "lstm1_out"))) {
         // the layer holds plane activations (c3_conv3.h): hand the caller the fp32 values they stand for
         const int C = m->kind == C3_KIND_PILEUP ? 256 : kConvCout[s[3] - '0'];
@@ -52,9 +62,11 @@ int c3_debug_fetch(c3_model *m, const char *name, float *host_out, int64_t n_flo
         hipError_t e = hipMemcpy(host_out, tmp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
         if (e != hipSuccess) return fail("debug fetch copy failed: %s", hipGetErrorString(e));
+        unscale();
         return 0;
     }
     HIP_TRY(hipMemcpy(host_out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    unscale();
     return 0;
 }
 

@@ -144,6 +144,7 @@ struct c3_model {
     float *l4_pre = nullptr, *l4_post = nullptr;  // [FC] 2^k / 2^-k
     float *b5 = nullptr;
     float *w5f = nullptr, *whf = nullptr, *bh48 = nullptr;  // L5 / head weights as fragments of fc_tail_mfma_kernel (c3_tail.h)
+    std::vector<int> act_exp[9];  // channel equalisation (c3_pack.h): activation channel c of layer l lives on the device times 2^act_exp[l][c]
     float *zeros = nullptr;  // 256-byte zero page: padding taps of the conv loaders read from here
     int FC = 0, K4 = 0;
 

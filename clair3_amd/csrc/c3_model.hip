@@ -154,13 +154,17 @@ int c3_model_load(c3_model *m, const c3_tensor_desc *tensors, int n_tensors) {
     } else {
         int cin = m->C;
         if (3 * cin > 32) return fail("full-alignment input_channels %d not supported (3*C must be <= 32)", cin);
+        FaChannelExps ex;
+        TRY(fa_channel_exps(tm, ex));
         for (int l = 0; l < 9; ++l) {
-            TRY(pack_conv(m, tm, l, cin));
+            TRY(pack_conv(m, tm, l, cin, ex));
+            m->act_exp[l] = *ex.out_of(l);
             cin = kConvCout[l];
         }
         expected = 54;
+        TRY(pack_tail(m, tm, &ex.stage[2]));
     }
-    TRY(pack_tail(m, tm));
+    if (m->kind == C3_KIND_PILEUP) TRY(pack_tail(m, tm));
     expected += 2 + 4 * (size_t)m->nb;
     if (tm.size() != expected) {
         // strict like load_state_dict: report the first unexpected key

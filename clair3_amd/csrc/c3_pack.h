@@ -61,16 +61,23 @@ static int want(const TensorMap &tm, const std::string &name, std::initializer_l
     return 0;
 }
 
-static int pack_tail(c3_model *m, const TensorMap &tm) {
+// l4_in_exp: the channel exponents of the tensor L4 reads (full alignment: the last stage's, column j reads channel j % 256 --
+// PyramidPolling flattens (bin, channel)); nullptr for the pileup network
+static int pack_tail(c3_model *m, const TensorMap &tm, const std::vector<int> *l4_in_exp = nullptr) {
     const int FC = m->FC, K4 = m->K4, nb = m->nb;
-    const float *w, *b;
-    TRY(want(tm, "L4.weight", {FC, K4}, &w));
+    const float *w0, *b;
+    TRY(want(tm, "L4.weight", {FC, K4}, &w0));
     TRY(want(tm, "L4.bias", {FC}, &b));
-    TRY(upload(m, &m->l4_w, std::vector<float>(w, w + (size_t)FC * K4)));
+    std::vector<float> w4(w0, w0 + (size_t)FC * K4);
+    if (l4_in_exp)
+        for (int f = 0; f < FC; ++f)
+            for (int j = 0; j < K4; ++j) w4[(size_t)f * K4 + j] = std::ldexp(w4[(size_t)f * K4 + j], -(*l4_in_exp)[j % l4_in_exp->size()]);
+    const float *w = w4.data();
+    TRY(upload(m, &m->l4_w, w4));
     {
         std::vector<float> sc, post;
         row_scales(w, FC, (size_t)K4, sc, post);
-        TRY(upload_split_pieces(m, &m->l4_w16, std::vector<float>(w, w + (size_t)FC * K4), FC, sc));
+        TRY(upload_split_pieces(m, &m->l4_w16, w4, FC, sc));
         TRY(upload(m, &m->l4_pre, sc));
         TRY(upload(m, &m->l4_post, post));
     }
@@ -321,8 +328,58 @@ static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in,
 // conv layer l: fold BatchNorm2d(eval, eps=1e-3) into weight and bias (clair3/model.py:191,195-197):
 //   scale = gamma / sqrt(var + eps);  w' = w * scale;  b' = (b - mean) * scale + beta
 // layout [Cout][kh][kw][Cin]; conv1 additionally folds x/100 (model.py:378) and pads each kh to 32 slots.
-static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
+// Channel equalisation (exact): ReLU is positively homogeneous, so the network computes the same function when an activation
+// channel is multiplied by 2^k -- its producers' folded weights and bias times 2^k, the weights of its consumers that read it
+// times 2^-k; powers of two, so every product and sum scales exactly and the rows are the ones of the checkpoint as given.
+// A trained checkpoint may keep a channel at 1e-3 of its neighbours (a small BatchNorm gamma, compensated by large weights in
+// the next layer); as fp16 piece planes such a channel would carry its values with the ABSOLUTE precision of fp16 subnormals
+// (6e-8: 6e-5 relative at 1e-3).  k is chosen per channel so that |gamma| + |beta| of its producers -- the magnitude the
+// BatchNorm gives it -- lands in [1, 2).  Channels of a stage are produced by the stage convolution and by the residual
+// block's second convolution (the identity add: one k for both) and read by the block's first convolution and the next stage
+// (the last stage: by L4 through the pooling); the channels inside a block by conv1+bn1 / conv2.
+struct FaChannelExps {
+    std::vector<int> stage[3], inner[3];  // per stage: exponents of the stage's channels / of the block's inner channels
+    const std::vector<int> *out_of(int l) const { return l % 3 == 1 ? &inner[l / 3] : &stage[l / 3]; }
+    const std::vector<int> *in_of(int l) const { return l == 0 ? nullptr : (l % 3 == 2 ? &inner[l / 3] : &stage[(l - 1) / 3]); }
+};
+static int fa_channel_exps(const TensorMap &tm, FaChannelExps &ex) {
+    auto mags = [&](int l, std::vector<double> &mag) -> int {
+        const int Cout = kConvCout[l];
+        const float *g, *beta;
+        TRY(want(tm, std::string(kBnName[l]) + ".weight", {Cout}, &g));
+        TRY(want(tm, std::string(kBnName[l]) + ".bias", {Cout}, &beta));
+        mag.resize(Cout);
+        for (int c = 0; c < Cout; ++c) mag[c] = std::fabs((double)g[c]) + std::fabs((double)beta[c]);
+        return 0;
+    };
+    auto exps = [](const std::vector<double> &mag, std::vector<int> &k) {
+        k.assign(mag.size(), 0);
+        for (size_t c = 0; c < mag.size(); ++c) {
+            if (!(mag[c] > 0.0) || !std::isfinite(mag[c])) continue;
+            int e;
+            (void)std::frexp(mag[c], &e);                       // mag = f * 2^e, f in [0.5, 1)
+            k[c] = std::min(40, std::max(-40, 1 - e));          // mag * 2^k in [1, 2)
+        }
+    };
+    for (int s = 0; s < 3; ++s) {
+        std::vector<double> a, b2, in;
+        TRY(mags(3 * s, a));
+        TRY(mags(3 * s + 2, b2));
+        TRY(mags(3 * s + 1, in));
+        for (size_t c = 0; c < a.size(); ++c) a[c] = std::max(a[c], b2[c]);
+        exps(a, ex.stage[s]);
+        exps(in, ex.inner[s]);
+    }
+    return 0;
+}
+
+static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin, const FaChannelExps &ex) {
     const int Cout = kConvCout[l];
+    const std::vector<int> &kout = *ex.out_of(l);
+    const std::vector<int> *kin = ex.in_of(l);
+    // fold(co) = gamma / sqrt(var + eps) * 2^k_out(co);  every weight additionally times 2^-k_in(ci)
+    auto fold = [&](const float *g, const float *var, int co) { return std::ldexp((double)g[co] / std::sqrt((double)var[co] + 1e-3), kout[co]); };
+    auto in_f = [&](int ci) { return kin ? std::ldexp(1.0, -(*kin)[ci]) : 1.0; };
     const float *w, *b, *g, *beta, *mean, *var;
     const std::string cv = kConvName[l], bn = kBnName[l];
     TRY(want(tm, cv + ".weight", {Cout, Cin, 3, 3}, &w));
@@ -334,12 +391,12 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     const int ldb = l == 0 ? 96 : 9 * Cin;
     std::vector<float> pw((size_t)Cout * ldb, 0.f), pb(Cout);
     for (int co = 0; co < Cout; ++co) {
-        const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
-        pb[co] = (float)(((double)b[co] - (double)mean[co]) * scale + (double)beta[co]);
+        const double scale = fold(g, var, co);
+        pb[co] = (float)(((double)b[co] - (double)mean[co]) * scale + std::ldexp((double)beta[co], kout[co]));
         for (int ci = 0; ci < Cin; ++ci)
             for (int kh = 0; kh < 3; ++kh)
                 for (int kw = 0; kw < 3; ++kw) {
-                    const double v = (double)w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] * scale;
+                    const double v = (double)w[(((size_t)co * Cin + ci) * 3 + kh) * 3 + kw] * scale * in_f(ci);
                     if (l == 0)
                         pw[(size_t)co * ldb + kh * 32 + kw * Cin + ci] = (float)(v / 100.0);
                     else
@@ -359,7 +416,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
     if (l == 0 && (Cin == 8 || Cin == 9)) {
         std::vector<float> v1((size_t)64 * 9 * Cin);
         for (int co = 0; co < 64; ++co) {
-            const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+            const double scale = fold(g, var, co);
             for (int i = 0; i < 9 * Cin; ++i) v1[(size_t)co * 9 * Cin + i] = (float)((double)w[(size_t)co * 9 * Cin + i] * scale * (128.0 / 100.0));
         }
         row_scales(v1.data(), 64, (size_t)9 * Cin, c1s, c1post);
@@ -377,7 +434,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                             const int co = 32 * cb + (lane & 31), tap = 2 * t + (lane >> 5);
                             float v = 0.f;
                             if (tap < 9) {
-                                const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+                                const double scale = fold(g, var, co);
                                 v = (float)((double)w[(((size_t)co * Cin + j) * 3 + tap / 3) * 3 + tap % 3] * scale * (128.0 / 100.0)) * c1s[co];  // the kernel feeds x / 128
                             }
                             const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
@@ -407,7 +464,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin) {
                         const int co = 32 * cb + (lane & 31), q = 16 * (t & 1) + 8 * (lane >> 5) + j, ky = t >> 1;
                         float v = 0.f;
                         if (q < 27) {
-                            const double scale = (double)g[co] / std::sqrt((double)var[co] + 1e-3);
+                            const double scale = fold(g, var, co);
                             v = (float)((double)w[(((size_t)co * Cin + q % 9) * 3 + ky) * 3 + q / 9] * scale * (128.0 / 100.0)) * c1s[co];
                         }
                         const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);

@@ -352,19 +352,23 @@ def test_plane_pipeline_stays_at_fp32_level(monkeypatch, oracle_mod):
             assert v <= 5 * errs[(ch, "fp32")][k] + 3e-7, (ch, k, errs)
 
 
-def _layer_errors(m, d, names):
+def _layer_errors(m, d, names, sd):
     """per layer: max |a - d| over the tensor relative to the tensor's range, and the worst CHANNEL relative to that channel's own
-    range (a channel whose values are 1e-3 of the tensor's is invisible in the first number and is what the next layer's
-    large weights amplify)"""
+    scale (a channel whose values are 1e-3 of the tensor's is invisible in the first number and is what the next layer's
+    large weights amplify).  A channel's scale is what its BatchNorm gives it, |gamma| + |beta| (the larger of the two
+    producers behind a residual add) -- its observed range if that is larger: a channel the ReLU leaves almost dead on these
+    nine windows is the clipped tail of a sum of that scale, and so is its rounding noise"""
     whole, chan = {}, {}
     for name in names:
+        l = int(name[3:])
         a = m.debug_fetch(name, d[name].shape)
         assert np.isfinite(a).all(), name
         err = np.abs(a - d[name]).reshape(-1, a.shape[-1]).max(0)
         rng = np.abs(d[name]).reshape(-1, a.shape[-1]).max(0)
         whole[name] = float(err.max()) / max(1.0, float(rng.max()))
-        live = rng > 1e-6
-        chan[name] = float((err[live] / rng[live]).max()) if live.any() else 0.0
+        mag = lambda k: np.abs(sd[syn.FA_CONV_LAYERS[k][1] + ".weight"]) + np.abs(sd[syn.FA_CONV_LAYERS[k][1] + ".bias"])
+        scale = np.maximum(rng, np.maximum(mag(l), mag(l - 2)) if l % 3 == 2 else mag(l))
+        chan[name] = float((err / np.maximum(scale, 1e-30)).max())
     return whole, chan
 
 
@@ -386,7 +390,7 @@ def test_trained_like_weights_layer_by_layer(channels, monkeypatch, oracle_mod):
         m = make_model(syn.FULL_ALIGNMENT, channels, True, sd, keep=True)
         y = m.predict_numpy(x)
         assert m.range_status() == (0, mode == "fp32")
-        whole, chan = _layer_errors(m, d, names)
+        whole, chan = _layer_errors(m, d, names, sd)
         whole["y"] = util.assert_rows_match(y, y_o, what=f"trained-like, C={channels}, {mode}")
         res[mode] = (whole, chan)
         for k in env:
@@ -397,8 +401,8 @@ def test_trained_like_weights_layer_by_layer(channels, monkeypatch, oracle_mod):
         assert v < 2e-5, (k, v)
         assert v <= 5 * res["fp32"][0][k] + 3e-7, (k, v, res["fp32"][0][k])
     for k, v in res["f16x3"][1].items():
-        assert v < 1e-4, (k, v)
-        assert v <= 5 * res["fp32"][1][k] + 2e-6, (k, v, res["fp32"][1][k])
+        assert v < 2e-5, (k, v)
+        assert v <= 5 * res["fp32"][1][k] + 1e-6, (k, v, res["fp32"][1][k])
     # the fused product path (conv1 inside res1a / res1b, pooling inside res3b) on the same weights
     y = make_model(syn.FULL_ALIGNMENT, channels, True, sd).predict_numpy(x)
     assert util.assert_rows_match(y, y_o, what=f"trained-like, C={channels}, product path") < 2e-5
@@ -424,8 +428,8 @@ def test_large_folded_weights_keep_their_fp16_pieces_in_range(oracle_mod):
     instead of overflowing the high fp16 piece; the next stage's BatchNorm brings the range back."""
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=51)
     sd = {k: np.array(v, copy=True) for k, v in sd.items()}
-    sd["conv3.bn.weight"] *= 400.0
-    sd["conv3.bn.bias"] *= 400.0
+    for k in ("conv3.conv.weight", "conv3.conv.bias", "conv3.bn.running_mean"):
+        sd[k] *= 400.0
     for k in ("res_block2.0.conv1.weight", "res_block2.0.conv2.weight"):
         sd[k] /= 20.0
     sd["conv5.conv.weight"] /= 400.0
@@ -448,8 +452,9 @@ def test_activations_beyond_the_fp16_range_fall_back_to_fp32(oracle_mod, capfd):
     the batch again -- the caller still gets the reference's rows"""
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=61)
     sd = {k: np.array(v, copy=True) for k, v in sd.items()}
-    sd["conv3.bn.weight"] *= 4.0e6
-    sd["conv3.bn.bias"] *= 4.0e6
+    for k in ("conv3.conv.weight", "conv3.conv.bias", "conv3.bn.running_mean"):
+        sd[k] *= 4.0e6  # the convolution's output grows, the BatchNorm's running statistics do not follow: a stage at ~1e7 that no
+                        # re-parametrisation at load time (channel equalisation reads gamma and beta) can see coming
     for k in ("res_block2.0.conv1.weight", "res_block2.0.conv2.weight"):
         sd[k] /= 2.0e3
     sd["conv5.conv.weight"] /= 4.0e6
@@ -471,8 +476,9 @@ def test_device_resident_entry_has_the_range_guard(oracle_mod, capfd):
     import torch
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=61)
     sd = {k: np.array(v, copy=True) for k, v in sd.items()}
-    sd["conv3.bn.weight"] *= 4.0e6
-    sd["conv3.bn.bias"] *= 4.0e6
+    for k in ("conv3.conv.weight", "conv3.conv.bias", "conv3.bn.running_mean"):
+        sd[k] *= 4.0e6  # the convolution's output grows, the BatchNorm's running statistics do not follow: a stage at ~1e7 that no
+                        # re-parametrisation at load time (channel equalisation reads gamma and beta) can see coming
     for k in ("res_block2.0.conv1.weight", "res_block2.0.conv2.weight"):
         sd[k] /= 2.0e3
     sd["conv5.conv.weight"] /= 4.0e6
@@ -503,8 +509,9 @@ def test_range_guard_with_two_batches_in_flight(oracle_mod, capfd):
     current mode)"""
     sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=61)
     sd = {k: np.array(v, copy=True) for k, v in sd.items()}
-    sd["conv3.bn.weight"] *= 4.0e6
-    sd["conv3.bn.bias"] *= 4.0e6
+    for k in ("conv3.conv.weight", "conv3.conv.bias", "conv3.bn.running_mean"):
+        sd[k] *= 4.0e6  # the convolution's output grows, the BatchNorm's running statistics do not follow: a stage at ~1e7 that no
+                        # re-parametrisation at load time (channel equalisation reads gamma and beta) can see coming
     for k in ("res_block2.0.conv1.weight", "res_block2.0.conv2.weight"):
         sd[k] /= 2.0e3
     sd["conv5.conv.weight"] /= 4.0e6
