@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic soak (not a test): random batch sizes, seeds and recipes through the C ABI against the oracle, for the three model
-shapes; every row of every batch.  usage: fuzz_parity.py [seconds]"""
+"""Diagnostic soak (not a test): random batch sizes, seeds, recipes AND weight sets (plain / trained-like / peaked) through the C ABI
+against the oracle, for the five model shapes.  usage: fuzz_parity.py [seconds]"""
 import os
 import sys
 import time
@@ -18,15 +18,18 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "7")))
 cases = [(syn.PILEUP, 18, False), (syn.PILEUP, 18, True), (syn.FULL_ALIGNMENT, 8, True), (syn.FULL_ALIGNMENT, 9, True), (syn.FULL_ALIGNMENT, 8, False)]
 models = {}
 t_end = time.time() + budget
-n_batches = n_rows = 0
+n_batches = n_rows = n_models = 0
 worst = 0.0
 while time.time() < t_end:
     kind, ch, indel = cases[int(rng.integers(len(cases)))]
     seed = int(rng.integers(1 << 30))
     key = (kind, ch, indel)
     if key not in models or rng.random() < 0.2:
-        sd = syn.make_state_dict(kind, ch, indel, seed=seed)
+        # weights, not only batches: half the models are re-parametrised the way training leaves them (per-channel scales over
+        # decades, zero bias_hh, a few +-8 LSTM weights: synthetic._trained_like), a quarter have peaked heads
+        sd = syn.make_state_dict(kind, ch, indel, seed=seed, peaked=bool(rng.random() < 0.25), trained_like=bool(rng.random() < 0.5))
         models[key] = (make_model(kind, ch, indel, sd), sd)
+        n_models += 1
     m, sd = models[key]
     hi = 1300 if kind == syn.PILEUP else 330
     n = int(rng.integers(1, hi)) if rng.random() < 0.7 else int(rng.choice([1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 184, 185, 186, 255, 256, 257]))
@@ -51,4 +54,4 @@ while time.time() < t_end:
             sys.exit(1)
     n_batches += 1
     n_rows += n
-print(f"ok: {n_batches} batches, {n_rows} windows, worst |dY| on the checked rows {worst:.2e}")
+print(f"ok: {n_batches} batches, {n_rows} windows, {n_models} weight sets, worst |dY| on the checked rows {worst:.2e}")

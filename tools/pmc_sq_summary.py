@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise the two SQ counter passes of tools/gpu_round.sh `pmcsq2` (gpurun_out/pmc_sq_a, pmc_sq_b) per kernel:
+"""Summarise the two SQ counter passes of tools/gpu_round.sh `sq_fa` / `sq_p` (gpurun_out/pmc_sq_a_<fa|p>, pmc_sq_b_<fa|p>) per kernel:
 MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs)), wave occupancy, wait shares, and the
-vector-instruction mix (SQ_INSTS_VALU counts MFMAs too).  usage: pmc_sq_summary.py > profiles/<run>_pmc_sq.md"""
+vector-instruction mix (SQ_INSTS_VALU counts MFMAs too).  usage: pmc_sq_summary.py <fa|p> > profiles/<run>_pmc_sq_<fa|p>.md"""
 import collections
 import csv
 import os
@@ -23,8 +23,9 @@ def mean(d, k):
 
 
 def main():
-    A = agg(os.path.join(ROOT, "gpurun_out/pmc_sq_a/c3_counter_collection.csv"))
-    B = agg(os.path.join(ROOT, "gpurun_out/pmc_sq_b/c3_counter_collection.csv"))
+    sfx = sys.argv[1] if len(sys.argv) > 1 else "fa"
+    A = agg(os.path.join(ROOT, f"gpurun_out/pmc_sq_a_{sfx}/c3_counter_collection.csv"))
+    B = agg(os.path.join(ROOT, f"gpurun_out/pmc_sq_b_{sfx}/c3_counter_collection.csv"))
     print("| kernel | launches | us (under PMC) | MfmaUtil % | waves per SIMD | VALU instr per MFMA (excl. the MFMA) | LDS instr per MFMA | VMEM instr per MFMA |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|")
     for k, a in A.items():

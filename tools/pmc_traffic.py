@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Turn the two rocprofv3 PMC passes of tools/gpu_round.sh (stage `pmc`: --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-separate runs, as MI355X_MICROARCH.md prescribes) into profiles/pmc_traffic.json, which bench.py reports as
-roofline.traffic.  gfx950 correction: FETCH_SIZE of wide coalesced reads is doubled."""
+"""Turn the two rocprofv3 PMC passes of tools/gpu_round.sh (stages `pmc_fa` / `pmc_p`: --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+separate runs over ONLY the one-batch-in-flight leg of one workload, as MI355X_MICROARCH.md prescribes) into
+profiles/pmc_traffic.json / pmc_traffic_pileup.json, which bench.py reports as roofline.traffic.  gfx950 correction: FETCH_SIZE
+of wide coalesced reads is doubled.    usage: pmc_traffic.py <tag>   |   pmc_traffic.py pileup <tag>"""
 import collections
 import csv
 import json
@@ -19,11 +20,9 @@ def agg(path):
 
 
 def main(tag):
-    f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch/c3_counter_collection.csv"))
-    w = agg(os.path.join(ROOT, "gpurun_out/pmc_write/c3_counter_collection.csv"))
-    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("gemm_mfma_kernel<c3::PlaneConv" in k) or ("wino_conv_kernel" in k) or \
-        ("conv1_i8" in k) or ("conv3x3_planes_kernel" in k) or ("dense_planes_kernel<true" in k) or \
-        ("dense_planes_pipe_kernel<true" in k) or ("dense_planes_ws_kernel<true" in k)
+    f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch_fa/c3_counter_collection.csv"))
+    w = agg(os.path.join(ROOT, "gpurun_out/pmc_write_fa/c3_counter_collection.csv"))
+    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("conv1_i8" in k) or ("conv3x3_planes_kernel" in k) or ("dense_planes_pipe_kernel<true" in k)
     tot_f = tot_w = n = 0
     per = {}
     all_f = all_w = 0.0
@@ -50,7 +49,8 @@ def main(tag):
     out = {
         "tag": tag,
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around "
-                  "`bench.py --gpus 1 --steps 5 --warmup 2 --workload full_alignment` (B=256)",
+                  "`bench.py --gpus 1 --workload full_alignment --streams 1 --no-host-leg --no-cpu-baseline --no-reference-gpu --no-profiled-pass "
+                  "--steps 5 --warmup 5 --repeats 3` (B=256, only the one-batch-in-flight leg; tools/gpu_round.sh pmc_fa)",
         "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B",
         "kernel_family": "the convolution launches of one full-alignment step (8 with conv1 computed inside res1a / res1b, else 9)",
         "launches_per_step": n / steps if steps else None,
@@ -70,8 +70,8 @@ def main(tag):
 
 def main_pileup(tag):
     """the two BiLSTM recurrences of one pileup step (B = 1024): gpurun_out/pmcp_fetch, pmcp_write (stage `pmcp`)"""
-    f = agg(os.path.join(ROOT, "gpurun_out/pmcp_fetch/c3_counter_collection.csv"))
-    w = agg(os.path.join(ROOT, "gpurun_out/pmcp_write/c3_counter_collection.csv"))
+    f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch_p/c3_counter_collection.csv"))
+    w = agg(os.path.join(ROOT, "gpurun_out/pmc_write_p/c3_counter_collection.csv"))
     lstm = lambda k: ("lstm1_fused_kernel" in k) or ("lstm_recurrent_kernel" in k)
     tot_f = tot_w = n = 0
     per = {}
@@ -95,7 +95,8 @@ def main_pileup(tag):
     out = {
         "tag": tag,
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around "
-                  "`bench.py --gpus 1 --steps 5 --warmup 2 --workload pileup` (B=1024)",
+                  "`bench.py --gpus 1 --workload pileup --streams 1 --no-host-leg --no-cpu-baseline --no-reference-gpu --no-profiled-pass "
+                  "--steps 5 --warmup 5 --repeats 3` (B=1024, only the one-batch-in-flight leg; tools/gpu_round.sh pmc_p)",
         "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B",
         "kernel_family": "the two BiLSTM recurrence launches of one pileup step (lstm1_fused_kernel + lstm_recurrent_kernel_v2<160>)",
         "launches": n,
