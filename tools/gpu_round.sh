@@ -13,14 +13,15 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT="$PWD/gpurun_out"
 leg() {  # leg <workload>: the bench flags that run one workload's one-batch-in-flight leg and nothing else
-  echo "--gpus 1 --workload $1 --streams 1 --no-host-leg --no-cpu-baseline --no-reference-gpu --no-profiled-pass --steps ${STEPS:-50} --warmup 5 --repeats 3"
+  echo "--gpus 1 --workload $1 --streams 1 --no-host-leg --no-cpu-baseline --no-reference-gpu --steps ${STEPS:-50} --warmup 5 --repeats 3"
 }
-prof() {  # prof <tag> <workload>
+prof() {  # prof <tag> <workload>: kernel trace + stats of the one-in-flight leg AND its HIP-event pass (the same kernels, the same one
+          # batch in flight), so the roofline object of the JSON line comes from the very launches the CSV averages
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$1" -o c3 -- python "$OLDPWD/bench.py" $(leg $2) > "$OUT/$1.json" 2> "$OUT/$1.err"); echo "$1 rc=$?"; find "$OUT/$1" -name '*kernel_stats*' | head -2
 }
 pmc() {  # pmc <tag> <workload> <counters...>
   local tag=$1 wl=$2; shift 2
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$tag" -o c3 -- python "$OLDPWD/bench.py" $(STEPS=5 leg $wl) > /dev/null 2> "$OUT/$tag.err"); echo "$tag rc=$?"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$tag" -o c3 -- python "$OLDPWD/bench.py" $(STEPS=5 leg $wl) --no-profiled-pass > /dev/null 2> "$OUT/$tag.err"); echo "$tag rc=$?"
 }
 for s in ${1:-test bench}; do
   case $s in
