@@ -269,23 +269,55 @@ def run_workload(name, args, rank, world, local):
                                              "frac_of_device_resident": el_dev / el_sync,
                                              "path": "model.predict_numpy = _hip_predict = c3_predict: one blocking call per batch"}
             # what the UNMODIFIED reference loop gets after callvar.install(): its batch generator rebound to
-            # worker.lookahead_batches (batches submitted two ahead) and one _torch_predict (= predict._hip_predict) per batch
+            # worker.lookahead_batches over the tensor FILES of stage A (memory-mapped .npy + .info, batches of 1000 that never
+            # span files; consecutive batches of a file travel in one forward pass, two groups in flight beyond the one being
+            # read) and one blocking _torch_predict (= predict._hip_predict) per batch
             from clair3_amd import predict as c3predict, worker as c3worker
+            import shutil
+            per_file = 10000 if kind == syn.PILEUP else 4000  # <= 10 000 windows per file (preprocess/SelectCandidates.py:379)
+            n_files = max(2, min(12, (k * bref + per_file - 1) // per_file))
+            tdir = tempfile.mkdtemp(prefix="c3_bench_files_")
+            try:
+                names = []
+                tiled = np.concatenate([xb] * (per_file // bref))
+                info = "\n".join("chrS:%d:%s\t30-RA 30 " % (i + 1, "ACGT" * 8 + "A") for i in range(per_file)) + "\n"
+                for fi in range(n_files):
+                    np.save(os.path.join(tdir, f"t{fi}.npy"), tiled)
+                    with open(os.path.join(tdir, f"t{fi}.info"), "w") as fh:
+                        fh.write(info)
+                    names.append(f"t{fi}")
+                list_fn = os.path.join(tdir, "tensor_list")
+                with open(list_fn, "w") as fh:
+                    fh.write("\n".join(names) + "\n")
+                del tiled
 
-            def loop(n_batches):
-                gen = c3worker.lookahead_batches(model, ((xb[:], None, None) for _ in range(n_batches)), c3predict._PENDING, depth=2)
-                for X, _, _ in gen:  # clair3/CallVariantsFromCffi.py:308-317
-                    yy = c3predict._hip_predict(model, None, X)
-                return yy
-            loop(3)
-            t0 = time.perf_counter()
-            y = loop(k)
-            el_loop = time.perf_counter() - t0
-            assert y.shape[0] == bref and np.isfinite(y).all()
-            hl["batch_1000"]["dropin_loop"] = {"value": bref * k / el_loop, "ms_per_call": 1e3 * el_loop / k,
-                                               "frac_of_device_resident": el_dev / el_loop,
-                                               "path": "callvar.install(): tensor_generator_for_chunk -> worker.lookahead_batches (2 ahead), "
-                                                       "one blocking _torch_predict per batch = wait for rows already in flight"}
+                def loop(group_windows):
+                    gen = c3worker.lookahead_batches(model, c3worker.iter_tensor_files(list_fn), bref, c3predict._PENDING, depth=2,
+                                                     group_windows=group_windows)
+                    n = 0
+                    for X, _, _ in gen:  # clair3/CallVariantsFromCffi.py:308-317
+                        yy = c3predict._hip_predict(model, None, X)
+                        n += len(yy)
+                    assert n == n_files * per_file and np.isfinite(yy).all()
+                    return n
+                gw = c3worker.group_windows_for(model)
+                loop(gw)
+                t0 = time.perf_counter()
+                n_loop = loop(gw)
+                el_loop = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                loop(0)
+                el_loop1 = time.perf_counter() - t0
+            finally:
+                shutil.rmtree(tdir, ignore_errors=True)
+            hl["batch_1000"]["dropin_loop"] = {"value": n_loop / el_loop, "ms_per_call": 1e3 * el_loop / (n_loop / bref),
+                                               "frac_of_device_resident": (n_loop / el_loop) / (bref * k / el_dev),
+                                               "windows_per_forward_pass": gw, "tensor_files": n_files, "windows_per_file": per_file,
+                                               "one_forward_pass_per_batch": {"value": n_loop / el_loop1,
+                                                                              "frac_of_device_resident": (n_loop / el_loop1) / (bref * k / el_dev)},
+                                               "path": "callvar.install(): tensor_generator_for_chunk -> worker.lookahead_batches over memory-mapped tensor "
+                                                       "files (groups of consecutive batches per forward pass, 2 groups ahead), one blocking _torch_predict "
+                                                       "per batch of 1000 = wait for rows already in flight; frac is against the device-resident rate at B=1000"}
             # every handle of the device-resident headline fed from the host: batch i on handle i % S, two submits in flight each
             if len(models) > 1:
                 el3, y = host_leg(models, xb, k, 3, slots=2)

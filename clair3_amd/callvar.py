@@ -50,10 +50,10 @@ def _check_gpu_memory_or_exit(memory, device_ids=None, print_log=True):
 
 def _make_batch_generator(original):
     """tensor_generator_for_chunk (clair3/CallVariantsFromCffi.py:106-148) for the GPU branch: the same batches in the same
-    order from the same ``--output_tensor_can_fn_list`` files, but memory-mapped and submitted to the GPU ``PREFETCH_DEPTH``
-    batches ahead of the loop (clair3_amd/worker.py), so that the loop's one blocking ``_torch_predict`` per batch finds its
-    rows computed -- the unmodified loop then runs at the rate of the submit / wait ring instead of H2D -> forward -> D2H
-    in sequence.  Every other use (in-process tensors, no model loaded through the rebound loader, CPU) is the
+    order from the same ``--output_tensor_can_fn_list`` files, but memory-mapped and submitted to the GPU ahead of the loop
+    (clair3_amd/worker.py: groups of consecutive batches per forward pass, ``PREFETCH_DEPTH`` groups in flight beyond the
+    one being read), so that the loop's one blocking ``_torch_predict`` per batch finds its rows computed -- the unmodified
+    loop then runs at the rate of the submit / wait ring instead of H2D -> forward -> D2H in sequence.  Every other use (in-process tensors, no model loaded through the rebound loader, CPU) is the
     reference's own generator."""
     from . import worker as transport
 
@@ -66,8 +66,9 @@ def _make_batch_generator(original):
         want = bool(predict.DECODER_COLUMNS and model.add_indel_length)
         if want != model._decode_cols:
             model.decode_columns(want)
-        yield from transport.lookahead_batches(model, transport.iter_batches(args.output_tensor_can_fn_list, batch_size),
-                                               predict._PENDING, depth=PREFETCH_DEPTH)
+        yield from transport.lookahead_batches(model, transport.iter_tensor_files(args.output_tensor_can_fn_list), batch_size,
+                                               predict._PENDING, depth=PREFETCH_DEPTH,
+                                               group_windows=transport.group_windows_for(model))
 
     tensor_generator_for_chunk._c3hip_original = original
     return tensor_generator_for_chunk

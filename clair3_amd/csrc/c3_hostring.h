@@ -97,9 +97,11 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
     const size_t yb = (size_t)batch * m->row * sizeof(float);
-    if (batch > 0 && m->host_copy_kernel && xb <= kKernelCopyMax && yb <= kKernelCopyMax && !src_locked && !is_registered(x_host, xb)) {
+    // C3HIP_HOST_COPY_KERNEL: 0 = never, 1 = up to kKernelCopyMax, n > 1 = up to n KB (A/B of the threshold)
+    const size_t kcopy_max = m->host_copy_kernel > 1 ? (size_t)m->host_copy_kernel << 10 : kKernelCopyMax;
+    if (batch > 0 && m->host_copy_kernel && xb <= kcopy_max && yb <= kcopy_max && !src_locked && !is_registered(x_host, xb)) {
         TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, (yb + 255) & ~(size_t)255));
-        memcpy(sl.pin_x, x_host, xb);
+        StagePool::get().copy(sl.pin_x, x_host, xb);  // (plain memcpy below 1 MB, split over the helpers above)
         hipLaunchKernelGGL(host_copy_kernel, dim3(128), dim3(256), 0, m->stream, (const uint4 *)sl.pin_x, (uint4 *)sl.dev_x, (xb + 15) / 16,
                            (const uint32_t *)nullptr, (uint32_t *)nullptr);
         HIP_TRY(hipGetLastError());

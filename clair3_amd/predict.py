@@ -28,7 +28,7 @@ def _load_torch_checkpoint(model, checkpoint_path, device=None):
 # creates its batch generator (clair3/CallVariantsFromCffi.py:246-273), so the rebound generator (callvar.install: the
 # transport of clair3_amd/worker.py behind tensor_generator_for_chunk) can find the handle it should run ahead on.
 _CURRENT_MODEL = None
-# id(X) -> (model, ticket, X) of batches the rebound generator has already submitted (worker.lookahead_batches)
+# id(X) -> (model, group, X, lo, hi) of batches the rebound generator has already submitted (worker.lookahead_batches)
 _PENDING = {}
 
 
@@ -65,8 +65,9 @@ def _hip_predict(model, device, X):
         model.to(device)
     ent = _PENDING.pop(id(X), None)
     if ent is not None and ent[0] is model and ent[2] is X:
-        # submitted ahead by the rebound batch generator (worker.lookahead_batches): the rows are on their way or here
-        return model.wait(ent[1])
+        # submitted ahead by the rebound batch generator (worker.lookahead_batches), alone or in a group of consecutive
+        # batches: the rows are on their way or here
+        return ent[1].take(ent[3], ent[4])
     want = bool(DECODER_COLUMNS and model.add_indel_length)
     if want != model._decode_cols:
         model.decode_columns(want)

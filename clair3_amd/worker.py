@@ -60,54 +60,98 @@ def iter_batches(list_fn, batch_size, first=0, stop=None):
 HOST_SLOTS = 4  # C3_HOST_SLOTS (include/c3hip.h): submits in flight per handle
 
 
-def lookahead_batches(model, batches, pending, depth=2):
+class _Group:
+    """One forward pass over a run of consecutive batches of a file; its rows are waited for once, by the first batch that asks."""
+    __slots__ = ("model", "ticket", "rows")
+
+    def __init__(self, model, ticket):
+        self.model, self.ticket, self.rows = model, ticket, None
+
+    def take(self, lo, hi):
+        if self.rows is None:
+            self.rows = self.model.wait(self.ticket)
+        return self.rows[lo:hi]
+
+    def drain(self):
+        if self.rows is None:
+            try:
+                self.rows = self.model.wait(self.ticket)
+            except Exception:
+                self.rows = ()
+
+
+def group_windows_for(model):
+    """How many windows the transport sends through ONE forward pass when the caller's batches are smaller: the pileup kernels
+    are latency-bound at the reference's batch of 1000 (4.4 M windows/s device-resident at B=1000, 5.9 M from B=4000 on:
+    profiles/r03_d_batch_sweep.txt), the full-alignment ones nearly flat (769 k at 1000, 783 k at 2000).  C3HIP_PREFETCH_GROUP
+    overrides (0 / 1 = one forward pass per batch)."""
+    env = os.environ.get("C3HIP_PREFETCH_GROUP")
+    if env is not None:
+        return max(0, int(env))
+    return 4000 if getattr(model, "KIND", None) == 0 else 2000
+
+
+def lookahead_batches(model, files, batch_size, pending, depth=2, group_windows=0):
     """The transport behind the reference's OWN loop.  ``call_variants_from_cffi`` pulls one batch from its generator and
     makes one blocking ``_torch_predict`` call on it (clair3/CallVariantsFromCffi.py:302-317); this generator keeps the
-    loop's shape and runs ``depth`` batches ahead of it: before batch i is yielded, batches i .. i + depth have been handed
-    to ``model.submit`` (staging copy, H2D, kernels and D2H queued), and ``pending[id(X_i)] = (model, ticket, X_i)`` tells
-    the rebound ``_torch_predict`` (predict._hip_predict) that its rows only need to be waited for.  Same batches, same
-    order, same rows as the blocking calls -- a window's row does not depend on the batch it travels in."""
+    loop's shape -- the same batches (never across files, the last batch of a file short), the same order -- and runs ahead
+    of it: consecutive batches of a file travel in GROUPS of up to ``group_windows`` windows (one contiguous slice of the
+    memory-mapped tensor, one ``model.submit``: staging copy, H2D, kernels and D2H queued), ``depth`` groups beyond the one the
+    loop is reading are in flight, and ``pending[id(X)] = (model, group, X, lo, hi)`` tells the rebound ``_torch_predict``
+    (predict._hip_predict) that the rows of batch ``X`` only need to be waited for and sliced.  Same rows as the blocking
+    calls: a window's row does not depend on the batch it travels in.
+    ``files``: an iterator of (tensor, positions, alt_infos) per tensor file (iter_tensor_files)."""
     from collections import deque
     slots = depth + 1
     if not 1 <= slots <= HOST_SLOTS:
         raise ValueError(f"depth must be in [0, {HOST_SLOTS - 1}], got {depth}")
-    queue = deque()  # (X, ticket, positions, alt_infos), oldest first
-    it = iter(batches)
-    n_submitted, exhausted, last = 0, False, None
+    per_group = max(1, int(group_windows) // int(batch_size)) * int(batch_size)
+
+    def groups():  # (tensor slice of the group, [(lo, hi, positions, alt_infos) per batch, offsets inside the group])
+        for tensor, positions, alt_infos in files:
+            n = len(tensor)
+            for g0 in range(0, n, per_group):
+                g1 = min(g0 + per_group, n)
+                parts = [(lo - g0, min(lo + batch_size, g1) - g0, positions[lo:min(lo + batch_size, g1)], alt_infos[lo:min(lo + batch_size, g1)])
+                         for lo in range(g0, g1, batch_size)]
+                yield tensor[g0:g1], parts
+
+    queue = deque()  # (group, Xg, parts), oldest first
+    it = groups()
+    n_submitted, exhausted = 0, False
+    handed = []  # batches of the group being read that the loop has been given: (X, group)
     try:
         while True:
-            if last is not None:
-                # the loop did not call _torch_predict on the batch it was given (it would have popped the entry): the slot
-                # must be free before it is used again
-                ent = pending.pop(id(last), None)
-                if ent is not None:
-                    model.wait(ent[1])
-                last = None
             while not exhausted and len(queue) < slots:
                 try:
-                    X, positions, alt_infos = next(it)
+                    Xg, parts = next(it)
                 except StopIteration:
                     exhausted = True
                     break
-                X = np.ascontiguousarray(X)
-                ticket = model.submit(X, slot=n_submitted % slots)
+                Xg = np.ascontiguousarray(Xg)
+                group = _Group(model, model.submit(Xg, slot=n_submitted % slots))
                 n_submitted += 1
-                queue.append((X, ticket, positions, alt_infos))
+                queue.append((group, Xg, parts))
             if not queue:
                 return
-            X, ticket, positions, alt_infos = queue.popleft()
-            pending[id(X)] = (model, ticket, X)
-            last = X
-            yield X, positions, alt_infos
+            group, Xg, parts = queue[0]
+            for lo, hi, positions, alt_infos in parts:
+                X = Xg[lo:hi]
+                pending[id(X)] = (model, group, X, lo, hi)
+                handed.append(X)
+                yield X, positions, alt_infos
+            # the loop has moved past this group: whatever it did not ask for must not stay registered, and the group's slot
+            # must be free before it is used again
+            for X in handed:
+                pending.pop(id(X), None)
+            handed = []
+            group.drain()
+            queue.popleft()
     finally:
-        # abandoned or failed half way: nothing may stay in flight on the handle
-        if last is not None and id(last) in pending:
-            queue.appendleft((last, pending.pop(id(last))[1], None, None))
-        for X, ticket, _, _ in queue:
-            try:
-                model.wait(ticket)
-            except Exception:
-                pass
+        for X in handed:
+            pending.pop(id(X), None)
+        for group, _, _ in queue:  # abandoned or failed half way: nothing may stay in flight on the handle
+            group.drain()
 
 
 def predict_batches(model, batches, consume, slots=3):

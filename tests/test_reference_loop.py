@@ -146,16 +146,19 @@ def test_worker_loop_prints_the_same_vcf_with_decoder_columns(tmp_path):
     assert sorted(plain_rows) == sorted(wide_rows)
 
 
-@pytest.mark.parametrize("decoder", [False, True])
-def test_worker_loop_on_the_lookahead_generator(tmp_path, decoder):
+@pytest.mark.parametrize("decoder,group", [(False, "0"), (True, "0"), (False, "80"), (True, None)])
+def test_worker_loop_on_the_lookahead_generator(tmp_path, decoder, group, monkeypatch):
     """callvar.install() also rebinds tensor_generator_for_chunk: once a model has been loaded through the rebound loader,
-    the loop's batches are submitted to the handle two ahead of its blocking _torch_predict calls (worker.lookahead_batches).
-    Same batches, same VCF text; three submits in flight at most; nothing left in flight at the end."""
+    the loop's batches are submitted to the handle ahead of its blocking _torch_predict calls (worker.lookahead_batches) --
+    one forward pass per batch (C3HIP_PREFETCH_GROUP=0), per two batches (80 windows), or per file (the default group is
+    larger than these files).  Same batches, same VCF text; three submits in flight at most; nothing left in flight at the end."""
     sizes = [40 + 40 + 7, 5, 30, 40]  # 3 + 1 + 1 + 1 batches of 40 (the loop's GPU batch, 1000, scaled down for the oracle)
     lst = write_tensor_files(tmp_path, sizes)
+    if group is not None:
+        monkeypatch.setenv("C3HIP_PREFETCH_GROUP", group)
     plain_rows, plain_calls = run_worker(tmp_path, lst, decoder=decoder, tag="blocking", batch=40)
     ahead_rows, ahead_calls = run_worker(tmp_path, lst, decoder=decoder, tag="ahead", prefetch=True, batch=40)
     assert plain_calls["submitted"] == 0 and plain_calls["plain" if not decoder else "wide"] == 6
-    assert ahead_calls["submitted"] == 6 and ahead_calls["max_in_flight"] == 3
+    assert ahead_calls["submitted"] == {"0": 6, "80": 5, None: 4}[group] and ahead_calls["max_in_flight"] == 3
     assert len(plain_rows) >= sum(sizes) // 2
     assert sorted(plain_rows) == sorted(ahead_rows)
