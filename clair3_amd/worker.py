@@ -19,33 +19,57 @@ import numpy as np
 
 
 def read_info(path):
-    """``<ctg>:<pos>:<ref seq>\\t<depth>-<alt info>`` per line -> (positions, alt_infos); same parsing as
-    clair3/CallVariantsFromCffi.py:114-122."""
+    """``<ctg>:<pos>:<ref seq>\\t<depth>-<alt info>`` per line -> (positions, alt_infos); the strings the reference's parsing
+    yields (clair3/CallVariantsFromCffi.py:114-122: strip, split on newlines, first two tab-separated fields of every line)."""
     with open(path, "r") as f:
         text = f.read().strip()
-    positions, alt_infos = [], []
     if not text:
-        return positions, alt_infos
+        return [], []
+    n_lines = text.count("\n") + 1
+    cols = text.replace("\n", "\t").split("\t")
+    if len(cols) == 2 * n_lines:  # two fields per line (what stage A writes): one split for the whole file ...
+        positions, alt_infos = cols[0::2], cols[1::2]
+        # ... unless a line with one field and a line with three cancelled out: "<ctg>:<pos>:<seq>" / "<depth>-..." tell
+        if all(":" in p for p in positions) and all(a[:1].isdigit() for a in alt_infos):
+            return positions, alt_infos
+    positions, alt_infos = [], []
     for line in text.split("\n"):
-        cols = line.split("\t")
-        positions.append(cols[0])
-        alt_infos.append(cols[1])
+        c = line.split("\t")
+        positions.append(c[0])
+        alt_infos.append(c[1])
     return positions, alt_infos
 
 
-def iter_tensor_files(list_fn, first=0, stop=None):
+def _load_tensor_file(parent, name):
+    tensor = np.load(os.path.join(parent, name + ".npy"), mmap_mode="r")
+    positions, alt_infos = read_info(os.path.join(parent, name + ".info"))
+    if len(tensor) != len(positions) or len(tensor) != len(alt_infos):
+        raise ValueError(f"{name}: {len(tensor)} tensor rows but {len(positions)} .info rows")
+    return tensor, positions, alt_infos
+
+
+def iter_tensor_files(list_fn, first=0, stop=None, ahead=True):
     """Yield (tensor, positions, alt_infos) for every entry of an ``--output_tensor_can_fn_list`` file; tensors are
     memory-mapped.  Entries are relative to the list file's directory (CallVariantsFromCffi.py:112-113).
-    ``first`` / ``stop`` restrict the walk to a contiguous run of entries (a rank's share of a sharded job)."""
+    ``first`` / ``stop`` restrict the walk to a contiguous run of entries (a rank's share of a sharded job).
+    ``ahead``: the next file's .info (10 000 lines: milliseconds of Python string work, as long as the GPU needs for the
+    file's pileup windows) is read on a helper thread while the caller works on the current file."""
     parent = os.path.dirname(list_fn)
     with open(list_fn, "r") as f:
         names = [n for n in f.read().strip().split("\n") if n != ""]
-    for name in names[first:stop]:
-        tensor = np.load(os.path.join(parent, name + ".npy"), mmap_mode="r")
-        positions, alt_infos = read_info(os.path.join(parent, name + ".info"))
-        if len(tensor) != len(positions) or len(tensor) != len(alt_infos):
-            raise ValueError(f"{name}: {len(tensor)} tensor rows but {len(positions)} .info rows")
-        yield tensor, positions, alt_infos
+    names = names[first:stop]
+    if not ahead or len(names) < 2:
+        for name in names:
+            yield _load_tensor_file(parent, name)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="c3-info") as pool:
+        nxt = pool.submit(_load_tensor_file, parent, names[0])
+        for i in range(len(names)):
+            cur = nxt.result()
+            if i + 1 < len(names):
+                nxt = pool.submit(_load_tensor_file, parent, names[i + 1])
+            yield cur
 
 
 def iter_batches(list_fn, batch_size, first=0, stop=None):
