@@ -27,8 +27,9 @@ static bool is_registered(const void *p, size_t n) {
 // reads the pinned staging buffer / writes the pinned result buffer directly (both are device-mapped), so a batch is ONE chain
 // of launches on one queue -- no copy engine, no cross-queue event waits, whose barrier packets cost a 210 us pileup batch
 // ~60 us of idle GPU per batch.  The transfer is then serial with the kernels, which is only worth it while it is
-// short: up to kKernelCopyMax bytes (~15 us at PCIe Gen5 rates); full-alignment batches (23.5 MB) keep the DMA engines.
-constexpr size_t kKernelCopyMax = (size_t)2 << 20;
+// short: up to kKernelCopyMax bytes (4000 pileup windows = 2.4 MB, ~50 us at PCIe Gen5 rates under ~700 us of kernels);
+// full-alignment batches (23.5 MB per 1000 windows) keep the DMA engines.
+constexpr size_t kKernelCopyMax = (size_t)4 << 20;
 __global__ __launch_bounds__(256) void host_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
                                                        const uint32_t *flag_src, uint32_t *flag_dst) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
