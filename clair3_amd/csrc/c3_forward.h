@@ -136,7 +136,7 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             TRY(div_magic(ww[l + 1], hh[l + 1] * ww[l + 1], &dp.mg_w));
             ps.mfma(2.0 * ((M + kDnBM - 1) / kDnBM * kDnBM) * (double)Cout * 9.0 * cin * 3, true);
             const int grid = std::min(dp.tiles, m->wg_slots / 2);  // one 512-thread workgroup (136 KB of LDS) per CU
-            hipLaunchKernelGGL(dense_planes_pipe_kernel<true>, dim3(grid), dim3(kDnThreads), 0, s, dp);
+            hipLaunchKernelGGL(dense_planes_glds_kernel<0>, dim3(grid), dim3(kDnThreads), 0, s, dp);
             HIP_TRY(hipGetLastError());
         } else {
             const bool res = l % 3 == 2;
@@ -328,7 +328,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             dp.a = m->h1, dp.w = m->proj2_pw, dp.bias = m->proj_b[1], dp.c = m->gx2, dp.post = m->proj2_post;
             dp.M = M, dp.N = 1280, dp.K = 256, dp.tiles_n = 1280 / kDnBN, dp.tiles = ((M + kDnBM - 1) / kDnBM) * dp.tiles_n;
             m->choice_proj2 = "128x128-chunk-stream";
-            hipLaunchKernelGGL(dense_planes_pipe_kernel<false>, dim3(std::min(dp.tiles, m->wg_slots / 2)), dim3(kDnThreads), 0, s, dp);
+            hipLaunchKernelGGL(dense_planes_pipe_kernel<0>, dim3(std::min(dp.tiles, m->wg_slots / 2)), dim3(kDnThreads), 0, s, dp);
             HIP_TRY(hipGetLastError());
         } else {
             DenseLoaderParams lp{m->h1, 256};

@@ -136,7 +136,7 @@ struct c3_model {
     float *conv1_wfrag16 = nullptr;  // conv1 as fragments of conv1_i8_f16_kernel / conv3x3_planes_kernel's SRC8 forms (C = 8 or 9)
     float *conv1_post = nullptr;     // their [64] per-channel 2^-k
     float *pconv_w[9] = {};  // stride-1 convs: conv3x3_planes_kernel chunks [Cout/64][Cin/64][9][64][16 pieces of 16 B];
-                             // stride-2 convs: dense_planes_pipe_kernel<true> chunks [Cout/128][9 Cin/64][128][16 pieces]
+                             // stride-2 convs: dense_planes_glds_kernel chunks [Cout/128][9 Cin/64][128][16 pieces]
     float *pconv_pre[9] = {}, *pconv_post[9] = {};  // [Cout] the output channels' powers of two 2^k / 2^-k (c3_pack.h row_scales)
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout (fp32 form)

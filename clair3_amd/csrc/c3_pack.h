@@ -499,7 +499,7 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin, const FaC
         TRY(upload(m, &m->pconv_w[l], pk));
     }
     if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kDnBN == 0) {
-        // dense_planes_pipe_kernel<true>: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
+        // dense_planes_glds_kernel: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
         const int NS = Cin / 64, NKc = 9 * NS;
         std::vector<float> sc, post;
         row_scales(pw.data(), Cout, (size_t)ldb, sc, post);

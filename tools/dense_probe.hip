@@ -51,8 +51,8 @@ int main(int argc, char **argv) {
     const int grid = dp.tiles < 256 ? dp.tiles : 256;
     const double gflop = 2.0 * M * N * K * 3 * 1e-9;
     printf("proj2 shape M=%d N=%d K=%d: %d tiles on %d workgroups, %.1f GFLOP executed (three piece products)\n", M, N, K, dp.tiles, grid, gflop);
-    auto report = [&](const char *name, float us) { printf("  %-58s %7.1f us  %6.0f TF executed\n", name, us, gflop / us * 1e-3); };
-#define RUN(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_pipe_kernel<false, false, abl>), dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20))
+    auto report = [&](const char *name, float us) { printf("  %-58s %7.1f us  %6.0f TF executed\n", name, us, gflop / us * 1e3); };
+#define RUN(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_pipe_kernel<abl>), dim3(grid), dim3(kDnThreads), 0, 0, dp); }, 20))
     RUN(0, "pipe kernel");
     RUN(16, "  - result stores");
     RUN(1, "  - operand loads");
@@ -89,6 +89,47 @@ int main(int argc, char **argv) {
             char nm[64];
             snprintf(nm, sizeof nm, "  full kernel, %d lanes per XCD (%d workgroups)", l, 8 * l * wp.tiles_n);
             report(nm, time_us([&] { hipLaunchKernelGGL((dense_planes_wres_kernel<0>), dim3(8 * l * wp.tiles_n), dim3(kDnThreads), 0, 0, wp); }, 20));
+        }
+    }
+    {   // ---- the stride-2 convolutions (conv3: 45 x 17 x 64 -> 23 x 9 x 128; conv5: 23 x 9 x 128 -> 12 x 5 x 256), B = 256 windows
+        const int Bc = 256;
+        const int shapes[2][6] = {{45, 17, 64, 23, 9, 128}, {23, 9, 128, 12, 5, 256}};
+        for (int si = 0; si < 2; ++si) {
+            const int Hin = shapes[si][0], Win = shapes[si][1], Cin = shapes[si][2], Ho = shapes[si][3], Wo = shapes[si][4], Co = shapes[si][5];
+            const int Mc = Bc * Ho * Wo, Kc = 9 * Cin;
+            const size_t abytes = (size_t)Bc * Hin * Win * Cin * 4, wbytes = (size_t)Co * Kc * 4, cbytes = (size_t)Mc * Co * 4;
+            void *ca, *cw, *cc;
+            CK(hipMalloc(&ca, abytes));
+            CK(hipMalloc(&cw, wbytes));
+            CK(hipMalloc(&cc, cbytes));
+            // any fp16-looking bytes will do for timing: reuse the random pieces generated above
+            for (size_t off = 0; off < abytes; off += ha.size() * 2) CK(hipMemcpy((char *)ca + off, ha.data(), std::min(ha.size() * 2, abytes - off), hipMemcpyHostToDevice));
+            for (size_t off = 0; off < wbytes; off += hw.size() * 2) CK(hipMemcpy((char *)cw + off, hw.data(), std::min(hw.size() * 2, wbytes - off), hipMemcpyHostToDevice));
+            DensePlanesParams cp;
+            cp.a = ca, cp.w = cw, cp.bias = dbias, cp.post = dbias, cp.c = (float *)cc;
+            cp.M = Mc, cp.N = Co, cp.K = Kc, cp.tiles_n = Co / kDnBN, cp.tiles = (Mc + kDnBM - 1) / kDnBM * cp.tiles_n;
+            cp.Hin = Hin, cp.Win = Win, cp.Cin = Cin, cp.Ho = Ho, cp.Wo = Wo, cp.stride = 2;
+            auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) / (uint64_t)d) + 1); };
+            cp.mg_hw = magic(Ho * Wo), cp.mg_w = magic(Wo);
+            const int gc = cp.tiles < 256 ? cp.tiles : 256;
+            const double gf = 2.0 * Mc * Co * (double)Kc * 3 * 1e-9;
+            printf("stride-2 convolution %dx%dx%d -> %dx%dx%d, B = %d: M=%d N=%d K=%d, %d tiles on %d workgroups, %.1f GFLOP executed\n", Hin, Win, Cin, Ho, Wo, Co, Bc, Mc, Co, Kc,
+                   cp.tiles, gc, gf);
+            auto rep = [&](const char *name, float us) { printf("  %-66s %7.1f us  %6.0f TF executed\n", name, us, gf / us * 1e3); };
+#define RUNG(abl, name) rep(name, time_us([&] { hipLaunchKernelGGL((dense_planes_glds_kernel<abl>), dim3(gc), dim3(kDnThreads), 0, 0, cp); }, 20))
+            RUNG(0, "LDS-DMA kernel (the product)");
+            RUNG(2, "  - the wait for the requests (wrong results)");
+            RUNG(1, "  - the requests in the loop");
+            RUNG(16, "  - epilogue");
+            RUNG(8, "  - fragment reads");
+            RUNG(4, "  - matrix instructions");
+            RUNG(9, "  - requests - fragment reads (matrix instructions + barriers)");
+            RUNG(41, "  matrix instructions only (no requests, reads, barriers)");
+            RUNG(12, "  requests + barriers only");
+            RUNG(14, "  requests + barriers only, never waited for (request throughput)");
+            RUNG(46, "  requests only, no waits, no barriers");
+#undef RUNG
+            (void)hipFree(ca), (void)hipFree(cw), (void)hipFree(cc);
         }
     }
     CK(hipDeviceSynchronize());
