@@ -300,12 +300,49 @@ def install_decoder():
                               variant_length_probabilities_2, reference_base=reference_base,
                               alt_info_dict=alt_info_dict, add_indel_length=add_indel_length)
 
+    printers = {}
+
     def batch_output(batch_chr_pos_seq, alt_info_list, batch_Y, output_config, output_utilities, args=None):
         width = 90 if output_config.add_indel_length else 24
         wide = isinstance(batch_Y, np.ndarray) and batch_Y.ndim == 2 and batch_Y.shape[1] == width + DECODE_COLS \
             and batch_Y.dtype == np.float32 and len(batch_Y) > 0
         if not wide:
             return reference_batch_output(batch_chr_pos_seq, alt_info_list, batch_Y, output_config, output_utilities, args)
+        if len(batch_Y) != len(batch_chr_pos_seq):
+            return reference_batch_output(batch_chr_pos_seq, alt_info_list, batch_Y[:, :width], output_config, output_utilities, args)  # its error message
+        key = (output_config, id(cv.param))
+        printer = printers.get(key)
+        if printer is None:
+            from .vcf_rows import RowPrinter
+            printer = printers[key] = RowPrinter(cv, output_config)
+            cv._c3hip_row_printers = printers
+        if printer.usable:
+            # rows whose first decision stands are printed from the columns (vcf_rows.py); every other row goes through the
+            # reference's own output_with, on the look-alike lists when the rows carry indel lengths
+            from .vcf_rows import FALLBACK
+            texts = printer.rows(batch_chr_pos_seq, alt_info_list, batch_Y)
+            cum = cv.param.label_shape_cum
+            if output_config.add_indel_length:
+                cur.base = batch_Y.__array_interface__["data"][0]
+                cur.stride = batch_Y.strides[0]
+                cur.nbytes = cur.stride * len(batch_Y)
+                cur.cols = batch_Y[:, width:]
+            try:
+                out = []
+                for i, text in enumerate(texts):
+                    if text is FALLBACK:
+                        y = batch_Y[i]
+                        p1, p2 = (y[cum[1]:cum[2]], y[cum[2]:cum[3]]) if output_config.add_indel_length else (0, 0)
+                        text = cv.output_with(batch_chr_pos_seq[i], alt_info_list[i], y[:cum[0]], y[cum[0]:cum[1]], p1, p2,
+                                              output_config, output_utilities)
+                    if text is not None:
+                        if args is not None:
+                            args.output_file.write(text)
+                        else:
+                            out.append(text)
+                return "".join(out)
+            finally:
+                cur.cols = None
         if not output_config.add_indel_length:
             # 24-column rows: the reference's lists hold 1-6 products each, nothing to save (measured: 33 k rows/s/core
             # either way); the columns are dropped and the reference decodes as it always does

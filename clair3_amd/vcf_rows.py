@@ -1,0 +1,398 @@
+"""SURVEY 8f N1, the rest of the decoder: the VCF row of a candidate whose FIRST decision stands, printed without the
+reference's per-row machinery.
+
+With decoder columns behind every probability row (include/c3hip.h, ``model.decode_columns()``) the first pass of
+``output_from`` (clair3/CallVariants.py:722-751) is known for the whole batch at once (``decode.first_decisions``): the
+class it settles on, the winning entry of that class, QUAL, the homo-reference early exit.  What is left per row is the
+allele lookup in the row's alt_info string and the row's text.  ``RowPrinter.rows`` does exactly that.  Where the
+reference rejects the candidate and loops (``probabilities[idx] = 0; continue``, :760 ff.: the reads do not offer the
+allele) it walks the same sequence of candidates the loop would meet -- every entry of the nine class lists above the
+homo-reference probability, by falling probability, ties in the order of the loop's if / elif chain and of ``.index()`` --
+instead of re-scanning ten lists per rejected candidate.  What it does not fully understand goes to the reference's own
+``output_with`` (on the same decoder columns, through ``decode.install_decoder``'s list look-alikes): a maximum shared by
+two classes, a reference base outside the IUPAC table, any output mode other than the plain VCF row (debug, gVCF,
+haploid modes, long-indel read counting, ensemble output).  The allele lookups themselves ARE
+the reference's functions (``find_alt_base``, ``insertion_bases_using_alt_info_from``, ``deletion_bases_using_alt_info_from``,
+called through the module the drop-in is installed into), as are ``filtration_value_from``, ``genotype_string_from`` and
+``convert_iupac_to_n`` and ``quality_score_from`` (called on the float32 scalar the reference would hold, so QUAL follows
+the reference under either NumPy promotion rule); what is restated here is the control flow of ``output_from``
+(:722-1016) and the read-count / formatting tail of ``output_with`` (:1176-1394), each block citing the lines it follows.
+
+tests/test_decode_dropin.py: identical text to the unpatched ``batch_output`` on golden rows, on rows peaked on every
+class with matching, partially matching and empty alt_info, and on adversarial rows; the share of rows that took the fast
+path is reported.
+"""
+import numpy as np
+
+from . import decode as dec
+
+FALLBACK = object()  # "print this row with the reference's output_with"
+
+_GENOTYPE_OF_CLASS = (0, 1, 2, 1, 1, 2, 2, 2, 2, None)  # homo_reference / homo_variant / hetero_variant per class (:1204-1209)
+# rank of a class in output_from's if / elif chain (:748, :758, :778, :800, :830, :879, :897, :924, :977): among classes that
+# hold the same maximum the first of the chain is the one whose candidate is looked up (and zeroed on rejection)
+_CHAIN_RANK = np.array([0, 0, 1, 2, 5, 3, 4, 6, 7, 8])
+# class and index of every entry of the nine lists laid end to end, and its rank in the chain
+_KLASS = {indel: np.concatenate([np.full(n, k) for k, n in enumerate(dec._CLASS_LEN[indel]) if k]) for indel in (True, False)}
+_INDEX = {indel: np.concatenate([np.arange(n) for k, n in enumerate(dec._CLASS_LEN[indel]) if k]) for indel in (True, False)}
+_RANK = {indel: _CHAIN_RANK[_KLASS[indel]] for indel in (True, False)}
+# rows without indel lengths (clair3/CallVariants.py:526-566): every entry is ONE float32 product zygosity x gt21 (commutative,
+# so one gather-multiply gives the 23 of them bit for bit): the zygosity / gt21 index of every entry in list order
+_Z24 = np.array([1] * 4 + [2] * 6 + [1, 1] + [2] * 4 + [2] + [2] * 4 + [2, 2])
+_G24 = np.array(list(dec.HOMO_SNP_GT21) + list(dec.HETERO_SNP_GT21) + [15, 10] + [16, 17, 18, 19] + [15] + [11, 12, 13, 14] + [10, 20])
+_PLAIN = {ord(ch): None for ch in "ACGTNacgtn,."}  # what convert_iupac_to_n leaves alone (shared/utils.py:27-40)
+
+
+def _text(x):
+    """chr_pos_seq / alt_info as str (:1127-1131, :1145-1148)"""
+    if type(x) == np.memmap:
+        return x[0].decode()
+    if type(x) == np.bytes_ or type(x) == bytes:
+        return x.decode()
+    return x
+
+
+class _Lookups:
+    """The allele lookups of one row: the reference's own functions on the row's alt_info dictionary, each distinct question
+    asked once (they depend on the dictionary and a length / a base only, and a row that rejects many candidates asks the
+    same few again and again)."""
+    __slots__ = ("cv", "d", "infer", "memo")
+
+    def __init__(self, cv, d, infer):
+        self.cv, self.d, self.infer, self.memo = cv, d, infer, {}
+
+    def find_alt_base(self, alt=None):
+        k = ("x", alt)
+        if k not in self.memo:
+            self.memo[k] = self.cv.find_alt_base(self.d, alt)
+        return self.memo[k]
+
+    def ins(self, propose, ignore="", multi=False):
+        k = ("i", propose, ignore, multi)
+        if k not in self.memo:
+            self.memo[k] = self.cv.insertion_bases_using_alt_info_from(
+                alt_info_dict=self.d, propose_insertion_length=propose, maximum_insertion_length=self.infer,
+                insertion_bases_to_ignore=ignore, return_multi=multi)
+        return self.memo[k]
+
+    def dele(self, propose, ignore="", multi=False):
+        k = ("d", propose, ignore, multi)
+        if k not in self.memo:
+            self.memo[k] = self.cv.deletion_bases_using_alt_info_from(
+                alt_info_dict=self.d, propose_deletion_length=propose, maximum_deletion_length=self.infer,
+                deletion_bases_to_ignore=ignore, return_multi=multi)
+        return self.memo[k]
+
+
+class RowPrinter:
+    """One per (reference module, output_config).  ``usable`` is False when the configuration asks for anything but the
+    plain VCF row; ``rows`` then must not be called."""
+
+    def __init__(self, cv, output_config):
+        c = output_config
+        self.cv, self.cfg = cv, c
+        self.usable = not (c.is_debug or c.gvcf or c.is_haploid_precise_mode_enabled or c.is_haploid_sensitive_mode_enabled
+                           or c.enable_long_indel or c.is_output_for_ensemble or c.input_probabilities)
+        self.width = 90 if c.add_indel_length else 24
+        self.flank = cv.param.flankingBaseNum
+        G = cv.Genotype
+        self.gt = [cv.genotype_string_from(g) for g in (G.homo_reference, G.homo_variant, G.hetero_variant)]
+        self.gt_multi = cv.genotype_string_from(G.hetero_variant_multi)
+        self.info = "P" if c.pileup else "F"
+        self.max_len = cv.VariantLength.max
+        self.taken = self.retried = self.handed_back = 0  # rows printed here / of those after rejections / rows left to output_with
+
+    # ------------------------------------------------------------------------------------------------ one pass of output_from
+    def _alleles(self, cls, pos, ref, look):
+        """(reference_base, alternate_base) the loop of output_from is left with after the pass for class ``cls`` / entry
+        ``pos``, or None where it goes on to the next candidate.  The loop runs ``while reference_base is None or
+        alternate_base is None`` (:721), so a ``continue`` that comes AFTER both were assigned ends it just like an accepted
+        candidate does: a SNP whose looked-up base is the reference base (:754, :773), an ACGT+insertion whose SNP has no
+        reads (:822-825), two equal insertions (:875-877), two deletions that fail the allele check (:973-975) all leave
+        the loop with the alleles assigned so far -- restated here as the reference behaves, not as it reads.
+        ``look``: the row's _Lookups."""
+        cv = self.cv
+        indel, cap = self.cfg.add_indel_length, self.max_len
+        find_alt_base, ins, dele = look.find_alt_base, look.ins, look.dele
+        if cls == 1:  # homo SNP (:748-756)
+            lab = cv.HOMO_SNP_LABELS[pos]
+            alt = lab[0] if lab[0] != ref else lab[1]
+            _, alt = find_alt_base(alt)
+            return None if alt is None else (ref, alt)  # alt == ref leaves the loop too (and output_with prints nothing, :1178)
+        if cls == 2:  # hetero SNP (:758-775)
+            lab = cv.HETERO_SNP_LABELS[pos]
+            if lab[0] != ref and lab[1] != ref:
+                bases, _ = find_alt_base()
+                return None if len(bases) < 2 else (ref, ",".join(bases[:2]))
+            alt = lab[0] if lab[0] != ref else lab[1]
+            _, alt = find_alt_base(alt)
+            return None if alt is None else (ref, alt)
+        entry = dec.class_entry(cls, pos, indel)
+        if cls == 3:  # homo insertion (:778-796)
+            bases = ins((entry if entry and entry < cap else None))
+            return None if len(bases) == 0 else (ref, bases)
+        if cls == 5:  # hetero ACGT + insertion (:800-828)
+            base, length = entry if indel else (entry, None)
+            bases = ins((length if length and length < cap else None))
+            if len(bases) == 0:
+                return None
+            if base != ref:
+                snps, _ = find_alt_base()
+                if len(snps) == 0:
+                    return ref, bases  # :822-825: zeroed and `continue`d with both alleles assigned -- the loop ends here
+                return ref, "{},{}".format(snps[0], bases)
+            return ref, bases
+        if cls == 6:  # two insertions (:830-877)
+            pair = []
+            if indel:
+                l1, l2 = entry
+                b1 = ins((l1 if l1 and l1 < cap else None))
+                if len(b1):
+                    b2 = ins((l2 if l2 and l2 < cap else None), b1)
+                    if len(b2):
+                        pair = [b1, b2]
+            if len(pair) < 2:
+                pair = ins(None, "", True)
+            if len(pair) < 2:
+                return None
+            first, other = pair
+            return (ref, first) if other == first else (ref, "{},{}".format(other, first))  # :869-877
+        if cls == 4:  # homo deletion (:879-895)
+            bases = dele((entry if entry and entry < cap else None))
+            if len(bases) == 0:
+                return None
+            r = ref + bases
+            return r, r[0]
+        if cls == 7:  # hetero ACGT + deletion (:897-922)
+            base, length = entry if indel else (entry, None)
+            bases = dele((length if length and length < cap else None))
+            if len(bases) == 0:
+                return None
+            r = ref + bases
+            if base != r[0]:
+                return r, "{},{}".format(r[0], base + r[1:])
+            return r, r[0]
+        if cls == 8:  # two deletions (:924-975)
+            pair = []
+            if indel:
+                l1, l2 = sorted(entry, reverse=True)
+                b1 = dele((l1 if l1 and l1 < cap else None))
+                if len(b1) > 0:
+                    b2 = dele((l2 if l2 and l2 < cap else None), b1)
+                    if len(b2) > 0:
+                        pair = [b1, b2] if len(b1) > len(b2) else [b2, b1]
+            if len(pair) < 2:
+                pair = dele(None, "", True)
+            if len(pair) < 2:
+                return None
+            longer, other = pair
+            r = ref + longer
+            a1, a2 = r[0], r[0] + r[len(other) + 1:]
+            if a1 != a2 and r != a1 and r != a2:
+                return r, "{},{}".format(a1, a2)
+            return r, a1  # :973-975
+        # cls == 9: insertion and deletion (:977-1008)
+        l1, l2 = entry if indel else (None, None)
+        ibases = ins((l2 if l2 and l2 < cap else None))
+        dbases = dele((l1 if l1 and l1 < cap else None))
+        if len(ibases) == 0 or len(dbases) == 0:
+            return None
+        r = ref + dbases
+        return r, "{},{}".format(r[0], ibases + r[1:])
+
+    # ------------------------------------------------------------------------------------------------ the tail of output_with
+    def _row(self, cls, ref, alt, prob, chromosome, position, depth, d):
+        """the text of output_with (:1176-1394) for a row of class ``cls`` with alleles (ref, alt) and maximum probability
+        ``prob`` (the float32 scalar), or None where it prints nothing"""
+        cv, c = self.cv, self.cfg
+        is_ref = cls == 0
+        if (not c.is_show_reference and is_ref) or (not is_ref and ref == alt):  # :1176-1180
+            return None
+        multi = "," in str(alt)
+        gt = self.gt_multi if multi else self.gt[_GENOTYPE_OF_CLASS[cls]]  # :1203-1211 (class 9 always carries two alleles)
+        snp, insd, deld, ref_count = {}, {}, {}, 0  # decode_alt_info (:1215-1230)
+        for k, n in d.items():
+            n = int(n)
+            t = k[0]
+            if t == "X":
+                snp[k[1]] = n
+            elif t == "I":
+                insd[k[1:]] = n
+            elif t == "D":
+                deld[k[1:]] = n
+            elif t == "R":
+                ref_count = n
+        ref_count = max(0, ref_count)
+        supported, counts = 0, []
+        if is_ref:  # :1236-1238
+            supported, alt = ref_count, "."
+        elif cls <= 2:  # SNPs (:1240-1246)
+            for base in str(alt):
+                if base == ",":
+                    continue
+                n = snp[base] if base in snp else 0
+                supported += n
+                counts.append(n)
+        elif cls == 3 or cls == 6:  # insertions (:1247-1255)
+            for bases in alt.split(","):
+                n = insd[bases] if bases in insd else 0
+                supported += n
+                counts.append(n)
+        elif cls == 5:  # SNP + insertion (:1256-1270)
+            snp_base = alt.split(",")[0][0] if multi else None
+            bases = alt.split(",")[1] if multi else alt
+            n_snp = (snp[snp_base] if snp_base in snp else 0) if multi else 0
+            n_ins = insd[bases] if bases in insd else 0
+            supported = n_ins + n_snp
+            if snp_base:
+                counts.append(n_snp)
+            counts.append(n_ins)
+        elif cls == 4 or cls == 8:  # deletions (:1271-1288)
+            if len(deld) > 0:
+                if cls == 4:
+                    bases = ref[1:] if len(ref) > 1 else None
+                    supported = deld[bases] if bases in deld else 0
+                    counts.append(supported)
+                elif len(deld) > 1:
+                    for bases in alt.split(","):
+                        n_del = len(ref) - len(bases)
+                        hit = [deld[k] for k in deld if len(k) == n_del]
+                        n = hit[0] if len(hit) > 0 else 0
+                        counts.append(n)
+                        supported += n
+        elif cls == 7:  # SNP + deletion (:1289-1305)
+            alts = alt.split(",")
+            snp_base = (alts[1][0] if len(alts) > 1 else None) if multi else None
+            n_snp = (snp[snp_base] if snp_base in snp else 0) if multi else 0
+            bases = ref[1:] if len(ref) > 1 else None
+            n_del = deld[bases] if bases in deld else 0
+            supported = n_del + n_snp
+            if snp_base:
+                counts.append(n_snp)
+            counts.append(n_del)
+        else:  # insertion and deletion (:1306-1322)
+            for bases in alt.split(","):
+                n_del = len(ref) - len(bases)
+                if n_del < 0:
+                    ibases = bases[:-(len(ref) - 1)] if len(ref) > 1 else bases
+                    n = insd[ibases] if ibases in insd else 0
+                else:
+                    hit = [deld[k] for k in deld if len(k) == n_del]
+                    n = hit[0] if len(hit) > 0 else 0
+                counts.append(n)
+                supported += n
+        af = ((supported + 0.0) / depth) if depth != 0 else 0.0  # :1324-1326
+        if af > 1:
+            af = 1
+        qual = cv.quality_score_from(prob)  # :1329
+        filt = cv.filtration_value_from(quality_score_for_pass=c.quality_score_for_pass, quality_score=qual, is_reference=is_ref)
+        if not c.keep_iupac_bases:  # :1342-1344; the function returns strings of A/C/G/T/N , . unchanged
+            if ref.translate(_PLAIN):
+                ref = cv.convert_iupac_to_n(ref)
+            if alt.translate(_PLAIN):
+                alt = cv.convert_iupac_to_n(alt)
+        ad = str(ref_count) + (("," + ",".join([str(n) for n in counts])) if len(counts) else "")  # :1357-1360
+        afs = "%.4f" % af if len(counts) <= 1 else ",".join(["%.4f" % (min(1.0, 1.0 * n / depth)) for n in counts])
+        return "%s\t%d\t.\t%s\t%s\t%.2f\t%s\t%s\tGT:GQ:DP:AD:AF\t%s:%d:%d:%s:%s\n" % (
+            chromosome, position, ref, alt, qual, filt, self.info, gt, qual, depth, ad, afs)
+
+    # ------------------------------------------------------------------------------------------------ a batch
+    def rows(self, batch_chr_pos_seq, alt_info_list, batch_Y):
+        """batch_Y: (B, 24|90 + DECODE_COLS) float32.  Returns a list with, per row, its VCF text, None (the reference prints
+        nothing for it) or FALLBACK."""
+        n = len(batch_chr_pos_seq)
+        parsed = [None] * n
+        centre = bytearray(n)
+        for i in range(n):  # :1127-1143
+            info = _text(batch_chr_pos_seq[i]).rstrip().split(":")
+            if len(info) == 3:
+                chromosome, position, seq = info
+            else:
+                position, seq = info[-2], info[-1]
+                chromosome = ":".join(info[:-2])
+            ref = seq[self.flank if len(seq) > 1 else 0]
+            parsed[i] = (chromosome, int(position), ref)
+            o = ord(ref)
+            centre[i] = o if o < 256 else 0
+        cols = batch_Y[:, self.width:]
+        b = np.frombuffer(bytes(centre), dtype=np.uint8)
+        bi = dec._REF_BASE_INDEX[b].astype(np.int64)
+        known = bi >= 0
+        bi = np.where(known, bi, 0)
+        r = np.arange(n)
+        cls = cols[r, 23 + bi].astype(np.int64)
+        k = np.maximum(cls, 1) - 1
+        pos = cols[r, 13 + k].astype(np.int64).tolist()
+        prob = np.where(cls > 0, cols[r, k], cols[r, 9 + bi])  # float32: the maximum of the first pass (:722-733) / all_pro[0] (:702-707)
+        # a maximum that two classes share: output_with's flag chains are not output_from's (:1203-1209 against :748 ff.)
+        shared = (cols[:, 0:9] == cols[r, k][:, None]).sum(axis=1) > 1
+        fast = (known & ~((cls > 0) & shared)).tolist()
+        cls = cls.tolist()
+        out = [FALLBACK] * n
+        for i in range(n):
+            if not fast[i]:
+                continue
+            chromosome, position, ref = parsed[i]
+            a = _text(alt_info_list[i]).rstrip().split("-")  # :1150-1154
+            depth = int(a[0])
+            seqs = (a[1] if len(a) > 1 else "").split(" ")
+            d = dict(zip(seqs[::2], [int(item) for item in seqs[1::2]])) if len(seqs) else {}
+            c = cls[i]
+            acgt = "ACGT"[bi[i]]
+            if c == 0:  # homo reference, early exit or not (:702-707, :735-740): both alleles are the A/C/G/T form of the base
+                out[i] = self._row(0, acgt, acgt, prob[i], chromosome, position, depth, d)
+                continue
+            look = _Lookups(self.cv, d, self.cfg.maximum_variant_length_that_need_infer)
+            alleles = self._alleles(c, pos[i], ref, look)
+            if alleles is not None:
+                out[i] = self._row(c, alleles[0], alleles[1], prob[i], chromosome, position, depth, d)
+                continue
+            found = self._next_candidate(batch_Y[i], cols[i, 9 + bi[i]], c, pos[i], ref, look)
+            if found is FALLBACK:
+                continue
+            self.retried += 1
+            if found is None:  # nothing above the homo-reference probability is offered by the reads (:735-740)
+                out[i] = self._row(0, acgt, acgt, cols[i, 9 + bi[i]], chromosome, position, depth, d)
+            else:
+                c, alleles, p = found
+                out[i] = self._row(c, alleles[0], alleles[1], p, chromosome, position, depth, d)
+        back = sum(1 for v in out if v is FALLBACK)
+        self.handed_back += back
+        self.taken += n - back
+        return out
+
+    def _next_candidate(self, y, homo_ref, cls0, pos0, ref, look):
+        """The passes of output_from's loop after its first candidate (class cls0, entry pos0) was rejected: -> (class,
+        alleles, maximum probability) of the first candidate the reads offer, None when the loop ends on the homo-reference
+        probability, FALLBACK when the accepted maximum is shared by two classes.
+        Each pass of the loop takes the maximum over homo_Ref and the nine lists, returns the reference call when that is
+        homo_Ref (:735), else looks up the first class of the chain that holds it at its first index and zeroes that entry
+        on rejection -- i.e. it walks the entries above homo_Ref by (probability falling, chain rank, index)."""
+        c = self.cfg
+        indel = c.add_indel_length
+        g, z = y[:21], y[21:24]
+        if indel:
+            p1, p2 = y[24:57], y[57:90]
+            values = np.concatenate([dec.class_list(k, g, z, p1, p2, True) for k in range(1, 10)])
+        else:
+            values = z[_Z24] * g[_G24]
+        keep = np.nonzero(values > homo_ref)[0]
+        values = values[keep]
+        order = np.lexsort((_INDEX[indel][keep], _RANK[indel][keep], -values.astype(np.float64)))
+        keep = keep[order]
+        values, klass, index = values[order], _KLASS[indel][keep].tolist(), _INDEX[indel][keep].tolist()
+        for j in range(len(klass)):
+            k, e = klass[j], index[j]
+            if j == 0 and (k != cls0 or e != pos0):
+                return FALLBACK  # the device's first decision is not the head of the walk: leave the row to the reference
+            alleles = None if j == 0 else self._alleles(k, e, ref, look)
+            if alleles is None:
+                continue
+            v = values[j]
+            t = j + 1
+            while t < len(klass) and values[t] == v:  # untried entries with the same probability: flags of other classes (:742-750)
+                if klass[t] != k:
+                    return FALLBACK
+                t += 1
+            return k, alleles, v
+        return None

@@ -33,7 +33,7 @@ def ref():
         del sys.modules[k]  # the next test that imports the reference gets unpatched modules
 
 
-def config(cv, pileup, indel):
+def config(cv, pileup, indel, **changes):
     if pileup:
         import shared.param_p as param
     else:
@@ -44,7 +44,14 @@ def config(cv, pileup, indel):
         is_haploid_sensitive_mode_enabled=False, is_output_for_ensemble=False, quality_score_for_pass=None,
         tensor_fn=None, input_probabilities=False, add_indel_length=indel, gvcf=False, pileup=pileup,
         enable_long_indel=False, maximum_variant_length_that_need_infer=param.maximum_variant_length_that_need_infer,
-        keep_iupac_bases=False)
+        keep_iupac_bases=False)._replace(**changes)
+
+
+def printer_of(cv, cfg):
+    """the RowPrinter (clair3_amd/vcf_rows.py) the rebound batch_output keeps for this configuration, counters reset"""
+    pr = cv._c3hip_row_printers[(cfg, id(cv.param))]
+    pr.taken = pr.retried = pr.handed_back = 0
+    return pr
 
 
 def widen(y, indel):
@@ -117,18 +124,21 @@ def test_retry_loop_is_the_reference_s(indel, ref):
         calls["rows"] += 1
         return real_outcome(*a, **k)
     decode._ClassProbs._array, decode.outcome_from_columns = counting_array, counting_outcome
+    cv.batch_output(pos[:1], alt[:1], widen(y[:1], indel), cfg, None)
+    pr = printer_of(cv, cfg)
     try:
         got = cv.batch_output(pos, alt, widen(y, indel), cfg, None)
     finally:
         decode._ClassProbs._array, decode.outcome_from_columns = real_array, real_outcome
     assert got == want
     assert want.count("\n") >= len(y) // 2
-    if not indel:  # 24-column rows: columns dropped, the reference's own enumeration (nothing to save there)
-        assert calls["rows"] == 0
-        return
-    assert calls["rows"] == len(y)
-    assert 0 < calls["lists"] < 9 * calls["rows"]
-    print(f"indel={indel}: {calls['rows']} rows, {calls['lists']} class lists had to be formed")
+    # rows are printed from the columns (vcf_rows.py), also after rejected candidates; only rows whose maximum two classes
+    # share go back to the reference's output_with -- on the look-alike lists when they carry indel lengths
+    assert pr.taken + pr.handed_back == len(y) and pr.retried > len(y) // 10
+    assert pr.handed_back <= len(y) // 4
+    assert calls["rows"] == (pr.handed_back if indel else 0)
+    print(f"indel={indel}: {pr.taken} rows printed from the columns ({pr.retried} after rejected candidates), "
+          f"{pr.handed_back} handed back, {calls['lists']} class lists formed for those")
 
 
 @pytest.mark.parametrize("indel", [True, False])
@@ -170,3 +180,78 @@ def test_rows_without_columns_take_the_reference_path(ref):
     cfg = config(cv, False, True)
     assert cv.batch_output(meta["positions"], meta["alt_info"], y, cfg, None) == meta["vcf_rows"]
     assert unpatched(meta["positions"], meta["alt_info"], y, cfg, None) == meta["vcf_rows"]
+
+
+@pytest.mark.parametrize("indel", [True, False])
+@pytest.mark.parametrize("noise", [0.0, 0.35])
+def test_rows_with_a_story_print_the_reference_s_text(indel, noise, ref):
+    """rows peaked on each of the ten outcome classes with alt_info that offers (noise 0) or partly lacks (0.35) the alleles
+    the class needs -- what a trained model and a real pileup hand the decoder: every row is printed from the columns
+    (clair3_amd/vcf_rows.py), none goes back to the reference, and the text is the unpatched batch_output's"""
+    from tests.decode_rows import consistent_rows
+    cv, unpatched = ref
+    pos, alt, y, classes = consistent_rows(1500, seed=7 + indel, indel=indel, noise=noise)
+    cfg = config(cv, not indel, indel)
+    want = unpatched(pos, alt, y, cfg, None)
+    cv.batch_output(pos[:1], alt[:1], widen(y[:1], indel), cfg, None)
+    pr = printer_of(cv, cfg)
+    assert cv.batch_output(pos, alt, widen(y, indel), cfg, None) == want
+    assert pr.taken == len(y) and pr.handed_back == 0
+    assert (pr.retried == 0) if noise == 0 else (pr.retried > 100)
+    if noise == 0:  # the story holds: one row per candidate, of the class it was peaked on
+        rows = want.splitlines()
+        assert len(rows) == len(y)
+        gts = [r.rsplit("\t", 1)[1].split(":")[0] for r in rows]
+        assert all(g == "0/0" for g, c in zip(gts, classes) if c == 0)
+        assert all(g == "1/1" for g, c in zip(gts, classes) if c in (1, 3, 4))
+        assert all(g in ("0/1", "1/2") for g, c in zip(gts, classes) if c in (2, 5, 6, 7, 8, 9))
+
+
+def test_output_modes_and_odd_inputs(ref):
+    """the switches of OutputConfig and the input forms output_with accepts (clair3/CallVariants.py:1127-1154): bytes and
+    numpy.bytes_ strings, contig names with colons, IUPAC and lower-case bases, depth 0, a QUAL threshold, no reference rows,
+    kept IUPAC bases; the modes the row printer leaves to the reference (gVCF, haploid) go through it unchanged"""
+    from tests.decode_rows import consistent_rows
+    cv, unpatched = ref
+    pos, alt, y, classes = consistent_rows(400, seed=19, indel=True, noise=0.2)
+    rng = np.random.default_rng(5)
+    for i in range(len(pos)):
+        chrom, p, seq = pos[i].split(":")
+        kind = i % 8
+        if kind == 1:
+            chrom = "HLA-A*01:01:01:01"
+        elif kind == 2:
+            seq = seq[:16] + "NRYKM"[i % 5] + seq[17:]            # IUPAC centre base (BASE2ACGT resolves it, :690)
+        elif kind == 3:
+            seq = seq[:17] + "N" + seq[18:]                        # IUPAC base inside a deletion
+        pos[i] = f"{chrom}:{p}:{seq}" + ("\n" if kind == 4 else "")
+        if kind == 5 and classes[i] == 0:
+            alt[i] = "0-" + alt[i].split("-", 1)[1]               # depth 0 (:1324; with two alternative alleles the reference divides by it, :1357)
+        elif kind == 6:
+            alt[i] = alt[i].split("-")[0] + "-"                   # no reads of any kind
+        if kind == 7:
+            pos[i], alt[i] = pos[i].encode(), np.bytes_(alt[i].encode())
+    yw = widen(y, True)
+    for changes in ({}, {"is_show_reference": False}, {"quality_score_for_pass": 12}, {"keep_iupac_bases": True},
+                    {"gvcf": True}, {"is_haploid_precise_mode_enabled": True}, {"is_haploid_sensitive_mode_enabled": True}):
+        cfg = config(cv, False, True, **changes)
+        want = unpatched(pos, alt, y, cfg, None)
+        got = cv.batch_output(pos, alt, yw, cfg, None)
+        assert got == want, changes
+        pr = cv._c3hip_row_printers[(cfg, id(cv.param))]
+        assert pr.usable == (not (changes.get("gvcf") or any(k.startswith("is_haploid") for k in changes)))
+    # a centre base outside the IUPAC table is the reference's KeyError (:690), with or without the columns
+    bad = pos[0].decode() if isinstance(pos[0], bytes) else pos[0]
+    chrom, p, seq = bad.rsplit(":", 2)
+    bad = f"{chrom}:{p}:{seq[:16]}x{seq[17:]}"
+    cfg = config(cv, False, True)
+    with pytest.raises(KeyError):
+        unpatched([bad], alt[:1], y[:1], cfg, None)
+    with pytest.raises(KeyError):
+        cv.batch_output([bad], alt[:1], yw[:1], cfg, None)
+    # the file-writing form (args.output_file, :1108-1110)
+    import io
+    import types
+    sink = types.SimpleNamespace(output_file=io.StringIO())
+    assert cv.batch_output(pos, alt, yw, cfg, None, sink) == ""
+    assert sink.output_file.getvalue() == unpatched(pos, alt, y, cfg, None)
