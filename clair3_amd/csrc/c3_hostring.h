@@ -57,7 +57,6 @@ extern "C" {
 static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     if (!sl.ev_h2d) {
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.ev_compute, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
     }
     if (!sl.pin_flag) HIP_TRY(hipHostMalloc((void **)&sl.pin_flag, 64, hipHostMallocDefault));
@@ -122,11 +121,13 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
         HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
         const bool f16 = m->f16_ok;
         TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
-        HIP_TRY(hipEventRecord(sl.ev_compute, m->stream));
-        HIP_TRY(hipStreamWaitEvent(m->d2h_stream, sl.ev_compute, 0));
-        HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, yb, hipMemcpyDeviceToHost, m->d2h_stream));
-        HIP_TRY(hipMemcpyAsync(sl.pin_flag, m->range_flag, 4, hipMemcpyDeviceToHost, m->d2h_stream));
-        HIP_TRY(hipEventRecord(sl.ev_out, m->d2h_stream));
+        // the rows (96 - 484 B per window) and the range flag leave through a copy kernel on the COMPUTE stream, whatever the
+        // batch: handing them to a transfer stream (event, cross-queue wait, two DMA copies, event) cost the compute queue
+        // ~75 us per batch -- 538 k -> 647 k windows/s host to host at B = 256 (profiles/r03_e_d2h_by_kernel.txt)
+        hipLaunchKernelGGL(host_copy_kernel, dim3(32), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
+                           (const uint32_t *)m->range_flag, sl.pin_flag);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
         sl.used_f16 = f16;
     }
     sl.y_host = y_host, sl.y_bytes = yb, sl.batch = batch, sl.x_dtype = x_dtype, sl.busy = true;

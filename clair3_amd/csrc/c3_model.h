@@ -96,7 +96,7 @@ struct HostSlot {
     void *dev_x = nullptr;
     float *dev_y = nullptr;
     size_t cap_x = 0, cap_y = 0;
-    hipEvent_t ev_h2d = nullptr, ev_compute = nullptr, ev_out = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_out = nullptr;
     float *y_host = nullptr;
     size_t y_bytes = 0;
     int64_t batch = 0;  // what is in flight (for the fp32 re-run of c3_predict_wait)
@@ -114,7 +114,7 @@ struct c3_model {
     int nb = 2, nout = 24;
     int row = 24;  // floats per output row: nout, + kDecodeCols when c3_model_set_decode_columns is on
     bool loaded = false;
-    hipStream_t stream = nullptr, h2d_stream = nullptr, d2h_stream = nullptr;
+    hipStream_t stream = nullptr, h2d_stream = nullptr;  // kernels (and the rows on their way out); staged windows on their way in
 
     // ---- packed weights (device) ----
     // pileup

@@ -74,8 +74,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     m->FC = kind == C3_KIND_PILEUP ? 128 : 256;
     m->K4 = kind == C3_KIND_PILEUP ? m->positions * 320 : 14 * 256;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->h2d_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->d2h_stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&m->h2d_stream, hipStreamNonBlocking) != hipSuccess) {
         fail("hipStreamCreate failed");
         delete m;
         return nullptr;
@@ -274,7 +273,6 @@ int c3_model_destroy(c3_model *m) {
         if (sl.dev_x) (void)hipFree(sl.dev_x);
         if (sl.dev_y) (void)hipFree(sl.dev_y);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
-        if (sl.ev_compute) (void)hipEventDestroy(sl.ev_compute);
         if (sl.ev_out) (void)hipEventDestroy(sl.ev_out);
     }
     for (auto &r : m->recs) {
@@ -283,7 +281,6 @@ int c3_model_destroy(c3_model *m) {
     }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     if (m->h2d_stream) (void)hipStreamDestroy(m->h2d_stream);
-    if (m->d2h_stream) (void)hipStreamDestroy(m->d2h_stream);
     delete m;
     return 0;
 }
