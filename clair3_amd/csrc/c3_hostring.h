@@ -23,12 +23,12 @@ static bool is_registered(const void *p, size_t n) {
     return false;
 }
 
-// Small batches (the pileup network: 594 B per window in, 96 B out) cross PCIe inside the COMPUTE stream instead: a copy kernel
-// reads the pinned staging buffer / writes the pinned result buffer directly (both are device-mapped), so a batch is ONE chain
-// of launches on one queue -- no copy engine, no cross-queue event waits, whose barrier packets cost a 210 us pileup batch
-// ~60 us of idle GPU per batch.  The transfer is then serial with the kernels, which is only worth it while it is
-// short: up to kKernelCopyMax bytes (4000 pileup windows = 2.4 MB, ~50 us at PCIe Gen5 rates under ~700 us of kernels);
-// full-alignment batches (23.5 MB per 1000 windows) keep the DMA engines.
+// Rows always leave through a copy kernel on the COMPUTE stream (host_copy_kernel writes the pinned, device-mapped result
+// buffer): handing them to a transfer stream -- event, cross-queue wait, DMA copies, event -- cost the compute queue ~75 us per
+// batch (profiles/r03_e_d2h_by_kernel.txt).  Windows come in on the transfer stream (DMA engine; the compute stream's wait for
+// that event is free, the transfer finished batches ago) -- except a small batch with nothing else in flight (the blocking call
+// of one chunk): there a copy kernel on the compute stream reading the pinned staging buffer is the shorter way, up to
+// kKernelCopyMax bytes (4000 pileup windows = 2.4 MB, ~50 us at PCIe Gen5 rates).
 constexpr size_t kKernelCopyMax = (size_t)4 << 20;
 __global__ __launch_bounds__(256) void host_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
                                                        const uint32_t *flag_src, uint32_t *flag_dst) {
@@ -99,7 +99,12 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     const size_t yb = (size_t)batch * m->row * sizeof(float);
     // C3HIP_HOST_COPY_KERNEL: 0 = never, 1 = up to kKernelCopyMax, n > 1 = up to n KB (A/B of the threshold)
     const size_t kcopy_max = m->host_copy_kernel > 1 ? (size_t)m->host_copy_kernel << 10 : kKernelCopyMax;
-    if (batch > 0 && m->host_copy_kernel && xb <= kcopy_max && yb <= kcopy_max && !src_locked && !is_registered(x_host, xb)) {
+    // ... and only while no other batch of this handle is in flight: behind a running batch the transfer stream brings the windows
+    // in under its kernels (pileup ring 4.22 M -> 4.37 M windows/s), alone the copy kernel is the shorter way (blocking call of one
+    // chunk 3.87 M against 3.64 M)
+    bool alone = true;
+    for (int k = 0; k < kHostSlots; ++k) alone &= !m->slot[k].busy;
+    if (batch > 0 && m->host_copy_kernel && alone && xb <= kcopy_max && yb <= kcopy_max && !src_locked && !is_registered(x_host, xb)) {
         TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, (yb + 255) & ~(size_t)255));
         StagePool::get().copy(sl.pin_x, x_host, xb);  // (plain memcpy below 1 MB, split over the helpers above)
         hipLaunchKernelGGL(host_copy_kernel, dim3(128), dim3(256), 0, m->stream, (const uint4 *)sl.pin_x, (uint4 *)sl.dev_x, (xb + 15) / 16,
