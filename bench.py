@@ -236,14 +236,17 @@ def run_workload(name, args, rank, world, local):
     if world == 1 and not args.no_host_leg:
         hl = {"slots_in_flight": HOST_SLOTS, "handles": 1,
               "path": "pageable numpy -> staging pool memcpy -> pinned -> H2D -> kernels -> D2H -> numpy (c3_predict_submit / _wait)"}
-        el, y = host_leg(model, x_host, args.steps, args.warmup)
+        # the supplementary host legs run >= 100 (B = 256 / 1024) and >= 25 (B = 1000) steps whatever --steps says: a ring of four
+        # batches needs more than the driver's 20 steps before filling and draining it stop showing (0.875 against 0.955)
+        hsteps = max(args.steps, 100)
+        el, y = host_leg(model, x_host, hsteps, args.warmup)
         assert y.shape == (batch, 90 if indel else 24) and np.isfinite(y).all()
-        hl.update({"value": batch * args.steps / el, "ms_per_step": 1e3 * el / args.steps, "batch": batch,
-                   "frac_of_device_resident_one_in_flight": (batch * args.steps / el) / res["one_batch_in_flight"]["value"]})
+        hl.update({"value": batch * hsteps / el, "ms_per_step": 1e3 * el / hsteps, "batch": batch, "steps": hsteps,
+                   "frac_of_device_resident_one_in_flight": (batch * hsteps / el) / res["one_batch_in_flight"]["value"]})
         if not args.batch:
             bref = 1000  # the reference's GPU batch (CallVariantsFromCffi.py:265-269: predictBatchSize * 5)
             xb = syn.make_windows(kind, bref, seed=2000, channels=channels)
-            k = max(10, args.steps * batch // bref)
+            k = max(25, args.steps * batch // bref)
             el, y = host_leg(model, xb, k, 3)
             xd = torch.from_numpy(xb).to(dev)
             for _ in range(3):
@@ -302,9 +305,12 @@ def run_workload(name, args, rank, world, local):
                     return n
                 gw = c3worker.group_windows_for(model)
                 loop(gw)
-                t0 = time.perf_counter()
-                n_loop = loop(gw)
-                el_loop = time.perf_counter() - t0
+                el_loops = []
+                for _ in range(3):  # a 35 - 45 ms job: the best of three passes (the spread goes into the line)
+                    t0 = time.perf_counter()
+                    n_loop = loop(gw)
+                    el_loops.append(time.perf_counter() - t0)
+                el_loop = min(el_loops)
                 t0 = time.perf_counter()
                 loop(0)
                 el_loop1 = time.perf_counter() - t0
@@ -312,6 +318,7 @@ def run_workload(name, args, rank, world, local):
                 shutil.rmtree(tdir, ignore_errors=True)
             hl["batch_1000"]["dropin_loop"] = {"value": n_loop / el_loop, "ms_per_call": 1e3 * el_loop / (n_loop / bref),
                                                "frac_of_device_resident": (n_loop / el_loop) / (bref * k / el_dev),
+                                               "passes": [round(n_loop / e) for e in el_loops],
                                                "windows_per_forward_pass": gw, "tensor_files": n_files, "windows_per_file": per_file,
                                                "one_forward_pass_per_batch": {"value": n_loop / el_loop1,
                                                                               "frac_of_device_resident": (n_loop / el_loop1) / (bref * k / el_dev)},
