@@ -4,7 +4,7 @@
 // Why: one host thread moves ~10 GB/s; a full-alignment batch of 1000 windows is 23.5 MB (clair3/CallVariantsFromCffi.py:
 // 265-269 -> 1000 x 89 x 33 x 8 int8), i.e. 2-3 ms of memcpy against ~1.3 ms of kernels and ~0.5 ms of PCIe Gen5 DMA:
 // the staging copy, not the GPU, bounded the host-inclusive rate of round 1.  The pool splits every
-// staged piece over C3HIP_STAGE_THREADS helpers (default 3) plus the calling thread.  Threads are created lazily on the
+// staged piece over three helpers plus the calling thread.  Threads are created lazily on the
 // first staged copy -- after the reference worker has forked its decode pool (CallVariantsFromCffi.py:246 vs :302), so
 // no thread is ever lost to a fork.
 #pragma once
@@ -53,9 +53,7 @@ private:
     int ensure_started() {
         if (started_) return (int)threads_.size();
         started_ = true;
-        int n = 3;
-        if (const char *e = getenv("C3HIP_STAGE_THREADS")) n = atoi(e);
-        n = n < 0 ? 0 : (n > 15 ? 15 : n);
+        const int n = 3;  // measured against 1, 2, 5 and 7 in round 2: the copy is memory-bound beyond four threads
         for (int i = 0; i < n; ++i) {
             threads_.emplace_back([this] { run(); });
             threads_.back().detach();

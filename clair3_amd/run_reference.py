@@ -36,8 +36,7 @@ def main(argv=None):
     if do_install:
         from clair3_amd import callvar
         names = callvar.install(decoder=decoder)
-        if os.environ.get("C3HIP_VERBOSE"):
-            print("[clair3_amd] rebound: " + ", ".join(names), file=sys.stderr)
+        print("[clair3_amd] rebound: " + ", ".join(names), file=sys.stderr)
     sys.argv = [os.path.join(ref, "clair3.py")] + argv
     runpy.run_path(sys.argv[0], run_name="__main__")
 

@@ -84,8 +84,7 @@ def test_unmodified_worker_command_on_libc3hip(name, ref, jobs):
     kind, channels, indel, pileup, dwell, sizes = CASES[name]
     job = jobs(name)
     got = os.path.join(job["dir"], "hip.vcf")
-    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, dwell=dwell, hip=True,
-                                 extra_env={"C3HIP_VERBOSE": "1"})
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, dwell=dwell, hip=True)
     assert rc == 0, out[-3000:]
     assert "tensor_generator_for_chunk" in out  # install() ran in that process
     assert f"Total processed positions : {sum(sizes)}" in out, out[-3000:]
