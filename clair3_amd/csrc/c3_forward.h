@@ -280,8 +280,10 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     m->last_planes = h1_planes;
     {
         ProfScope ps(m, s, "p.lstm1", 2.0 * M * 1024.0 * m->C + 2.0 * M * 2.0 * 512.0 * 128.0, sizeof(T) * (double)M * m->C + 4.0 * M * 256.0);
-        // half tiles (8 windows per workgroup, c3_lstm_fused.h OPT bit 2) while the full tiles would leave CUs without a workgroup
-        const bool half1 = l1_f16 && m->half_tiles && m->sharing <= 1 && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 2;
+        // half tiles (8 windows per workgroup, c3_lstm_fused.h OPT bit 2) while the full tiles would leave half the CUs without a
+        // workgroup (<= 1024 windows on 256 CUs; beyond that two half tiles share a CU and take twice as long: 1100 windows 94 us
+        // against 60 us on full tiles)
+        const bool half1 = l1_f16 && m->half_tiles && m->sharing <= 1 && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 4;
         const double tiles = (double)(half1 ? (n + 7) / 8 * 16 : (n + 15) / 16 * 16) * Tn * 2;  // (window, step, direction) rows of the 16-row tiles
         // recurrent part 512 x 128 as fp16x3 (or fp32); input part: int8 windows 512 x 32 against two weight pieces, else 512 x 20 fp32
         ps.mfma(l1_f16 ? tiles * 2.0 * 512 * (128 * 3 + (sizeof(T) == 1 ? 32 * 2 : 0)) : tiles * 2.0 * 512 * (128 + 20), l1_f16);
