@@ -39,6 +39,10 @@ def _limit_gpu_memory(memory_mb, device):
     return  # libc3hip sizes its own workspace (c3_mem_info is the accounting hook); nothing to cap
 
 
+def _limit_gpu_memory_legacy(memory_mb):  # clair3/CallVariants.py:72 has no device parameter
+    return
+
+
 def _check_gpu_memory_or_exit(memory, device_ids=None, print_log=True):
     from shared.utils import log_error  # reference helper, only available inside the reference tree
     try:
@@ -99,6 +103,15 @@ def install(worker=True, gpu_wrapper=True, decoder=False):
         done += ["clair3.CallVariantsFromCffi." + n for n in
                  ("_torch_predict", "_load_torch_checkpoint", "_select_device", "_limit_gpu_memory",
                   "tensor_generator_for_chunk")]
+    if worker:
+        # the twins of the same four functions in the legacy stdin-pipe worker (clair3/CallVariants.py:54-87; call_variants
+        # :1456 ff. imports the model classes when it runs, i.e. it gets the rebound ones): same model call, its own transport
+        import clair3.CallVariants as legacy
+        legacy._torch_predict = predict._hip_predict
+        legacy._load_torch_checkpoint = predict._load_torch_checkpoint
+        legacy._select_device = _select_device_for_worker
+        legacy._limit_gpu_memory = _limit_gpu_memory_legacy
+        done += ["clair3.CallVariants." + n for n in ("_torch_predict", "_load_torch_checkpoint", "_select_device", "_limit_gpu_memory")]
     if decoder:
         from . import decode
         if worker:

@@ -75,6 +75,38 @@ def run_worker(ref, lst, chkpnt, call_fn, pileup, indel, dwell=False, hip=True, 
     return r.returncode, r.stdout + r.stderr
 
 
+def write_pipe_tensors(path, kind, n, channels=None, seed=0):
+    """the text stream the legacy worker reads from stdin (clair3/utils.py:79-148 tensor_generator_from): one window per line,
+    ``chrom<TAB>coord<TAB>seq<TAB>values<TAB>alt_info``"""
+    from tests.test_decode_dropin import alt_infos
+    x = syn.make_windows(kind, n, seed=seed + 40, channels=channels)
+    pos, alt = alt_infos(n, seed=seed + 70)
+    with open(path, "w") as f:
+        for j in range(n):
+            seq = pos[j].split(":")[2]
+            f.write(f"chr{1 + j % 3}\t{5000 + 41 * j}\t{seq}\t{' '.join(map(str, x[j].ravel().tolist()))}\t{alt[j]}\n")
+    return n
+
+
+def run_legacy_worker(ref, tensor_txt, chkpnt, call_fn, pileup, indel, hip=True, decoder=False, timeout=900):
+    """the reference's stdin-pipe worker (``clair3.py CallVariants --tensor_fn PIPE``, clair3/CallVariants.py:1456-1621), on
+    libc3hip (--use_gpu True after install()) or on its own modules on the CPU; returns (returncode, stdout + stderr)"""
+    cmd = [sys.executable, "-m", "clair3_amd.run_reference", "--ref", ref]
+    if not hip:
+        cmd.append("--no-install")
+    if decoder:
+        cmd.append("--decoder")
+    cmd += ["CallVariants", "--tensor_fn", "PIPE", "--chkpnt_fn", chkpnt, "--call_fn", call_fn, "--sampleName", "SAMPLE",
+            "--platform", "ont", "--use_gpu", "True" if hip else "False", "--showRef", "--add_indel_length", str(bool(indel))]
+    if pileup:
+        cmd.append("--pileup")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, STUBS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+    with open(tensor_txt) as stdin:
+        r = subprocess.run(cmd, env=env, stdin=stdin, capture_output=True, text=True, timeout=timeout, cwd=os.path.dirname(call_fn))
+    return r.returncode, r.stdout + r.stderr
+
+
 def vcf_records(path):
     """{(chrom, pos): fields} of a VCF the worker wrote (rows arrive in completion order of its decode processes)"""
     out = {}

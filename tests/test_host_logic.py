@@ -59,10 +59,13 @@ def test_install_rebinds_the_reference_call_sites():
         orig = {n: inspect.signature(getattr(w, n)) for n in ("_torch_predict", "_load_torch_checkpoint", "_select_device",
                                                               "_limit_gpu_memory", "tensor_generator_for_chunk")}
         orig_g = {n: inspect.signature(getattr(g, n)) for n in ("get_gpu_memory", "check_gpu_memory")}
+        import clair3.CallVariants as legacy
+        orig_l = {n: inspect.signature(getattr(legacy, n)) for n in ("_torch_predict", "_load_torch_checkpoint", "_select_device",
+                                                                     "_limit_gpu_memory")}
         from clair3_amd import callvar, predict
         from clair3_amd.model import Clair3_F, Clair3_P
         names = callvar.install()
-        assert len(names) == 9
+        assert len(names) == 13
         assert w.tensor_generator_for_chunk._c3hip_original.__module__ == "clair3.CallVariantsFromCffi"
         assert callvar.install() == names  # idempotent: the generator is wrapped once
         assert not hasattr(w.tensor_generator_for_chunk._c3hip_original, "_c3hip_original")
@@ -73,6 +76,9 @@ def test_install_rebinds_the_reference_call_sites():
             assert list(inspect.signature(getattr(w, n)).parameters) == list(sig.parameters), n
         for n, sig in orig_g.items():
             assert list(inspect.signature(getattr(g, n)).parameters) == list(sig.parameters), n
+        for n, sig in orig_l.items():  # the legacy stdin-pipe worker's twins (clair3/CallVariants.py:54-87)
+            assert list(inspect.signature(getattr(legacy, n)).parameters) == list(sig.parameters), n
+        assert legacy._torch_predict is predict._hip_predict
         # constructor keywords used at CallVariantsFromCffi.py:232,243
         m = ref_model.Clair3_F(add_indel_length=True, predict=True, input_channels=9)
         assert m.output_size == 90 and m.input_channels == 9
@@ -82,7 +88,7 @@ def test_install_rebinds_the_reference_call_sites():
         unpatched = cv.batch_output
         assert not predict.DECODER_COLUMNS
         names = callvar.install(decoder=True)
-        assert len(names) == 11 and predict.DECODER_COLUMNS
+        assert len(names) == 15 and predict.DECODER_COLUMNS
         assert cv.batch_output is not unpatched and w.batch_output is cv.batch_output
         for n, params in sig.items():
             assert list(inspect.signature(getattr(cv, n)).parameters) == params, n

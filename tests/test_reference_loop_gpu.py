@@ -132,3 +132,24 @@ def test_gpu_wrapper_slot_probe_on_the_device(ref):
     assert slots == sorted(set(slots)) and len(slots) >= 1  # one slot per visible device
     assert int(m.group(2)) > 100_000  # MB free on an MI355X
     assert "would start" in r.stdout
+
+
+@pytest.mark.parametrize("name,decoder", [("pileup", False), ("full_alignment", False), ("full_alignment", True)])
+def test_legacy_stdin_worker_on_libc3hip(name, decoder, ref, tmp_path):
+    """the reference's other worker, ``clair3.py CallVariants --tensor_fn PIPE`` (clair3/CallVariants.py:1456-1621: text
+    tensors on stdin, int32 pileup windows, batches of predictBatchSize, decode on a thread beside the next load): install()
+    rebinds its twins of the four model-call functions as well -- same VCF as the same command on the reference's CPU modules"""
+    kind, channels, indel, pileup, _, _ = CASES[name]
+    n = 900 if pileup else 260
+    d = str(tmp_path)
+    txt = os.path.join(d, "tensors.txt")
+    refloop.write_pipe_tensors(txt, kind, n, channels=channels)
+    ck = os.path.join(d, "model")
+    refloop.write_checkpoint(ck + ".pt", kind, channels, indel)
+    want, got = os.path.join(d, "reference_cpu.vcf"), os.path.join(d, "hip.vcf")
+    rc, out = refloop.run_legacy_worker(ref, txt, ck, want, pileup, indel, hip=False)
+    assert rc == 0 and f"Total processed positions in None : {n}" in out, out[-3000:]
+    rc, out = refloop.run_legacy_worker(ref, txt, ck, got, pileup, indel, hip=True, decoder=decoder)
+    assert rc == 0 and f"Total processed positions in None : {n}" in out, out[-3000:]
+    assert "clair3.CallVariants._torch_predict" in out  # run_reference lists what install() rebound
+    check(name, dict(want=want, n=n, ref_s=None), got, out, "legacy_decoder" if decoder else "legacy")
