@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "7")))
 cases = [(syn.PILEUP, 18, False), (syn.PILEUP, 18, True), (syn.FULL_ALIGNMENT, 8, True), (syn.FULL_ALIGNMENT, 9, True), (syn.FULL_ALIGNMENT, 8, False)]
 models = {}
 t_end = time.time() + budget
-n_batches = n_rows = n_models = 0
+n_batches = n_rows = n_models = n_sensitive = 0
 worst = 0.0
 while time.time() < t_end:
     kind, ch, indel = cases[int(rng.integers(len(cases)))]
@@ -27,10 +27,11 @@ while time.time() < t_end:
     if key not in models or rng.random() < 0.2:
         # weights, not only batches: half the models are re-parametrised the way training leaves them (per-channel scales over
         # decades, zero bias_hh, a few +-8 LSTM weights: synthetic._trained_like), a quarter have peaked heads
-        sd = syn.make_state_dict(kind, ch, indel, seed=seed, peaked=bool(rng.random() < 0.25), trained_like=bool(rng.random() < 0.5))
-        models[key] = (make_model(kind, ch, indel, sd), sd)
+        flags = dict(seed=seed, peaked=bool(rng.random() < 0.25), trained_like=bool(rng.random() < 0.5))
+        sd = syn.make_state_dict(kind, ch, indel, **flags)
+        models[key] = (make_model(kind, ch, indel, sd), sd, flags)
         n_models += 1
-    m, sd = models[key]
+    m, sd, flags = models[key]
     hi = 1300 if kind == syn.PILEUP else 330
     n = int(rng.integers(1, hi)) if rng.random() < 0.7 else int(rng.choice([1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 184, 185, 186, 255, 256, 257]))
     recipe = "uniform" if rng.random() < 0.3 else "realistic"
@@ -42,8 +43,28 @@ while time.time() < t_end:
     err = float(np.abs(y[idx] - y_o).max())
     worst = max(worst, err)
     lab = (y[idx, :21].argmax(1) == y_o[:, :21].argmax(1)).all() and (y[idx, 21:24].argmax(1) == y_o[:, 21:24].argmax(1)).all()
+    if not (err < 1e-4) and np.isfinite(y).all() and lab:
+        # a window can be so sensitive under these weights (LSTM entries of +-8: a recurrence that amplifies rounding) that the
+        # reference's own fp32 arithmetic is 1e-4 from the exact rows; the library is held to three times the distance of the
+        # fp32 PyTorch restatement of the reference modules from the fp64 oracle on the same rows
+        from oracle import torch_port
+        y_t = torch_port.forward(kind, torch_port.to_torch(sd), x[idx], indel).numpy()
+        err_t = float(np.abs(y_t - y_o).max())
+        if err <= 3.0 * err_t + 2e-5:
+            print(f"sensitive window: kind={kind} n={n} seed={seed} weights={flags}: |dY| {err:.2e}, fp32 PyTorch itself {err_t:.2e} from the oracle", flush=True)
+            n_sensitive += 1
+            err = 0.0
     if not (err < 1e-4) or not np.isfinite(y).all() or not lab:
-        print(f"MISMATCH kind={kind} ch={ch} indel={indel} n={n} seed={seed} recipe={recipe} err={err:.3e} labels_equal={lab}")
+        print(f"MISMATCH kind={kind} ch={ch} indel={indel} n={n} seed={seed} recipe={recipe} err={err:.3e} labels_equal={lab} weights={flags}")
+        # where does the distance come from: the fp32 PyTorch restatement of the reference modules (what the parity gate is
+        # about) and the library's fp32-MFMA forms, each against the fp64 oracle
+        from oracle import torch_port
+        y_t = torch_port.forward(kind, torch_port.to_torch(sd), x[idx], indel).numpy()
+        os.environ["C3HIP_FP32"] = "1"
+        y32 = make_model(kind, ch, indel, sd).predict_numpy(x)[idx]
+        bad = int(np.abs(y[idx] - y_o).max(axis=1).argmax())
+        print(f"  fp32 torch vs oracle {np.abs(y_t - y_o).max():.3e}; libc3hip fp32 forms vs oracle {np.abs(y32 - y_o).max():.3e}; "
+              f"fp16x3 vs fp32 torch {np.abs(y[idx] - y_t).max():.3e}; worst row {idx[bad]}")
         sys.exit(1)
     # the same windows again in a different batch composition: bit-identical rows
     if n > 3:
@@ -54,4 +75,5 @@ while time.time() < t_end:
             sys.exit(1)
     n_batches += 1
     n_rows += n
-print(f"ok: {n_batches} batches, {n_rows} windows, {n_models} weight sets, worst |dY| on the checked rows {worst:.2e}")
+print(f"ok: {n_batches} batches, {n_rows} windows, {n_models} weight sets, worst |dY| on the checked rows {worst:.2e} "
+      f"({n_sensitive} batches held a window on which fp32 PyTorch itself is > 3e-5 from the oracle)")
