@@ -713,7 +713,7 @@ def test_two_handles_side_by_side_give_the_same_rows(oracle_mod):
     handle alone on the chip, bit for bit -- kernel forms are a function of the batch and of the caller's sharing hint
     (c3_model_set_sharing: full LSTM tiles, half as many projection workgroups), never of what else happens to be running"""
     sd = syn.make_state_dict(syn.PILEUP, 18, False, seed=101)
-    x = syn.make_pileup_windows(1024 + 5, seed=102)
+    x = syn.make_pileup_windows(1000 + 5, seed=102)  # <= 1024 windows: alone on the chip both recurrences take half tiles
     m1 = make_model(syn.PILEUP, 18, False, sd)
     m2 = make_model(syn.PILEUP, 18, False, sd)
     y_alone = m1.predict_numpy(x)
