@@ -40,6 +40,7 @@ _RANK = {indel: _CHAIN_RANK[_KLASS[indel]] for indel in (True, False)}
 # so one gather-multiply gives the 23 of them bit for bit): the zygosity / gt21 index of every entry in list order
 _Z24 = np.array([1] * 4 + [2] * 6 + [1, 1] + [2] * 4 + [2] + [2] * 4 + [2, 2])
 _G24 = np.array(list(dec.HOMO_SNP_GT21) + list(dec.HETERO_SNP_GT21) + [15, 10] + [16, 17, 18, 19] + [15] + [11, 12, 13, 14] + [10, 20])
+_WALK_PATIENCE = 12  # rejected candidates of a row before RowPrinter._hopeless sorts out the rest of its walk
 _PLAIN = {ord(ch): None for ch in "ACGTNacgtn,."}  # what convert_iupac_to_n leaves alone (shared/utils.py:27-40)
 
 
@@ -361,6 +362,34 @@ class RowPrinter:
         self.taken += n - back
         return out
 
+    def _hopeless(self, entries, look):
+        """For a row that keeps rejecting candidates: which of the walk's entries (positions in the nine lists laid end to end)
+        _alleles is certain to reject, from sixteen insertion and sixteen deletion lookups instead of one pass per entry.
+        What _alleles does per class (the line numbers there): a homo insertion / deletion and an ACGT + insertion / deletion
+        are rejected exactly when the lookup for their length comes back empty; an insertion-and-deletion when either does;
+        two insertions / two deletions are rejected exactly when the reads offer fewer than two alleles of that kind; SNPs are
+        always left to _alleles."""
+        cap = self.max_len
+        lengths = [(n if n < cap else None) for n in range(1, cap + 1)]
+        no_ins = np.array([len(look.ins(n)) == 0 for n in lengths])
+        no_del = np.array([len(look.dele(n)) == 0 for n in lengths])
+        dead = np.zeros(len(_KLASS[True]), dtype=bool)
+        o = np.cumsum((0,) + dec._CLASS_LEN[True][1:])  # start of class k's list at o[k - 1]
+        dead[o[2]:o[3]] = no_ins                                      # 3 homo_Ins: entry = length - 1
+        dead[o[3]:o[4]] = no_del                                      # 4 homo_Del
+        dead[o[4]:o[5]] = np.repeat(no_ins, 4)                        # 5 hetero_ACGT_Ins: entry = 4 (length - 1) + base
+        dead[o[6]:o[7]] = np.repeat(no_del, 4)                        # 7 hetero_ACGT_Del
+        dead[o[8]:o[9]] = np.logical_or.outer(no_del, no_ins).ravel()  # 9 hetero_InsDel: entry = 16 (deletion - 1) + insertion - 1
+        if self.cfg.maximum_variant_length_that_need_infer >= cap + 1:
+            # every proposed length (< 16, + the reference base for insertions) lies inside the general range of the lookups, so a
+            # second allele for a proposed pair can only be one that return_multi would offer as well: with fewer than two alleles
+            # of the kind in range both the proposals (:838-848, :929-944) and return_multi (:849-855, :945-950) come back short
+            if len(look.ins(None, "", True)) < 2:
+                dead[o[5]:o[6]] = True                                # 6 hetero_InsIns
+            if len(look.dele(None, "", True)) < 2:
+                dead[o[7]:o[8]] = True                                # 8 hetero_DelDel
+        return dead[entries].tolist()
+
     def _next_candidate(self, y, homo_ref, cls0, pos0, ref, look):
         """The passes of output_from's loop after its first candidate (class cls0, entry pos0) was rejected: -> (class,
         alleles, maximum probability) of the first candidate the reads offer, None when the loop ends on the homo-reference
@@ -381,12 +410,17 @@ class RowPrinter:
         order = np.lexsort((_INDEX[indel][keep], _RANK[indel][keep], -values.astype(np.float64)))
         keep = keep[order]
         values, klass, index = values[order], _KLASS[indel][keep].tolist(), _INDEX[indel][keep].tolist()
+        skip = None
         for j in range(len(klass)):
             k, e = klass[j], index[j]
             if j == 0 and (k != cls0 or e != pos0):
                 return FALLBACK  # the device's first decision is not the head of the walk: leave the row to the reference
+            if skip is not None and skip[j]:
+                continue
             alleles = None if j == 0 else self._alleles(k, e, ref, look)
             if alleles is None:
+                if j == _WALK_PATIENCE and indel:
+                    skip = self._hopeless(keep, look)
                 continue
             v = values[j]
             t = j + 1
