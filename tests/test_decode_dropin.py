@@ -207,13 +207,14 @@ def test_rows_with_a_story_print_the_reference_s_text(indel, noise, ref):
         assert all(g in ("0/1", "1/2") for g, c in zip(gts, classes) if c in (2, 5, 6, 7, 8, 9))
 
 
-def test_output_modes_and_odd_inputs(ref):
+@pytest.mark.parametrize("indel", [True, False])
+def test_output_modes_and_odd_inputs(indel, ref):
     """the switches of OutputConfig and the input forms output_with accepts (clair3/CallVariants.py:1127-1154): bytes and
     numpy.bytes_ strings, contig names with colons, IUPAC and lower-case bases, depth 0, a QUAL threshold, no reference rows,
     kept IUPAC bases; the modes the row printer leaves to the reference (gVCF, haploid) go through it unchanged"""
     from tests.decode_rows import consistent_rows
     cv, unpatched = ref
-    pos, alt, y, classes = consistent_rows(400, seed=19, indel=True, noise=0.2)
+    pos, alt, y, classes = consistent_rows(400, seed=19, indel=indel, noise=0.2)
     rng = np.random.default_rng(5)
     for i in range(len(pos)):
         chrom, p, seq = pos[i].split(":")
@@ -231,10 +232,10 @@ def test_output_modes_and_odd_inputs(ref):
             alt[i] = alt[i].split("-")[0] + "-"                   # no reads of any kind
         if kind == 7:
             pos[i], alt[i] = pos[i].encode(), np.bytes_(alt[i].encode())
-    yw = widen(y, True)
+    yw = widen(y, indel)
     for changes in ({}, {"is_show_reference": False}, {"quality_score_for_pass": 12}, {"keep_iupac_bases": True},
                     {"gvcf": True}, {"is_haploid_precise_mode_enabled": True}, {"is_haploid_sensitive_mode_enabled": True}):
-        cfg = config(cv, False, True, **changes)
+        cfg = config(cv, not indel, indel, **changes)
         want = unpatched(pos, alt, y, cfg, None)
         got = cv.batch_output(pos, alt, yw, cfg, None)
         assert got == want, changes
@@ -244,7 +245,7 @@ def test_output_modes_and_odd_inputs(ref):
     bad = pos[0].decode() if isinstance(pos[0], bytes) else pos[0]
     chrom, p, seq = bad.rsplit(":", 2)
     bad = f"{chrom}:{p}:{seq[:16]}x{seq[17:]}"
-    cfg = config(cv, False, True)
+    cfg = config(cv, not indel, indel)
     with pytest.raises(KeyError):
         unpatched([bad], alt[:1], y[:1], cfg, None)
     with pytest.raises(KeyError):
@@ -255,3 +256,38 @@ def test_output_modes_and_odd_inputs(ref):
     sink = types.SimpleNamespace(output_file=io.StringIO())
     assert cv.batch_output(pos, alt, yw, cfg, None, sink) == ""
     assert sink.output_file.getvalue() == unpatched(pos, alt, y, cfg, None)
+
+
+def test_hopeless_entries_are_exactly_the_ones_the_lookup_rejects(ref):
+    """RowPrinter._hopeless (the shortcut of a long rejection walk) against RowPrinter._alleles entry by entry, on alt_info
+    dictionaries with no / one / several insertions and deletions of every length, lengths beyond the inference range included:
+    an entry of classes 3-9 is marked hopeless exactly when the per-entry lookup rejects it"""
+    from clair3_amd import decode, vcf_rows
+    cv, _ = ref
+    cfg = config(cv, False, True)
+    pr = vcf_rows.RowPrinter(cv, cfg)
+    rng = np.random.default_rng(3)
+    n_entries = len(vcf_rows._KLASS[True])
+    checked = rejected = 0
+    for trial in range(60):
+        d = {}
+        for kind in "ID":
+            for _ in range(int(rng.integers(0, 4)) if trial % 5 else 0):
+                length = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 30, 49, 50, 51, 60]))
+                bases = "".join("ACGT"[j] for j in rng.integers(0, 4, size=length))
+                d[kind + ("A" + bases if kind == "I" else bases)] = int(rng.integers(1, 30))
+        if trial % 3 == 0:
+            d["XC"] = 5
+        d["RA"] = 9
+        look = vcf_rows._Lookups(cv, d, cfg.maximum_variant_length_that_need_infer)
+        dead = pr._hopeless(np.arange(n_entries), look)
+        for e in range(n_entries):
+            k, pos = int(vcf_rows._KLASS[True][e]), int(vcf_rows._INDEX[True][e])
+            if k <= 2:
+                assert not dead[e]  # SNP classes are always left to the lookup
+                continue
+            alleles = pr._alleles(k, pos, "A", vcf_rows._Lookups(cv, d, cfg.maximum_variant_length_that_need_infer))
+            assert dead[e] == (alleles is None), (trial, d, decode.CLASS_NAMES[k], pos, alleles)
+            checked += 1
+            rejected += alleles is None
+    assert checked > 40000 and 0.2 < rejected / checked < 0.9
