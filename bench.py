@@ -236,7 +236,7 @@ def run_workload(name, args, rank, world, local):
     if world == 1 and not args.no_host_leg:
         hl = {"slots_in_flight": HOST_SLOTS, "handles": 1,
               "path": "pageable numpy -> staging pool memcpy -> pinned -> H2D -> kernels -> D2H -> numpy (c3_predict_submit / _wait)"}
-        # the supplementary host legs run >= 100 (B = 256 / 1024) and >= 25 (B = 1000) steps whatever --steps says: a ring of four
+        # the supplementary host legs run >= 100 (B = 256 / 1024) and >= 25 (B = 1000) steps whatever --steps says: a ring of three
         # batches needs more than the driver's 20 steps before filling and draining it stop showing (0.875 against 0.955)
         hsteps = max(args.steps, 100)
         el, y = host_leg(model, x_host, hsteps, args.warmup)
