@@ -336,7 +336,13 @@ int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *ro
 
 int c3_host_register(void *p, size_t bytes) {
     if (!p || !bytes) return fail("null buffer");
-    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    // the device only ever READS a registered source.  Saying so matters for read-only, file-backed mappings (a memory-mapped
+    // tensor file): registered with the default flags their first transfer faults the pages in at 11 GB/s, read-only it runs
+    // at 56 GB/s (tests/diag/register_mmap_probe.py).  Runtimes that do not know the flag get the default registration.
+    if (hipHostRegister(p, bytes, hipHostRegisterReadOnly) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    }
     std::lock_guard<std::mutex> lk(g_registered_mu);
     g_registered.push_back({(const char *)p, bytes});
     return 0;

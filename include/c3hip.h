@@ -119,7 +119,9 @@ int c3_predict_wait(c3_model *m, int slot);
  * tensor file, or libclair3's fa_data.matrix buffer (preprocess/CreateTensorFullAlignmentFromCffi.py:136-168) -- so that
  * c3_predict / c3_predict_submit on any sub-range of it DMA straight from the caller's pages instead of staging through the
  * library's pinned buffer.  A registered source must stay unmodified until the matching c3_predict_wait returns (an
- * unregistered one may be reused as soon as submit returns).  Unregister before freeing the memory. */
+ * unregistered one may be reused as soon as submit returns).  Unregister before freeing the memory.  The range may be a
+ * read-only, file-backed mapping (a memory-mapped tensor file: the DMA engine then reads the page cache); the device never writes
+ * to a registered range. */
 int c3_host_register(void *host_ptr, size_t bytes);
 int c3_host_unregister(void *host_ptr);
 /* device-resident forward: x_dev / y_dev are device pointers on the model's device, stream is a
