@@ -1,3 +1,5 @@
+#!/bin/bash
+# device-resident rate (one batch in flight) and per-kernel HIP-event averages over batch sizes: bash tools/batch_sweep.sh
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 for cfg in "pileup 1000" "pileup 2000" "pileup 4000" "pileup 8000" "pileup 16000" "full_alignment 256" "full_alignment 1000" "full_alignment 2000"; do set -- $cfg
   timeout 300 python bench.py --gpus 1 --workload $1 --batch $2 --streams 1 --no-host-leg --no-cpu-baseline --no-reference-gpu --steps 30 --warmup 3 --repeats 3 2>/dev/null | python -c "
