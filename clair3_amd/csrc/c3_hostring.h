@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256) void host_copy_kernel(const uint4 *__restrict_
     if (flag_dst && blockIdx.x == 0 && threadIdx.x == 0) *flag_dst = *flag_src;
 }
 
+// workgroups of the copy kernel that writes the rows into the pinned result buffer: 32 for a batch (96 KB), up to 256 for a group
+// of 2000 full-alignment rows with decoder columns (968 KB): more stores in flight across PCIe
+static unsigned rows_out_grid(size_t bytes) { return (unsigned)std::min<size_t>(256, std::max<size_t>(32, bytes / 4096)); }
+
 // stage [src, src + bytes) through `pin` into `dev` on stream s, piecewise
 static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s, bool src_locked = false) {
     if (src_locked || is_registered(src, bytes)) {  // zero-copy: the DMA engine reads the caller's pages
@@ -112,7 +116,7 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
         HIP_TRY(hipGetLastError());
         const bool f16 = m->f16_ok;
         TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
-        hipLaunchKernelGGL(host_copy_kernel, dim3(32), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
+        hipLaunchKernelGGL(host_copy_kernel, dim3(rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
                            (const uint32_t *)m->range_flag, sl.pin_flag);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
@@ -129,7 +133,7 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
         // the rows (96 - 484 B per window) and the range flag leave through a copy kernel on the COMPUTE stream, whatever the
         // batch: handing them to a transfer stream (event, cross-queue wait, two DMA copies, event) cost the compute queue
         // ~75 us per batch -- 538 k -> 647 k windows/s host to host at B = 256 (profiles/r03_e_d2h_by_kernel.txt)
-        hipLaunchKernelGGL(host_copy_kernel, dim3(32), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
+        hipLaunchKernelGGL(host_copy_kernel, dim3(rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
                            (const uint32_t *)m->range_flag, sl.pin_flag);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
