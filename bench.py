@@ -278,7 +278,7 @@ def run_workload(name, args, rank, world, local):
             from clair3_amd import predict as c3predict, worker as c3worker
             import shutil
             per_file = 10000 if kind == syn.PILEUP else 4000  # <= 10 000 windows per file (preprocess/SelectCandidates.py:379)
-            n_files = 20 if kind == syn.PILEUP else 6  # a fixed job (200 000 / 24 000 windows): long enough that pipeline fill and drain do not dominate
+            n_files = 40 if kind == syn.PILEUP else 6  # a fixed job (400 000 / 24 000 windows): long enough that pipeline fill and drain do not dominate
             tdir = tempfile.mkdtemp(prefix="c3_bench_files_")
             try:
                 names = []
