@@ -67,10 +67,19 @@ def test_pipeline_keeps_order_and_overlaps(tmp_path):
     y = np.concatenate(rows)
     assert np.array_equal(y, oracle.pileup_forward(sd, np.concatenate(xs), n_threads=1))
     assert pos[7] == "chr20:1000:" + "ACGT" * 8 + "A"
-    # a ring of three slots: batches i+1 and i+2 are submitted before batch i is waited for
+    # one handle: the transport of the drop-in loop -- the batches of a file travel in one forward pass (these files are smaller
+    # than a group), two files ahead: three submits before the first wait, one per file
     kinds = [e[0] for e in m.log]
     assert kinds[:4] == ["submit", "submit", "submit", "wait"] and kinds[-1] == "wait"
-    assert [e[1] for e in m.log if e[0] == "submit"][:5] == [0, 1, 2, 0, 1]
+    assert [e[1] for e in m.log if e[0] == "submit"] == [0, 1, 2]
+    # the ring itself (what a list of handles gets): one forward pass per batch, batches i+1 and i+2 submitted before batch i is
+    # waited for, slots reused in turn -- and the same rows
+    m2, rows2 = OracleModel(sd), []
+    assert worker.predict_batches(m2, worker.iter_batches(lst, 4), lambda p, a, y: rows2.append(y)) == 19
+    kinds = [e[0] for e in m2.log]
+    assert kinds[:4] == ["submit", "submit", "submit", "wait"] and kinds[-1] == "wait"
+    assert [e[1] for e in m2.log if e[0] == "submit"][:5] == [0, 1, 2, 0, 1]
+    assert np.array_equal(np.concatenate(rows2), y)
 
 
 def test_info_rows_must_match(tmp_path):
