@@ -201,10 +201,13 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
     if (xbytes >= ((size_t)4 << 20) && !is_registered(x_host, xbytes)) {
         const uintptr_t lo = (uintptr_t)x_host & ~(uintptr_t)4095, hi = ((uintptr_t)x_host + xbytes + 4095) & ~(uintptr_t)4095;
         (void)hipSetDevice(m->device);
-        if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+        // read-only first: the device only reads the windows, and a read-only registration is the cheaper one (c3_host_register)
+        if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterReadOnly) == hipSuccess) {
             reg_base = (void *)lo;
         } else {
-            (void)hipGetLastError();  // not fatal: staged copy
+            (void)hipGetLastError();
+            if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) reg_base = (void *)lo;
+            else (void)hipGetLastError();  // not fatal: staged copy
         }
     }
     int64_t n_sub = 0, n_done = 0;  // chunks submitted / waited for
