@@ -183,8 +183,8 @@ def predict_batches(model, batches, consume, slots=3):
     (c3_predict_submit / c3_predict_wait, at most C3_HOST_SLOTS = 4) and call ``consume(positions, alt_infos, Y)`` for
     every batch, in order.  ``model`` needs ``submit(X, slot)`` / ``wait(ticket)`` (clair3_amd.model._HipModel).  Returns the
     number of windows processed.  Three slots keep the staging copy, the H2D transfer, the kernels and the D2H transfer of
-    consecutive batches overlapped: 0.97 of the device-resident rate at the reference's batch of 1000 (bench.py
-    host_inclusive).
+    consecutive batches overlapped: 0.93 - 0.975 of the device-resident rate at the reference's batch of 1000 (bench.py
+    host_inclusive.batch_1000).
 
     ``model`` may also be a list of handles loaded with the same weights: batch i then runs on handle i % len (own
     workspace and HIP streams each), so the kernels of consecutive batches overlap on the GPU as well."""
