@@ -262,15 +262,29 @@ def run_workload(name, args, rank, world, local):
                                 "frac_of_device_resident": el_dev / el}
             # the reference loop's own call: ONE blocking _torch_predict per batch (predict._hip_predict -> c3_predict, which cuts
             # the batch into chunks that travel through the ring)
+            # as the drop-in's loader sets the worker's model up (predict._load_torch_checkpoint): the call may page-lock its
+            # windows while it runs.  On a COPY of the batch that PyTorch has never copied from -- a process that registers
+            # sub-ranges of a host array AND lets PyTorch copy from it faults the GPU sooner or later on ROCm 7.2
+            # (tests/diag/register_vs_torch_probe.py), and xb went to the device through torch above
+            xs = np.array(xb, copy=True)
+            model.lock_sources(True)
             for _ in range(3):
-                y = model.predict_numpy(xb)
+                y = model.predict_numpy(xs)
             t0 = time.perf_counter()
             for _ in range(k):
-                y = model.predict_numpy(xb)
+                y = model.predict_numpy(xs)
             el_sync = time.perf_counter() - t0
+            model.lock_sources(False)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                y = model.predict_numpy(xs)
+            el_sync_staged = time.perf_counter() - t0
             hl["batch_1000"]["sync_call"] = {"value": bref * k / el_sync, "ms_per_call": 1e3 * el_sync / k,
                                              "frac_of_device_resident": el_dev / el_sync,
-                                             "path": "model.predict_numpy = _hip_predict = c3_predict: one blocking call per batch"}
+                                             "windows_not_page_locked": {"value": bref * k / el_sync_staged,
+                                                                         "note": "c3_predict's default: every piece through the staging buffer"},
+                                             "path": "_hip_predict on the worker's model = c3_predict with c3_model_set_lock_sources: one blocking call per batch"}
+            del xs
             # what the UNMODIFIED reference loop gets after callvar.install(): its batch generator rebound to
             # worker.lookahead_batches over the tensor FILES of stage A (memory-mapped .npy + .info, batches of 1000 that never
             # span files; consecutive batches of a file travel in one forward pass, two groups in flight beyond the one being

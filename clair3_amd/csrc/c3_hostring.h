@@ -193,12 +193,13 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
     constexpr int kRing = 3;
     const int64_t wbytes = c3_model_window_bytes(m, x_dtype);
     // A blocking call cannot hide its staging copy behind a previous batch, and that copy (pageable -> pinned, ~16 GB/s with the
-    // staging pool) is as long as the kernels of a full-alignment batch.  So the caller's pages are page-locked for the duration of
-    // the call (~0.1 ms per 24 MB, hipHostRegister) and the DMA engine reads them directly; if the range cannot be registered
-    // (e.g. a read-only mapping) the chunks go through the staging buffer as before.
+    // staging pool) is as long as the kernels of a full-alignment batch.  Where the caller allows it (c3_model_set_lock_sources:
+    // see the header for why it is not the default) its pages are page-locked for the duration of the call (~0.1 ms per 24 MB,
+    // hipHostRegister) and the DMA engine reads them directly; otherwise, or if the range cannot be registered, the pieces go
+    // through the staging buffer.
     const size_t xbytes = (size_t)(batch * wbytes);
     void *reg_base = nullptr;
-    if (xbytes >= ((size_t)4 << 20) && !is_registered(x_host, xbytes)) {
+    if (m->lock_sources && xbytes >= ((size_t)4 << 20) && !is_registered(x_host, xbytes)) {
         const uintptr_t lo = (uintptr_t)x_host & ~(uintptr_t)4095, hi = ((uintptr_t)x_host + xbytes + 4095) & ~(uintptr_t)4095;
         (void)hipSetDevice(m->device);
         // read-only first: the device only reads the windows, and a read-only registration is the cheaper one (c3_host_register)

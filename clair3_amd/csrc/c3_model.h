@@ -160,6 +160,7 @@ struct c3_model {
     int sharing = 1;          // handles the CALLER says feed this GPU side by side (c3_model_set_sharing): beside other batches the chip is
                               // full, so the recurrences stay on full tiles and the projection launches half as many, twice as long workgroups
     int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
+    bool lock_sources = false;  // c3_model_set_lock_sources: c3_predict may page-lock the caller's windows for the duration of a call
     int wg_slots = 512;       // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
 
     void *decode_dev = nullptr;  // scratch of c3_outcome_maxima

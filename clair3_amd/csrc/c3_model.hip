@@ -230,6 +230,12 @@ int c3_model_set_sharing(c3_model *m, int handles) {
     return 0;
 }
 
+int c3_model_set_lock_sources(c3_model *m, int on) {
+    if (!m) return fail("null model");
+    m->lock_sources = on != 0;
+    return 0;
+}
+
 int c3_model_describe(c3_model *m, char *buf, int n) {
     if (!m || !buf || n <= 0) return fail("null argument");
     if (m->kind == C3_KIND_PILEUP)

@@ -21,6 +21,10 @@ def _load_torch_checkpoint(model, checkpoint_path, device=None):
     else:
         state_dict = checkpoint
     model.load_state_dict(state_dict)
+    if hasattr(model, "lock_sources"):
+        # the worker's model: its windows come from np.load / the tensor generators and never meet PyTorch, so the blocking call
+        # may page-lock them for its duration (include/c3hip.h c3_model_set_lock_sources)
+        model.lock_sources(True)
     _register_current(model)
 
 
