@@ -193,8 +193,8 @@ int c3_stream_wait(void *stream, int device, int timeout_ms);
  * sharing: 16-window tiles and 120 workgroups, because the other batches fill the rest).  Rows are bit-identical either way. */
 int c3_model_set_sharing(c3_model *m, int handles);
 /* May the blocking c3_predict page-lock the CALLER's windows for the duration of a call (hipHostRegister around a batch of
- * >= 4 MB that is cut into pieces: the DMA engine then reads the caller's pages instead of a staged copy -- 0.84 instead of
- * ~0.7 of the device-resident rate for 1000 full-alignment windows)?  Off by default, because of what the ROCm 7.2 runtime
+ * >= 4 MB that is cut into pieces: the DMA engine then reads the caller's pages instead of a staged copy -- 0.88 instead of
+ * 0.86 of the device-resident rate for 1000 full-alignment windows, and no host core busy copying)?  Off by default, because of what the ROCm 7.2 runtime
  * does and not of anything in this library: a process that ALSO lets PyTorch copy from the same host array
  * (torch.from_numpy(x).cuda()) and registers / unregisters sub-ranges of it gets "Memory access fault by GPU" sooner or
  * later (tests/diag/register_vs_torch_probe.py reproduces it with hipHostRegister and torch alone).  The reference's worker
