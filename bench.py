@@ -624,6 +624,112 @@ def cpu_baseline(name, budget_s, batch, gpu_rows):
     return out, conc
 
 
+def _r(v, nd=4):
+    """numbers of the short line: enough digits to recompute, not fifteen"""
+    if isinstance(v, float):
+        return float(f"{v:.{nd + 2}g}")
+    return v
+
+
+def short_line(full, names, full_path):
+    """The ONE line on stdout (<= 4 KB).  value, ms_per_step and roofline all come from the SAME leg: one batch in flight on one
+    handle, windows resident in HBM (the bench contract); the SURVEY 8d host-to-host rate stands next to it as host_inclusive.
+    Everything else measured is in `full` (gpurun_out/bench_full.json)."""
+    def roof(r):
+        if not r:
+            return None
+        out = {k: _r(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_util", "traffic", "hbm_frac",
+                                         "avg_launch_us", "launches", "kernel_us_per_step", "step_us_one_batch_in_flight")}
+        out["kernel"] = "Clair3_F 3x3 convolution launches (fa.conv* / fa.res*)" if "convolution" in r.get("kernel", "") else \
+                        "Clair3_P BiLSTM launches (p.lstm* / p.proj*)"
+        tn = r.get("traffic_note") or {}
+        out["hbm_bytes_per_step"] = tn.get("hbm_bytes_per_step_all_kernels")
+        out["algorithmic_bytes_per_step"] = tn.get("algorithmic_bytes_per_step")
+        out["traffic_source"] = tn.get("source")
+        return out
+
+    def cpu(c):
+        if not c:
+            return None
+        out = {"value": _r(c["value"]), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+               "sample": c["sample"].split(";")[0] + "; the reference's modules called as _torch_predict does" if c["kind"] == "reference" else c["sample"].split(";")[0]}
+        if "per_core" in c:
+            out["one_thread"] = _r(c["per_core"]["value"])
+        if "per_core_x_cores" in c:
+            out["one_thread_x_usable_cores"] = {"value": _r(c["per_core_x_cores"]["value"]), "cores": c["per_core_x_cores"]["cores"]}
+        return out
+
+    def host(hl):
+        if not hl:
+            return None
+        out = {"value": _r(hl["value"]), "unit": "candidate-windows/s", "batch": hl["batch"], "slots_in_flight": hl["slots_in_flight"],
+               "frac_of_device_resident": _r(hl["frac_of_device_resident_one_in_flight"])}
+        b = hl.get("batch_1000")
+        if b:
+            out["batch_1000"] = {"ring": _r(b["value"]), "device_resident": _r(b["device_resident_one_in_flight"]),
+                                 "blocking_call": _r(b.get("sync_call", {}).get("value")),
+                                 "dropin_loop": _r(b.get("dropin_loop", {}).get("value"))}
+        return out
+
+    def conc(g):
+        if not g:
+            return None
+        return {"windows": g["windows"], "max_abs_dy": _r(g["max_abs_dy"]), "gt21_differ": g["gt21"]["differ"],
+                "zygosity_differ": g["zygosity"]["differ"],
+                "differ_outside_near_ties": g["gt21"]["differ_outside_near_ties_1e-5"] + g["zygosity"]["differ_outside_near_ties_1e-5"]}
+
+    def sub(r, S):
+        o = {"value": _r(r["one_batch_in_flight"]["value"]), "ms_per_step": _r(r["one_batch_in_flight"]["ms_per_step"]),
+             "batch_per_gpu": r["config"]["batch_per_gpu"], "batches_in_flight": 1,
+             "value_stats": {k: _r(v) for k, v in r["one_batch_in_flight"].items() if k in ("median", "min", "max", "repeats")}}
+        k = next((k for k in r if k.endswith("_batches_in_flight") and k != "one_batch_in_flight"), None)
+        if k:
+            o[k] = _r(r[k]["value"])
+        if r.get("roofline"):
+            o["roofline"] = roof(r["roofline"])
+        if r.get("host_inclusive"):
+            o["host_inclusive"] = host(r["host_inclusive"])
+        if r.get("cpu_baseline"):
+            o["cpu_baseline"] = cpu(r["cpu_baseline"])
+        if r.get("gt_concordance"):
+            o["gt_concordance"] = conc(r["gt_concordance"])
+        rg = (r.get("reference_on_this_gpu") or {}).get("batch_1000")
+        if rg:
+            o["reference_modules_on_this_gpu_batch_1000"] = _r(rg["value"])
+        if r.get("multi_gpu"):
+            mg = r["multi_gpu"]
+            o["multi_gpu"] = {k: mg.get(k) for k in ("gather", "rccl_ranks_seen", "fallback_reason", "ranks")}
+            o["multi_gpu"]["per_rank_windows_per_s"] = [_r(v) for v in (mg.get("per_rank_windows_per_s") or [])]
+        o["range_flag_raised"] = r["range_flag_raised"]
+        o["on_fp32_fallback"] = r["on_fp32_fallback"]
+        return o
+
+    head = sub(full, 0)
+    line = {"metric": full["metric"], "value": head.pop("value"), "unit": full["unit"], "n_gpus": full["n_gpus"], "steps": full["steps"],
+            "warmup": full["warmup"], "ms_per_step": head.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": full["dtype"], "data": "synthetic",
+            "config": {"workload": full["config"]["workload"], "batch_per_gpu": full["config"]["batch_per_gpu"],
+                       "windows_per_step": full["config"]["windows_per_step"], "batches_in_flight": 1,
+                       "inputs": "resident in HBM; host_inclusive = pageable host windows in, rows in host memory out"}}
+    head.pop("batch_per_gpu"), head.pop("batches_in_flight")
+    line.update(head)
+    for n in names[1:]:  # the other workloads: the same leg, their numbers only
+        if n in full:
+            o = sub(full[n], 0)
+            c = {"value": o["value"], "ms_per_step": o["ms_per_step"], "batch_per_gpu": o["batch_per_gpu"], "batches_in_flight": 1}
+            if o.get("roofline"):
+                c["roofline"] = {k: o["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_util", "hbm_bytes_per_step")}
+            if o.get("host_inclusive"):
+                c["host_inclusive"] = o["host_inclusive"]["value"]
+            if o.get("cpu_baseline"):
+                c["cpu_baseline"] = {k: o["cpu_baseline"][k] for k in ("value", "cores", "kind")}
+            if o.get("gt_concordance"):
+                c["gt_concordance"] = o["gt_concordance"]
+            line[n] = c
+    line["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -691,20 +797,30 @@ def main():
             return sub
 
         h = sub_line(names[0], head, args.cpu_budget)
-        line = {
-            "metric": "candidate-windows/sec", "value": h["value"], "unit": "candidate-windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats, "ms_per_step": h["ms_per_step"],
+        full = {
+            "metric": "candidate-windows/sec", "value": h["one_batch_in_flight"]["value"], "unit": "candidate-windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
+            "ms_per_step": h["one_batch_in_flight"]["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32(fp16x3)", "data": "synthetic",
             "dtype_note": "fp32 storage, accumulation and results; every fp32 product formed from two fp16 pieces per operand (three 16-bit MFMA products, DESIGN.md 1)",
             "config": {"workload": head["workload"], "batch_per_gpu": head["batch_per_gpu"],
                        "windows_per_step": head["windows_per_step"], "weights": "seeded random (no checkpoints offline)",
                        "sharding": f"windows x{world}, rows gathered to rank 0 every {GATHER_EVERY} steps (one gather: {head.get('multi_gpu', {}).get('gather')})" if world > 1 else "single GPU",
-                       "inputs": "resident in HBM before the timed region (host-to-host rate: host_inclusive)", "batches_in_flight": head["batches_in_flight"]},
+                       "inputs": "resident in HBM before the timed region (host-to-host rate: host_inclusive)", "batches_in_flight": 1},
             **{k: v for k, v in h.items() if k not in ("value", "unit", "ms_per_step", "config", "batches_in_flight")},
         }
         for n in names[1:]:
-            line[n] = sub_line(n, results[n], args.cpu_budget / 2 if n == "pileup" else 0)
-        print(json.dumps(line), flush=True)
+            full[n] = sub_line(n, results[n], args.cpu_budget / 2 if n == "pileup" else 0)
+        # everything measured goes to a file; stdout carries ONE short line the driver can parse (round 3's 21 KB line could not be)
+        full_path = os.environ.get("C3_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            with open(full_path, "w") as fh:
+                json.dump(full, fh, indent=1)
+        except OSError as e:
+            print(f"[bench] could not write {full_path}: {e!r}", file=sys.stderr)
+            full_path = None
+        print(json.dumps(short_line(full, names, full_path)), flush=True)
 
     if world > 1:
         import torch.distributed as dist

@@ -42,8 +42,14 @@ struct RcclApi {
     bool load() {
         if (handle) return true;
         const char *names[] = {getenv("C3HIP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
-        // first: a copy that is already in the process (PyTorch's), then the system one
         const char *why = nullptr;
+        // an explicit C3HIP_RCCL_LIB wins over any copy already in the process (RTLD_LOCAL: its ncclSend must not interpose
+        // PyTorch's) -- a site-specific build, or the two-ranks-on-one-GPU stand-in of tests/stubs/fake_rccl.cpp
+        if (names[0] && *names[0]) {
+            handle = dlopen(names[0], RTLD_NOW | RTLD_LOCAL);
+            if (!handle) why = dlerror();
+        }
+        // otherwise first a copy that is already in the process (PyTorch's), then the system one
         for (int pass = 0; pass < 2 && !handle; ++pass)
             for (const char *n : names) {
                 if (!n) continue;
@@ -211,7 +217,7 @@ int c3_comm_abort(c3_comm *c) {
         RcclApi &r = RcclApi::get();
         const ncclResult_t rc = r.CommAbort(c->nccl);
         c->nccl = nullptr;
-        c->world = 1;  // whatever is asked of this handle from now on is local
+        c->world = 1, c->rank = 0;  // whatever is asked of this handle from now on is local: a world of one, whose only rank is 0
         if (rc != ncclSuccess) return fail("ncclCommAbort failed: %s", r.GetErrorString(rc));
     }
     return 0;

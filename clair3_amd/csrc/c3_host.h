@@ -5,8 +5,10 @@
 // 265-269 -> 1000 x 89 x 33 x 8 int8), i.e. 2-3 ms of memcpy against ~1.3 ms of kernels and ~0.5 ms of PCIe Gen5 DMA:
 // the staging copy, not the GPU, bounded the host-inclusive rate of round 1.  The pool splits every
 // staged piece over three helpers plus the calling thread.  Threads are created lazily on the
-// first staged copy -- after the reference worker has forked its decode pool (CallVariantsFromCffi.py:246 vs :302), so
-// no thread is ever lost to a fork.
+// first staged copy.  With the rebound batch generator (callvar.install) that is the generator's first next(), i.e. BEFORE the
+// loop's first executor.submit makes the ProcessPoolExecutor fork its decode workers (CallVariantsFromCffi.py:246 vs :302-353):
+// the children inherit none of these threads (fork copies the calling thread only) and only ever run numpy / Python, and the
+// pool's mutexes are never held across the loop's submit calls, so nothing a child touches is left locked.
 #pragma once
 #include <atomic>
 #include <condition_variable>

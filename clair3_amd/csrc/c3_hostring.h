@@ -36,6 +36,12 @@ __global__ __launch_bounds__(256) void host_copy_kernel(const uint4 *__restrict_
     if (flag_dst && blockIdx.x == 0 && threadIdx.x == 0) *flag_dst = *flag_src;
 }
 
+// one thread per output float: raises the handle's range flag when a probability is not finite
+__global__ void rows_finite_kernel(const float *y, int64_t n, uint32_t *flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && (__float_as_uint(y[i]) & 0x7f800000u) == 0x7f800000u) atomicOr(flag, 2u);
+}
+
 // workgroups of the copy kernel that writes the rows into the pinned result buffer: 32 for a batch (96 KB), up to 256 for a group
 // of 2000 full-alignment rows with decoder columns (968 KB): more stores in flight across PCIe
 static unsigned rows_out_grid(size_t bytes) { return (unsigned)std::min<size_t>(256, std::max<size_t>(32, bytes / 4096)); }
@@ -59,6 +65,9 @@ static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStr
 extern "C" {
 
 static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
+    // host_copy_kernel moves whole 16-byte pieces ((bytes + 15) / 16 of them): every buffer it touches is sized to a multiple of
+    // 256 bytes here, for every path (90-column rows of an odd batch, 121-float decoder rows: yb % 16 != 0)
+    xb = (xb + 255) & ~(size_t)255, yb = (yb + 255) & ~(size_t)255;
     if (!sl.ev_h2d) {
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
@@ -84,17 +93,25 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     return 0;
 }
 
-static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked);
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked,
+                          float *y_dev_out = nullptr);
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
     return predict_submit(m, x_host, x_dtype, batch, y_host, slot, false);
 }
+// the ring with the rows LEFT ON THE DEVICE (a rank of a sharded job: its rows go to the RCCL gather, not to this host): the
+// forward pass writes them straight into the caller's device buffer, only the range flag crosses PCIe
+int c3_predict_submit_dev(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_dev, int slot) {
+    if (batch > 0 && !y_dev) return fail("null device buffer");
+    return predict_submit(m, x_host, x_dtype, batch, nullptr, slot, false, y_dev);
+}
 // src_locked: the caller (c3_predict) has page-locked x_host for the duration of ITS call -- a private fact of that call, not
 // published in g_registered, so no other thread or handle ever DMAs from pages that are about to be unlocked
-static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked) {
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked,
+                          float *y_dev_out) {
     if (!m) return fail("null model");
     if (slot < 0 || slot >= kHostSlots) return fail("slot must be in [0, %d)", kHostSlots);
     if (batch < 0) return fail("negative batch");
-    if (batch > 0 && (!x_host || !y_host)) return fail("null buffer");
+    if (batch > 0 && (!x_host || (!y_host && !y_dev_out))) return fail("null buffer");
     HostSlot &sl = m->slot[slot];
     if (sl.busy) return fail("slot %d still in flight: call c3_predict_wait first", slot);
     HIP_TRY(hipSetDevice(m->device));
@@ -115,9 +132,11 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
                            (const uint32_t *)nullptr, (uint32_t *)nullptr);
         HIP_TRY(hipGetLastError());
         const bool f16 = m->f16_ok;
-        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
-        hipLaunchKernelGGL(host_copy_kernel, dim3(rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
-                           (const uint32_t *)m->range_flag, sl.pin_flag);
+        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, y_dev_out ? y_dev_out : sl.dev_y));
+        if (y_dev_out && f16)
+            hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((batch * m->row + 255) / 256)), dim3(256), 0, m->stream, y_dev_out, batch * m->row, m->range_flag);
+        hipLaunchKernelGGL(host_copy_kernel, dim3(y_dev_out ? 1 : rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y,
+                           y_dev_out ? 0 : (yb + 15) / 16, (const uint32_t *)m->range_flag, sl.pin_flag);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
         sl.used_f16 = f16;
@@ -129,16 +148,19 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
         HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
         const bool f16 = m->f16_ok;
-        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, sl.dev_y));
+        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, y_dev_out ? y_dev_out : sl.dev_y));
+        if (y_dev_out && f16)  // rows that stay on the device are scanned there (bit 1 of the flag: a non-finite row)
+            hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((batch * m->row + 255) / 256)), dim3(256), 0, m->stream, y_dev_out, batch * m->row, m->range_flag);
         // the rows (96 - 484 B per window) and the range flag leave through a copy kernel on the COMPUTE stream, whatever the
         // batch: handing them to a transfer stream (event, cross-queue wait, two DMA copies, event) cost the compute queue
         // ~75 us per batch -- 538 k -> 647 k windows/s host to host at B = 256 (profiles/r03_e_d2h_by_kernel.txt)
-        hipLaunchKernelGGL(host_copy_kernel, dim3(rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y, (yb + 15) / 16,
-                           (const uint32_t *)m->range_flag, sl.pin_flag);
+        hipLaunchKernelGGL(host_copy_kernel, dim3(y_dev_out ? 1 : rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y,
+                           y_dev_out ? 0 : (yb + 15) / 16, (const uint32_t *)m->range_flag, sl.pin_flag);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
         sl.used_f16 = f16;
     }
+    sl.y_dev_out = y_dev_out;
     sl.y_host = y_host, sl.y_bytes = yb, sl.batch = batch, sl.x_dtype = x_dtype, sl.busy = true;
     return 0;
 }
@@ -151,6 +173,16 @@ int c3_predict_wait(c3_model *m, int slot) {
     sl.busy = false;
     if (sl.y_bytes == 0) return 0;
     HIP_TRY(hipEventSynchronize(sl.ev_out));
+    if (sl.y_dev_out) {  // rows stayed on the device: the flag (range bit + the device-side scan for non-finite rows) is all there is to read
+        if (sl.used_f16 && *sl.pin_flag != 0) {
+            if (m->f16_ok)
+                fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
+            m->f16_ok = false;
+            TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.y_dev_out));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+        return 0;
+    }
     if (sl.used_f16) {
         // Safety net of the fp16x3 products, per batch: what matters is how THIS slot's rows were computed, not what the
         // handle does now (another slot's wait may have switched it to fp32 while this batch was in flight).  An

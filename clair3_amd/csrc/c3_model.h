@@ -98,6 +98,7 @@ struct HostSlot {
     size_t cap_x = 0, cap_y = 0;
     hipEvent_t ev_h2d = nullptr, ev_out = nullptr;
     float *y_host = nullptr;
+    float *y_dev_out = nullptr;  // c3_predict_submit_dev: the rows stay in the caller's device buffer
     size_t y_bytes = 0;
     int64_t batch = 0;  // what is in flight (for the fp32 re-run of c3_predict_wait)
     uint32_t *pin_flag = nullptr;  // pinned copy of the model's range_flag after this batch

@@ -183,12 +183,6 @@ int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch
     return forward_device(m, (hipStream_t)stream, x_dev, x_dtype, batch, y_dev);
 }
 
-// one thread per output float: raises the handle's range flag when a probability is not finite
-__global__ void rows_finite_kernel(const float *y, int64_t n, uint32_t *flag) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n && (__float_as_uint(y[i]) & 0x7f800000u) == 0x7f800000u) atomicOr(flag, 2u);
-}
-
 int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, void *stream) {
     if (!m) return fail("null model");
     if (batch > 0 && (!x_dev || !y_dev)) return fail("null buffer");

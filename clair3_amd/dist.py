@@ -155,29 +155,47 @@ class RcclComm:
             if unique_id is None:
                 import torch
                 import torch.distributed as dist
+                # rank 0 ALWAYS takes part in the broadcast: if it cannot make an id (no librccl, ncclGetUniqueId failed) it sends
+                # 128 zero bytes, which every rank -- itself included -- reads as "no direct path"; raising before the broadcast
+                # would leave the other ranks inside it while this one moves on to the next collective
                 t = torch.zeros(128, dtype=torch.uint8)
+                id_error = None
                 if self.rank == 0:
-                    _lib.check(_lib.lib().c3_comm_unique_id(idbuf), "c3_comm_unique_id")
-                    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+                    try:
+                        _lib.check(_lib.lib().c3_comm_unique_id(idbuf), "c3_comm_unique_id")
+                        t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+                    except Exception as e:
+                        id_error = e
                 if dist.get_backend() == "nccl":
                     t = t.cuda(self.device)
                 dist.broadcast(t, src=0)
                 unique_id = bytes(t.cpu().numpy().tobytes())
+                if not any(unique_id):
+                    raise _lib.C3Error(f"rank 0 could not create an RCCL unique id{': ' + repr(id_error) if id_error else ''}")
             idbuf.raw = unique_id
-        box = {}
+        import threading
+        box, lock = {}, threading.Lock()
 
         def create():
-            box["h"] = _lib.lib().c3_comm_create(idbuf, self.rank, self.world, self.device)
-            box["err"] = _lib.last_error() if not box["h"] else ""  # thread-local: read it on the thread that failed
+            h = _lib.lib().c3_comm_create(idbuf, self.rank, self.world, self.device)
+            err = _lib.last_error() if not h else ""  # thread-local: read it on the thread that failed
+            with lock:
+                if box.get("abandoned"):  # the caller gave up waiting: nobody will ever use or close this communicator
+                    if h:
+                        _lib.lib().c3_comm_destroy(C.c_void_p(h))
+                    return
+                box["h"], box["err"] = h, err
 
         if create_timeout_s is None or self.world == 1:
             create()
         else:
-            import threading
             th = threading.Thread(target=create, daemon=True)
             th.start()
             th.join(create_timeout_s)
-            if th.is_alive():
+            with lock:
+                if "h" not in box:
+                    box["abandoned"] = True
+            if box.get("abandoned"):
                 raise TimeoutError(f"ncclCommInitRank did not return within {create_timeout_s} s")
         if not box.get("h"):
             raise _lib.C3Error(f"c3_comm_create: {box.get('err')}")

@@ -4,8 +4,9 @@ The reference cuts its candidates into tensor files of at most 10 000 windows (p
 list of files (``--output_tensor_can_fn_list``), and splits that LIST over GPU slots -- file i goes to slot i % n_slots, each slot
 writes its own VCF shard, SortVcf merges them (clair3/CallVariantsFromCffiGPU.py:138-156,163-199).  Here:
 
-  * the file list is split into CONTIGUOUS runs of files, balanced by window count (``shard_files``), one run per rank, so the
-    concatenation of the ranks' rows in rank order IS the reference's window order -- no sort step;
+  * the file list is split into CONTIGUOUS runs of files, balanced by window count (``shard_files``), one run per rank -- or,
+    when there are fewer than four files per rank, into contiguous WINDOW ranges that may cut a file (``shard_segments``) -- so
+    the concatenation of the ranks' rows in rank order IS the reference's window order -- no sort step;
   * every rank drives its GPU with ``worker.predict_batches`` (memory-mapped files, the reference's batch boundaries, a ring of
     submit/wait slots);
   * the (n_r, 24|90) rows meet on rank 0 in one gather (``dist.RowExchange``): on RCCL directly (``c3_gather_rows``) on a GPU
@@ -75,18 +76,72 @@ def shard_files(counts, world):
     return cuts
 
 
+def shard_segments(counts, world, min_files_per_rank=4):
+    """The work of every rank as a list of (file index, first window, stop window) segments, in job order.  With plenty of
+    files (>= ``min_files_per_rank`` x world) ranks own whole files (``shard_files``: the reference's unit of work, no file is
+    opened twice); with fewer the job is cut into CONTIGUOUS WINDOW RANGES (``dist.shard_range`` over the job's windows, SURVEY
+    8e), so two files on eight GPUs still fill eight GPUs.  Either way the ranks' rows concatenated in rank order are the
+    job's windows in order."""
+    n_files = len(counts)
+    if n_files >= min_files_per_rank * world:
+        cuts = shard_files(counts, world)
+        return [[(f, 0, int(counts[f])) for f in range(cuts[r], cuts[r + 1]) if counts[f]] for r in range(world)]
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    out = []
+    for r in range(world):
+        lo, hi = c3dist.shard_range(int(starts[-1]), r, world)
+        segs = []
+        for f in range(n_files):
+            a, b = max(lo, int(starts[f])), min(hi, int(starts[f + 1]))
+            if a < b:
+                segs.append((f, a - int(starts[f]), b - int(starts[f])))
+        out.append(segs)
+    return out
+
+
+def _segment_files(list_fn, names, segments):
+    """(tensor, positions, alt_infos) per segment: memory-mapped slices, the shape worker.lookahead_batches walks"""
+    parent = os.path.dirname(list_fn)
+    for f, lo, hi in segments:
+        tensor, positions, alt_infos = worker._load_tensor_file(parent, names[f])
+        yield tensor[lo:hi], positions[lo:hi], alt_infos[lo:hi]
+
+
+def _rows_to_device(model, files, rows_dev, positions):
+    """A rank whose rows are wanted ELSEWHERE (the gather): windows through the submit ring in groups of consecutive batches,
+    rows written by the forward pass straight into ``rows_dev`` (a (n_local, W) float32 CUDA tensor) -- they never visit
+    this host (c3_predict_submit_dev)."""
+    from collections import deque
+    group = max(1, worker.group_windows_for(model))
+    width = rows_dev.shape[1]
+    pending, off, i = deque(), 0, 0
+    for tensor, pos, _ in files:
+        positions.extend(pos)
+        for g0 in range(0, len(tensor), group):
+            x = np.ascontiguousarray(tensor[g0:g0 + group])
+            if len(pending) == 3:
+                model.wait(pending.popleft())
+            pending.append(model.submit_dev(x, rows_dev.data_ptr() + off * width * 4, slot=i % 3))
+            off += len(x)
+            i += 1
+    while pending:
+        model.wait(pending.popleft())
+    return off
+
+
 def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume=None, exchange=None):
     """Every rank calls this with the same list.  Returns on rank 0 a dict with the rows of the whole job in window order
     (numpy), the positions seen, and timings; on other ranks the timings only.
     ``model``: a loaded clair3_amd model (or a list of handles / any object with submit/wait, see worker.predict_batches).
     ``exchange``: a dist.RowExchange (RCCL directly, torch.distributed when that does not come up; made here when None);
     ``comm``: a dist.RcclComm to use as it is (no fallback).
-    The worker ring delivers every batch's rows to the HOST (that is where the decoder runs while the job is in flight), so
-    on a GPU job the rank's rows are uploaded once more for the gather and ``gather_s`` includes that -- 360 B per window."""
+    ``consume(positions, alt_infos, Y)``: a per-batch consumer on THIS rank's host (the decoder beside the job); without one,
+    on a GPU job, the rank's rows stay on its device from the forward pass to the gather (``rows_path`` = "device") and cross
+    PCIe once, on rank 0."""
     names, counts = file_window_counts(list_fn)
-    cuts = shard_files(counts, world)
-    mine = names[cuts[rank]:cuts[rank + 1]]
-    per_rank = [int(sum(counts[cuts[r]:cuts[r + 1]])) for r in range(world)]
+    segments = shard_segments(counts, world)
+    mine = segments[rank]
+    per_rank = [int(sum(hi - lo for _, lo, hi in segs)) for segs in segments]
     rows, positions = [], []
 
     def take(pos, alt, y):
@@ -95,34 +150,63 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
         if consume is not None:
             consume(pos, alt, y)
 
+    m0 = model[0] if isinstance(model, (list, tuple)) else model
+    on_gpu = False
+    if world > 1 or comm is not None:
+        import torch
+    if world > 1:
+        import torch.distributed as dist
+        on_gpu = dist.get_backend() == "nccl"  # then every tensor a collective touches lives on the rank's GPU
+    device = comm.device if comm is not None else (exchange.device if exchange is not None else int(getattr(m0, "_device", 0) or 0))
+    keep_on_device = (on_gpu or comm is not None) and consume is None and hasattr(m0, "submit_dev") and not isinstance(model, (list, tuple))
     t0 = time.perf_counter()
-    n_done = worker.predict_file_list(model, list_fn, take, batch_size=batch_size, first=cuts[rank], stop=cuts[rank + 1]) if mine else 0
+    y_dev = None
+    if keep_on_device:
+        y_dev = torch.empty((per_rank[rank], int(m0.row_size)), dtype=torch.float32, device=f"cuda:{device}")
+        n_done = _rows_to_device(m0, _segment_files(list_fn, names, mine), y_dev, positions)
+    elif not mine:
+        n_done = 0
+    elif isinstance(model, (list, tuple)):
+        batches = ((X[lo:lo + batch_size], p[lo:lo + batch_size], a[lo:lo + batch_size])
+                   for X, p, a in _segment_files(list_fn, names, mine) for lo in range(0, len(X), batch_size))
+        n_done = worker.predict_batches(model, batches, take)
+    else:
+        pending = {}
+        n_done = 0
+        for X, pos, alt in worker.lookahead_batches(model, _segment_files(list_fn, names, mine), batch_size, pending, depth=2,
+                                                    group_windows=worker.group_windows_for(model)):
+            _, group, _, lo, hi = pending.pop(id(X))
+            take(pos, alt, group.take(lo, hi))
+            n_done += len(pos)
     t_compute = time.perf_counter() - t0
-    assert n_done == per_rank[rank]
+    assert n_done == per_rank[rank], (n_done, per_rank, rank)
     y_local = np.concatenate(rows) if rows else None
-    out = {"rank": rank, "windows_local": n_done, "compute_s": t_compute, "files_local": len(mine), "per_rank": per_rank}
+    out = {"rank": rank, "windows_local": n_done, "compute_s": t_compute, "segments_local": len(mine), "per_rank": per_rank,
+           "files_local": len({f for f, _, _ in mine}), "rows_path": "device" if keep_on_device else "host"}
     if world == 1:
+        if y_dev is not None:  # a one-rank job handed a communicator: the rows took the device path, one copy brings them home
+            y_local = y_dev.cpu().numpy()
         out.update(rows=y_local, positions=positions, gather_s=0.0, total_s=time.perf_counter() - t0, gather="single")
         return out
-    import torch
-    import torch.distributed as dist
-    m0 = model[0] if isinstance(model, (list, tuple)) else model
-    on_gpu = dist.get_backend() == "nccl"  # then every tensor a collective touches lives on the rank's GPU
-    device = comm.device if comm is not None else (exchange.device if exchange is not None else int(getattr(m0, "_device", 0) or 0))
-    # the row width follows from the model; a stand-in without row_size (tests) and without rows asks the other ranks
-    width = getattr(m0, "row_size", None) or (rows[0].shape[1] if rows else None)
-    if width is None:
-        w = torch.tensor([0], dtype=torch.int64, device=f"cuda:{device}" if on_gpu else "cpu")
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        width = int(w.item())
-    if y_local is None:
-        y_local = np.zeros((0, int(width)), np.float32)
+    # the row width follows from the model; a stand-in without row_size (tests) asks the other ranks.  EVERY rank takes part,
+    # each with the width it knows (0 if none): a conditional collective deadlocks the ranks that skip it
+    local_width = int(getattr(m0, "row_size", 0) or (rows[0].shape[1] if rows else 0))
+    w = torch.tensor([local_width], dtype=torch.int64, device=f"cuda:{device}" if on_gpu else "cpu")
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    width = int(w.item())
+    if width <= 0:
+        raise RuntimeError("no rank knows the row width (no windows anywhere and a model without row_size)")
     t1 = time.perf_counter()
     if comm is None and exchange is None:
         exchange = c3dist.RowExchange(rank, world, device=device)
-    y_t = torch.from_numpy(y_local)
-    if on_gpu or comm is not None:
-        y_t = y_t.cuda(device)
+    if y_dev is not None:
+        y_t = y_dev
+    else:
+        if y_local is None:
+            y_local = np.zeros((0, width), np.float32)
+        y_t = torch.from_numpy(y_local)
+        if on_gpu or comm is not None:
+            y_t = y_t.cuda(device)
     got = comm.gather(y_t, per_rank, dst=0) if comm is not None else exchange.gather(y_t, per_rank, dst=0)
     if y_t.is_cuda:
         torch.cuda.synchronize(device)

@@ -217,6 +217,19 @@ class _HipModel:
                    "c3_predict_submit")
         return slot, y
 
+    def submit_dev(self, x, y_dev_ptr, slot=0):
+        """submit() with the rows left on the device: the forward pass writes them at device address ``y_dev_ptr``
+        (len(x) * row_size floats; c3_predict_submit_dev) -- what a rank of a sharded job does with rows that go to the gather.
+        wait() on the ticket returns None (it still runs the range guard)."""
+        x = np.ascontiguousarray(x)
+        dt = _NP_DTYPE.get(x.dtype)
+        if dt is None:
+            raise _lib.C3Error(f"unsupported window dtype {x.dtype} (int8 / int32 expected)")
+        self._check_shape(x.shape, dt)
+        _lib.check(_lib.lib().c3_predict_submit_dev(self._handle, x.ctypes.data, dt, x.shape[0], C.c_void_p(int(y_dev_ptr)), slot),
+                   "c3_predict_submit_dev")
+        return slot, None
+
     def wait(self, ticket):
         slot, y = ticket
         _lib.check(_lib.lib().c3_predict_wait(self._handle, slot), "c3_predict_wait")

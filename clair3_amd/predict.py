@@ -23,8 +23,11 @@ def _load_torch_checkpoint(model, checkpoint_path, device=None):
     model.load_state_dict(state_dict)
     if hasattr(model, "lock_sources"):
         # the worker's model: its windows come from np.load / the tensor generators and never meet PyTorch, so the blocking call
-        # may page-lock them for its duration (include/c3hip.h c3_model_set_lock_sources)
-        model.lock_sources(True)
+        # may page-lock them for its duration (include/c3hip.h c3_model_set_lock_sources; ~2 % on the blocking call).  A
+        # process that ALSO lets PyTorch copy from the same host arrays must not (ROCm 7.2 faults the GPU):
+        # C3HIP_LOCK_SOURCES=0 keeps every piece on the staging buffer
+        import os
+        model.lock_sources(os.environ.get("C3HIP_LOCK_SOURCES", "1").strip().lower() not in ("0", "false", "no", "off"))
     _register_current(model)
 
 

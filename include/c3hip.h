@@ -115,6 +115,12 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
  * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);
 int c3_predict_wait(c3_model *m, int slot);
+/* The same ring with the rows LEFT ON THE DEVICE: y_dev is a device pointer on the model's device (batch x c3_model_row_size()
+ * floats) that the forward pass writes directly; nothing but the range flag crosses PCIe on the way out.  For a rank of a
+ * sharded job whose rows go to c3_gather_rows, not to its own host -- the reference's per-GPU workers each write their rows to
+ * disk (clair3/CallVariantsFromCffiGPU.py:138-199); here they meet on rank 0 over xGMI and cross PCIe once, there.
+ * c3_predict_wait(slot) runs the range guard (flag + a device-side scan for non-finite rows) and re-runs on fp32 if needed. */
+int c3_predict_submit_dev(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_dev, int slot);
 /* Optional zero-copy input: page-lock a host range the caller will feed windows from -- a whole np.load'ed
  * tensor file, or libclair3's fa_data.matrix buffer (preprocess/CreateTensorFullAlignmentFromCffi.py:136-168) -- so that
  * c3_predict / c3_predict_submit on any sub-range of it DMA straight from the caller's pages instead of staging through the

@@ -137,7 +137,17 @@ EXCHANGE = textwrap.dedent("""
         def close(self):
             pass
 
-    if scenario != "gloo_job":
+    if scenario == "unique_id_fails_on_rank_0":
+        # the REAL RcclComm: rank 0 cannot make an id (no librccl / ncclGetUniqueId failed).  It must still take part in the
+        # broadcast -- the other ranks are inside it -- and everybody must then agree on the fallback (ADVICE r3: this used
+        # to leave ranks 1.. in dist.broadcast while rank 0 went on to the all-reduce)
+        from clair3_amd import _lib
+        L = _lib.lib()
+        real = L.c3_comm_unique_id
+        L.c3_comm_unique_id = (lambda buf: 1) if rank == 0 else real
+        L.c3_comm_create = lambda *a: (_ for _ in ()).throw(AssertionError("no rank may try to create a communicator"))
+        c3dist.RowExchange._cuda_job = lambda self: True
+    elif scenario != "gloo_job":
         c3dist.RcclComm = FakeComm
         c3dist.RowExchange._cuda_job = lambda self: True
     ex = c3dist.RowExchange(rank, world, device=0, timeout_s=1.0)
@@ -178,3 +188,4 @@ def test_row_exchange_falls_back_together(tmp_path):
     assert _run_exchange(tmp_path, "create_fails_on_rank_1") == (("torch_fallback", 2, True), "torch_fallback")
     assert _run_exchange(tmp_path, "rccl_sees_one_rank") == (("torch_fallback", 1, True), "torch_fallback")
     assert _run_exchange(tmp_path, "first_gather_times_out_on_rank_0") == (("torch_fallback", 2, True), "torch_fallback")
+    assert _run_exchange(tmp_path, "unique_id_fails_on_rank_0") == (("torch_fallback", 1, True), "torch_fallback")

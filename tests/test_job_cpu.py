@@ -86,4 +86,21 @@ def test_two_rank_job_matches_single_process(tmp_path):
     sd = syn.make_state_dict(syn.PILEUP, seed=11)
     x = syn.make_windows(syn.PILEUP, 37, seed=5, channels=18)
     assert np.array_equal(y, oracle.pileup_forward(sd, x, n_threads=1)), "rows of the two-rank job differ or are out of order"
-    assert open(out + ".pos").read() == "[24, 13]"  # files 0-2 to rank 0, 3-4 to rank 1: contiguous runs
+    assert open(out + ".pos").read() == "[19, 18]"  # five files on two ranks: contiguous WINDOW ranges (file 2 is cut at window 3)
+
+
+def test_shard_segments_by_files_or_by_window_ranges():
+    # plenty of files: whole files per rank, exactly shard_files' cuts
+    counts = [10] * 16
+    segs = job.shard_segments(counts, 4)
+    assert [[f for f, _, _ in s] for s in segs] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    assert all(lo == 0 and hi == 10 for s in segs for _, lo, hi in s)
+    # few files: contiguous window ranges, files cut where the range ends
+    for counts, world in (([10000, 10000], 8), ([7, 0, 5, 1], 3), ([3], 4), ([], 2), ([8, 8, 8, 8, 5], 2)):
+        segs = job.shard_segments(counts, world)
+        assert len(segs) == world
+        flat = [(f, w) for s in segs for f, lo, hi in s for w in range(lo, hi)]
+        assert flat == [(f, w) for f, c in enumerate(counts) for w in range(c)]  # complete, in order, nothing twice
+        sizes = [sum(hi - lo for _, lo, hi in s) for s in segs]
+        assert max(sizes) - min(sizes) <= 1
+    assert job.shard_segments([10000, 10000], 8)[3] == [(0, 7500, 10000)]

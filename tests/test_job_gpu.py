@@ -27,6 +27,31 @@ def test_job_rows_match_the_oracle_in_window_order(tmp_path, kind):
     assert [int(p.split(":")[1]) for p in res["positions"]] == list(range(1, n + 1))
 
 
+def test_rows_stay_on_the_device_until_the_gather(tmp_path):
+    """a rank whose rows go to the gather: c3_predict_submit_dev writes them into the gather's send buffer, nothing but the range
+    flag crosses PCIe before the collective (here the one-rank communicator: a device copy) -- same rows as the host ring, and
+    window-range segments cut the two files where the shard ends"""
+    from clair3_amd.model import Clair3_F
+    n = 531
+    lst, counts = job.write_synthetic_job(str(tmp_path), syn.FULL_ALIGNMENT, n, channels=8, per_file=300, unique=n, seed=12)
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=4)
+    m = Clair3_F(add_indel_length=True, predict=True, input_channels=8).to("cuda:0")
+    m.load_state_dict(sd)
+    host = job.run_job(m, lst, batch_size=100)
+    assert host["rows_path"] == "host"
+    comm = c3dist.RcclComm(0, 1, 0)
+    dev = job.run_job(m, lst, batch_size=100, comm=comm)
+    comm.close()
+    assert dev["rows_path"] == "device" and dev["rows"].shape == (n, 90)
+    assert np.array_equal(dev["rows"], host["rows"])
+    assert dev["positions"] == host["positions"]
+    # odd row counts through the padded slot buffers (90- and 121-float rows: bytes % 16 != 0)
+    m.decode_columns(True)
+    y = m.predict_numpy(syn.make_windows(syn.FULL_ALIGNMENT, 3, seed=1, channels=8))
+    assert y.shape == (3, 121) and np.isfinite(y).all()
+    m.decode_columns(False)
+
+
 def test_rccl_communicator_single_rank_gather():
     """world == 1: c3_gather_rows is a device copy on the caller's stream (no RCCL needed); the multi-rank path is the same
     entry with grouped ncclSend / ncclRecv and is exercised by the driver's multi-GPU runs"""

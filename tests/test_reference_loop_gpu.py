@@ -35,6 +35,22 @@ def ref():
     return root
 
 
+def file_window(directory, sizes):
+    """job-wide window index -> (the loop's batch that holds the window, its index in it, reference base): refloop.write_job numbers positions over the whole job and
+    tests/test_decode_dropin.alt_infos puts "ACGT"[j % 4] (j = index within the file) at the window's centre"""
+    import numpy as np
+
+    def get(g, batch=1000):
+        for i, n in enumerate(sizes):
+            if g < n:
+                lo = g // batch * batch  # the loop's batches of 1000 never span files (clair3/CallVariantsFromCffi.py:106-148)
+                xb = np.array(np.load(os.path.join(directory, f"t{i}.npy"), mmap_mode="r")[lo:lo + batch])
+                return xb, g - lo, "ACGT"[g % 4]
+            g -= n
+        raise IndexError(g)
+    return get
+
+
 def elapsed(out):
     m = re.search(r"Total time elapsed: ([0-9.]+) s", out)
     return float(m.group(1)) if m else None
@@ -57,23 +73,66 @@ def jobs(tmp_path_factory, ref):
         rc, out = refloop.run_worker(ref, lst, ck, want, pileup, indel, dwell=dwell, hip=False)
         assert rc == 0, out[-3000:]
         assert f"Total processed positions : {sum(sizes)}" in out, out[-3000:]
-        made[name] = dict(dir=d, lst=lst, ck=ck, want=want, n=sum(sizes), ref_s=elapsed(out))
+        made[name] = dict(dir=d, lst=lst, ck=ck, want=want, n=sum(sizes), ref_s=elapsed(out), kind=kind, channels=channels,
+                          indel=indel, window=file_window(d, sizes))
         return made[name]
     return get
+
+
+def explain_call_differences(job, diffs, ref_root):
+    """a differing call is accepted only with proof that it is a near-tie.  For every differing record: find
+    its window in the job's tensors, compute the reference's fp32 row (its own module on the CPU) and the library's row on the
+    GPU, enumerate the joint outcome probabilities the reference decoder ranks (clair3/CallVariants.py:510-660) for both rows
+    and require that (i) the rows are within the 1e-4 gate, (ii) the two rows rank at least one pair of outcomes differently --
+    otherwise the rows cannot explain the difference -- and (iii) every pair they rank differently is closer than 1e-6 in the
+    REFERENCE's own row (:722-751 picks the largest).  Returns the explanations (also printed)."""
+    import numpy as np
+    import torch
+    from tests import refmodels
+    from tests.test_parity_gpu import make_model
+    kind, channels, indel = job["kind"], job["channels"], job["indel"]
+    sd = {k: v.numpy() for k, v in torch.load(job["ck"] + ".pt", map_location="cpu").items()}
+    m_ref = refmodels.reference_model(ref_root, kind, sd, indel, channels)
+    m_hip = make_model(kind, channels, indel, sd)
+    notes = []
+    for (chrom, pos), a, b in diffs:
+        g = (int(pos) - 5000) // 41
+        assert 5000 + 41 * g == int(pos) and chrom == f"chr{1 + g % 3}", (chrom, pos)
+        xb, j, base = job["window"](g)  # the same batch the worker's loop formed: the CPU kernels ATen picks depend on its size
+        y_ref = refmodels.reference_rows(m_ref, xb)[j]
+        y_hip = m_hip.predict_numpy(np.ascontiguousarray(xb))[j]
+        p_ref = refmodels.outcome_probabilities(ref_root, y_ref, base, indel)
+        p_hip = refmodels.outcome_probabilities(ref_root, y_hip, base, indel)
+        inv = refmodels.order_inversions(p_ref, p_hip)
+        top2 = np.sort(p_ref)[-2:]
+        note = {"record": f"{chrom}:{pos}", "window": g, "reference_cpu": a, "libc3hip": b,
+                "max_abs_dy": float(np.abs(y_ref.astype(np.float64) - y_hip).max()),
+                "reference_top2_joint": [float(top2[1]), float(top2[0])], "reference_top2_gap": float(top2[1] - top2[0]),
+                "pairs_ranked_differently": len(inv), "largest_reference_gap_among_them": max([g_ for _, _, g_ in inv], default=None)}
+        print("CALL DIFFERS:", json.dumps(note, default=str))
+        notes.append(note)
+        assert note["max_abs_dy"] <= 1e-4, note
+        # (the worker's CPU run may have used another thread count than this re-evaluation: a tie of the two LARGEST outcomes
+        # within 1e-6 explains the record as well)
+        assert inv or note["reference_top2_gap"] <= 1e-6, f"rows rank every outcome alike yet the call differs -- not a near-tie: {note}"
+        assert (note["largest_reference_gap_among_them"] or 0.0) <= 1e-6, f"outcomes further apart than 1e-6 ranked differently: {note}"
+    return notes
 
 
 def check(name, job, got_vcf, out, tag):
     s = refloop.compare_vcfs(got_vcf, job["want"])
     s.update(case=name, run=tag, windows=job["n"], loop_seconds=elapsed(out), reference_cpu_loop_seconds=job["ref_s"])
+    assert s["records_a"] == s["records_b"] and s["records_a"] >= job["n"] // 2, s
+    assert not s["only_a"] and not s["only_b"], s
+    # the same calls.  QUAL is printed with two decimals from a log of probabilities that agree to ~1e-6, so a handful of rows may
+    # differ in the last digit (counted in qual_only).  A different CALL must be proven a near-tie of the reference's own joint
+    # outcome probabilities, record by record -- no allowance by count
+    s["near_ties"] = explain_call_differences(job, s["call_differs"], refloop.reference_root()) if s["call_differs"] else []
     os.makedirs(os.path.join(refloop.ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(refloop.ROOT, "gpurun_out", f"ref_loop_{name}_{tag}.json"), "w") as f:
         json.dump(s, f, default=str)
     print(json.dumps(s, default=str))
-    assert s["records_a"] == s["records_b"] and s["records_a"] >= job["n"] // 2, s
-    assert not s["only_a"] and not s["only_b"], s
-    # the same calls; QUAL is printed with two decimals from a log of probabilities that agree to ~1e-6, so a handful of rows may
-    # differ in the last digit (counted in qual_only); a different call is allowed only on < 0.1 % of the rows (near-ties)
-    assert len(s["call_differs"]) <= max(1, job["n"] // 1000), s
+    assert len(s["near_ties"]) == len(s["call_differs"])
     assert s["identical_text"] + s["qual_only"] >= s["records_a"] - len(s["call_differs"])
     assert s["identical_text"] >= 0.98 * s["records_a"], s
     return s
@@ -152,4 +211,7 @@ def test_legacy_stdin_worker_on_libc3hip(name, decoder, ref, tmp_path):
     rc, out = refloop.run_legacy_worker(ref, txt, ck, got, pileup, indel, hip=True, decoder=decoder)
     assert rc == 0 and f"Total processed positions in None : {n}" in out, out[-3000:]
     assert "clair3.CallVariants._torch_predict" in out  # run_reference lists what install() rebound
-    check(name, dict(want=want, n=n, ref_s=None), got, out, "legacy_decoder" if decoder else "legacy")
+    x_all = syn.make_windows(kind, n, seed=40, channels=channels)  # what refloop.write_pipe_tensors wrote
+    job = dict(want=want, n=n, ref_s=None, ck=ck, kind=kind, channels=channels, indel=indel,
+               window=lambda g: (x_all[g:g + 1], 0, "ACGT"[g % 4]))
+    check(name, job, got, out, "legacy_decoder" if decoder else "legacy")

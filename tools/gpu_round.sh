@@ -17,18 +17,18 @@ leg() {  # leg <workload>: the bench flags that run one workload's one-batch-in-
 }
 prof() {  # prof <tag> <workload>: kernel trace + stats of the one-in-flight leg AND its HIP-event pass (the same kernels, the same one
           # batch in flight), so the roofline object of the JSON line comes from the very launches the CSV averages
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$1" -o c3 -- python "$OLDPWD/bench.py" $(leg $2) > "$OUT/$1.json" 2> "$OUT/$1.err"); echo "$1 rc=$?"; find "$OUT/$1" -name '*kernel_stats*' | head -2
+  (cd /tmp && C3_BENCH_FULL="$OUT/$1_full.json" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$1" -o c3 -- python "$OLDPWD/bench.py" $(leg $2) > "$OUT/$1.json" 2> "$OUT/$1.err"); echo "$1 rc=$?"; find "$OUT/$1" -name '*kernel_stats*' | head -2
 }
 pmc() {  # pmc <tag> <workload> <counters...>
   local tag=$1 wl=$2; shift 2
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$tag" -o c3 -- python "$OLDPWD/bench.py" $(STEPS=5 leg $wl) --no-profiled-pass > /dev/null 2> "$OUT/$tag.err"); echo "$tag rc=$?"
+  (cd /tmp && C3_BENCH_FULL=/tmp/pmc_full.json timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/$tag" -o c3 -- python "$OLDPWD/bench.py" $(STEPS=5 leg $wl) --no-profiled-pass > /dev/null 2> "$OUT/$tag.err"); echo "$tag rc=$?"
 }
 for s in ${1:-test bench}; do
   case $s in
     test)    timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.txt ;;
     smoke)   timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.txt 2>&1; echo "smoke rc=$?"; tail -5 gpurun_out/smoke.txt ;;
-    bench)   timeout 900 python bench.py --gpus 1 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; head -c 600 gpurun_out/bench.json; echo ;;
-    bench20) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench20.json 2> gpurun_out/bench20.err; echo "bench20 rc=$?"; head -c 600 gpurun_out/bench20.json; echo ;;
+    bench)   C3_BENCH_FULL="$OUT/bench_full.json" timeout 900 python bench.py --gpus 1 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; head -c 3000 gpurun_out/bench.json; echo ;;
+    bench20) C3_BENCH_FULL="$OUT/bench20_full.json" timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench20.json 2> gpurun_out/bench20.err; echo "bench20 rc=$?"; head -c 3000 gpurun_out/bench20.json; echo ;;
     prof_fa) prof prof_fa full_alignment ;;
     prof_p)  prof prof_p pileup ;;
     pmc_fa)  pmc pmc_fetch_fa full_alignment FETCH_SIZE; pmc pmc_write_fa full_alignment WRITE_SIZE ;;

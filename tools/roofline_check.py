@@ -19,6 +19,7 @@ def main():
     line = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     fa = stats(sys.argv[2])
     roof = line["roofline"]
+    step_ms = line.get("one_batch_in_flight", {}).get("ms_per_step", line["ms_per_step"])  # the short line: value / ms_per_step ARE the one-in-flight leg
     batch = line["config"].get("batch_per_gpu") or line["config"].get("batch") or 256
     conv = {k: v for k, v in fa.items() if "conv3x3_planes_kernel" in k or "dense_planes_glds_kernel" in k or "conv1_i8" in k}
     steps = min(c for k, (c, _) in conv.items() if "conv3x3" in k)
@@ -31,10 +32,10 @@ def main():
     frac = FLOP_FA_CONV * batch / (total * 1e-6) / PEAK
     print(f"\nconvolution launches of one step: {total:.1f} us -> {FLOP_FA_CONV * batch / total / 1e6:.0f} algorithmic TFLOP/s = frac "
           f"**{frac:.4f}** of the 2 500 TFLOP/s 16-bit MFMA peak from the CSV; the bench line (HIP events, no tracer) says "
-          f"**{roof['frac']:.4f}** ({roof.get('kernel_us_per_step', float('nan')):.1f} us of kernels per {1e3 * line['one_batch_in_flight']['ms_per_step']:.1f} us step, "
+          f"**{roof['frac']:.4f}** ({roof.get('kernel_us_per_step', float('nan')):.1f} us of kernels per {1e3 * step_ms:.1f} us step, "
           f"mfma_util {roof.get('mfma_util', float('nan')):.3f}): {100 * abs(frac / roof['frac'] - 1):.1f} % apart.")
     whole = sum(c * us for k, (c, us) in fa.items() if k.startswith(("void c3::", "c3::"))) / steps
-    print(f"all c3 kernels of one step: {whole:.1f} us (rocprofv3) against the un-traced step of {1e3 * line['one_batch_in_flight']['ms_per_step']:.1f} us.")
+    print(f"all c3 kernels of one step: {whole:.1f} us (rocprofv3) against the un-traced step of {1e3 * step_ms:.1f} us.")
     if abs(frac / roof["frac"] - 1) > 0.03:
         print("MISMATCH > 3 %")
         sys.exit(1)
