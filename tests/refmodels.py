@@ -6,13 +6,17 @@ import sys
 import numpy as np
 
 
-def _import(root, names):
-    """import the reference's modules without leaving its packages on sys.path / in sys.modules (the suite's own modules of
-    the same top-level names -- `shared`, `clair3` -- must not be shadowed for later tests)"""
-    import importlib
+import contextlib
+
+
+@contextlib.contextmanager
+def _reference_on_path(root):
+    """the reference's packages importable inside the block, and gone from sys.path / sys.modules after it (the suite's own
+    modules of the same top-level names -- `shared`, `clair3` -- must not be shadowed for later tests).  The reference imports
+    lazily (clair3/model.py:93 imports shared.param_p inside __init__), so construction belongs inside the block too."""
     sys.path.insert(0, root)
     try:
-        return [importlib.import_module(n) for n in names]
+        yield
     finally:
         sys.path.remove(root)
         for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k == "shared" or k.startswith("shared.")]:
@@ -31,9 +35,11 @@ def reference_root_or_skip():
 def reference_model(root, kind, sd, indel, channels):
     """the reference's module in eval() with the state dict loaded strictly (clair3/CallVariantsFromCffi.py:19-28)"""
     import torch
-    (model_py,) = _import(root, ["clair3.model"])
-    cls = model_py.Clair3_P if kind == "pileup" else model_py.Clair3_F
-    m = cls(add_indel_length=indel, predict=True, input_channels=channels)
+    import importlib
+    with _reference_on_path(root):
+        model_py = importlib.import_module("clair3.model")
+        cls = model_py.Clair3_P if kind == "pileup" else model_py.Clair3_F
+        m = cls(add_indel_length=indel, predict=True, input_channels=channels)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     m.eval()
     return m
@@ -51,12 +57,14 @@ def outcome_probabilities(root, row, reference_base, indel):
     possible_outcome_probabilites_from), flattened in the function's own order -> 1-D float64 array.  The call the decoder makes
     is a function of the ORDER of these numbers (output_from walks them from the largest down, :722-751), so two rows give the
     same call whenever they order them the same way."""
-    (cv,) = _import(root, ["clair3.CallVariants"])
+    import importlib
     row = np.asarray(row, dtype=np.float32)
     gt21, zyg = row[0:21], row[21:24]
     l1, l2 = (row[24:57], row[57:90]) if indel else (None, None)
-    out = cv.possible_outcome_probabilites_from(gt21, zyg, l1, l2, reference_base=reference_base, alt_info_dict={},
-                                                add_indel_length=indel)
+    with _reference_on_path(root):
+        cv = importlib.import_module("clair3.CallVariants")
+        out = cv.possible_outcome_probabilites_from(gt21, zyg, l1, l2, reference_base=reference_base, alt_info_dict={},
+                                                    add_indel_length=indel)
     flat = []
     for item in out:
         if isinstance(item, (list, tuple)):

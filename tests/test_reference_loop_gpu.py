@@ -105,7 +105,7 @@ def explain_call_differences(job, diffs, ref_root):
         p_hip = refmodels.outcome_probabilities(ref_root, y_hip, base, indel)
         inv = refmodels.order_inversions(p_ref, p_hip)
         top2 = np.sort(p_ref)[-2:]
-        note = {"record": f"{chrom}:{pos}", "window": g, "reference_cpu": a, "libc3hip": b,
+        note = {"record": f"{chrom}:{pos}", "window": g, "libc3hip": a, "reference_cpu": b,  # compare_vcfs(got, want): a = the library's run
                 "max_abs_dy": float(np.abs(y_ref.astype(np.float64) - y_hip).max()),
                 "reference_top2_joint": [float(top2[1]), float(top2[0])], "reference_top2_gap": float(top2[1] - top2[0]),
                 "pairs_ranked_differently": len(inv), "largest_reference_gap_among_them": max([g_ for _, _, g_ in inv], default=None)}
