@@ -76,6 +76,8 @@ struct PlaneConvParams {
     const float *c1post = nullptr;   // conv1's [64] per-channel 2^-k (its fragments are packed times 2^k)
     int Hin = 0, Win = 0;
     uint32_t mg_hw = 0, mg_w = 0;    // fast_div magics of H * W and W (c3_gemm.h)
+    const void *wf = nullptr;        // conv3x3_duo_kernel (c3_conv3d.h): the weights in fragment order
+    int skew = 0;                    // conv3x3_duo_kernel: units of 1024 cycles the second workgroup of a CU starts later
 };
 
 // split four fp32 values into their fp16 pieces and store them behind `off` (hi plane) / `off + 128` (lo plane)

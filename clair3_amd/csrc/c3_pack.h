@@ -497,6 +497,25 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin, const FaC
                                 memcpy(&q16[((((((size_t)tn * NS + slab) * 9 + tap) * 64 + n) * 16 + g) * 8) + j], &piece, 2);
                             }
         TRY(upload(m, &m->pconv_w[l], pk));
+        // conv3x3_duo_kernel (c3_conv3d.h): the same 16 KB chunks in FRAGMENT order -- [wn][k-step][piece][lane] x 16 B: lane
+        // (n = lane & 31, kh = lane >> 5) of cout half wn holds channels 8 (2 ks + kh) .. + 7 of cout 32 wn + n, so a wave's
+        // matrix operand of one k-step is one contiguous kilobyte per piece, loaded straight into registers
+        std::vector<float> pf(pk.size());
+        uint16_t *f16 = reinterpret_cast<uint16_t *>(pf.data());
+        for (int tn = 0; tn < NS; ++tn)
+            for (int slab = 0; slab < NS; ++slab)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int wn = 0; wn < 2; ++wn)
+                        for (int ks = 0; ks < 4; ++ks)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int n = 32 * wn + (lane & 31), g = 2 * ks + (lane >> 5);
+                                    const size_t src = ((((((size_t)tn * NS + slab) * 9 + tap) * 64 + n) * 16 + g) * 8) + j;  // hi; lo = piece g + 8
+                                    const size_t dst = (((((((size_t)tn * NS + slab) * 9 + tap) * 2 + wn) * 4 + ks) * 2) * 64 + lane) * 8 + j;
+                                    f16[dst] = q16[src];
+                                    f16[dst + 64 * 8] = q16[src + 8 * 8];
+                                }
+        TRY(upload(m, &m->pconv_wf[l], pf));
     }
     if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kDnBN == 0) {
         // dense_planes_glds_kernel: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
