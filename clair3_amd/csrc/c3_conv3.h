@@ -1,38 +1,35 @@
 // c3_conv3.h -- the six stride-1 3x3 convolutions of Clair3_F's residual blocks (clair3/model.py:200-235, 83 % of the
-// network's FLOPs) as DIRECT convolutions on v_mfma_f32_32x32x16_f16, reading and writing "plane" activations.
+// network's FLOPs) as DIRECT convolutions on v_mfma_f32_32x32x16_f16, reading and writing "plane" activations, TWO workgroups
+// per CU.
 //
 // Plane activations.  Every fp32 activation x is kept as the two fp16 pieces the fp16x3 products need (x = hi + lo)
-// -- the same 4 bytes per value as fp32, but split ONCE by the producing epilogue instead of by every consumer tile
-// (round 1: 2.5 vector instructions per value per tile per tap).  Layout, C channels per pixel, NHWC order:
+// -- the same 4 bytes per value as fp32, but split ONCE by the producing epilogue instead of by every consumer tile.  Layout, C
+// channels per pixel, NHWC order:
 //     pixel row = C/64 slabs of 256 B;  slab s = [hi of channels 64s..64s+63 : 128 B][lo of the same channels : 128 B]
 // so a lane's MFMA operand (8 consecutive channels of one pixel) is one 16-byte piece per plane.
 //
-// Why direct and not Winograd any more.  Round 1 ran these layers as Winograd F(2x2,3x3): 2.25x fewer multiplications, paid for
-// with fp32 input/output transforms and a re-split of every transformed value -- 9 vector instructions per matrix instruction.
-// That trade was right while an fp32-equivalent product cost 64 matrix cycles; on the 16-bit instructions (3 x 32-cycle
-// products per 32x32x16 block) the matrix pipe is 5x cheaper and the vector work is what bounds the kernel (16 % MFMA-busy,
-// profiles/r01_q_pmc_sq.md).  The direct form has NO per-value vector work in its loop: operands go LDS -> register -> MFMA.
-//
-// One workgroup (512 threads, one per CU, persistent over tiles) = 256 consecutive output pixels (flattened over batch,
-// rows, columns) x 64 output channels:
-//  * the input pixels all nine taps of those 256 outputs touch are the flat range [m0 - W - 1, m0 + 255 + W + 1] -- ONE
-//    contiguous run of pixel rows.  For each 64-channel slab it is loaded into LDS once (292 rows x 256 B for W = 17) and
-//    every tap reads it at a row offset dh*W + dw; taps that fall off the window (top/bottom row, left/right column, other
-//    window) are redirected to an all-zero row by a per-lane 9-bit mask -- no im2col, 9x less A traffic than the tiled GEMM;
-//  * weights stream through LDS one (slab, tap) chunk at a time: 64 couts x 64 channels x 2 pieces = 16 KB, three LDS
-//    buffers and three register sets, one bare barrier in the middle of a chunk; fragment reads run one k-step ahead of the
-//    matrix instructions, across chunk boundaries too (see the prologue comment in the kernel);
-//  * LDS rows are 272 B apart (256 B of data + 16 B pad): the ds_read_b128 of 16 consecutive rows covers all 64 banks once,
-//    and the (piece, k-step) position inside a row is an immediate offset -- the loop has no address arithmetic besides one
-//    select + multiply per tap;
-//  * waves are 4 (pixels) x 2 (couts): 64 x 32 outputs each = two 32x32 accumulators, weights as the FIRST matrix operand, so a
-//    lane ends up with 4 consecutive output channels of one pixel; the epilogue adds the bias, sends the tile through LDS and
-//    leaves as (pixel, 8-channel) items: residual, ReLU, split into the two fp16 pieces, two 16-byte stores (8 lanes per
-//    128-byte plane row);
-//  * 132 KB of LDS, <= 248 registers, no spills;
-//  * every barrier is LDS-only (lds_barrier / bare s_barrier): __syncthreads() also waits for the epilogue's global stores
-//    and for every prefetch load in flight (loads and stores retire through one in-order counter).
-// Measurements, history and what bounds the kernel (the power-limited matrix stream): DESIGN.md 3.2 / 3.8.
+// One workgroup (256 threads = 4 waves as 2 (pixels) x 2 (couts), persistent over tiles) = 128 consecutive output pixels
+// (flattened over batch, rows, columns) x 64 output channels; a wave owns 64 x 32 outputs = two 32 x 32 accumulators:
+//  * the input pixels all nine taps of those 128 outputs touch are the flat range [m0 - W - 1, m0 + 127 + W + 1] -- ONE contiguous
+//    run of pixel rows.  For each 64-channel slab it is loaded into LDS once (164 rows x 256 B for W = 17) and every tap reads it
+//    at a row offset dh*W + dw; taps that fall off the window are redirected to an all-zero row by a per-lane 9-bit mask -- no
+//    im2col; LDS rows are 272 B apart (the ds_read_b128 of 16 consecutive rows covers all 64 banks once) and the (piece, k-step)
+//    position inside a row is an immediate offset;
+//  * LDS holds the halo tile and nothing else (45 KB; 70 KB with conv1's fragments in the first block), <= 214 registers: TWO
+//    workgroups per CU, one wave of each on every SIMD, so a tile's non-matrix phases -- halo load, slab switch, the tile through
+//    LDS, stores -- run under the matrix phase of the other workgroup;
+//  * WEIGHTS NEVER TOUCH LDS: packed in fragment order (c3_pack.h: [tn][slab][tap][wn][k-step][piece][lane] x 16 B), a wave's
+//    operand of one k-step is ONE contiguous 1 KB buffer load per piece, fetched straight into registers four k-steps (= one
+//    chunk) ahead.  The tap loop has NO barrier: the four waves drift freely, the only workgroup-wide synchronisation left is the
+//    slab switch and the epilogue.  The two waves of a cout half read the same kilobyte (the second read is an L1 hit);
+//  * weights are the FIRST matrix operand, so a lane ends up with 4 consecutive output channels of one pixel; the epilogue adds
+//    the bias, sends the tile through LDS and leaves as (pixel, 8-channel) items: residual, ReLU, split into the two fp16
+//    pieces, two 16-byte stores; every barrier is LDS-only (lds_barrier).
+// History: until round 4 these layers ran as ONE 512-thread workgroup per CU on 256-pixel tiles with the
+// weights streaming through three LDS buffers and a barrier per chunk.  Its phase trace (profiles/r04_a_conv_probe.txt): a
+// chunk of 1536 matrix cycles took 2100, and 8.4 k of a tile's 28.5 k cycles were its tail, with nothing to run under it.  The
+// form below gives bit-identical rows (same products per accumulator, same order) and is 4 % faster per step on the same box
+// (profiles/r04_b_ab_duo.txt); both forms sit at the clock the chip sustains under the matrix stream.
 #pragma once
 #include "c3_gemm.h"
 #include "c3_kernels.h"
@@ -45,19 +42,18 @@ namespace c3 {
 
 typedef uint32_t pl_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kPlBM = 256, kPlBN = 64;
-constexpr int kPlThreads = 512;                       // 8 waves: 4 (pixels) x 2 (couts), 64 x 32 outputs each
+constexpr int kPlBM = 128, kPlBN = 64;
+constexpr int kPlThreads = 256;                       // 4 waves: 2 (pixels) x 2 (couts), 64 x 32 outputs each
 constexpr int kPlRowB = 272;                           // LDS row stride
 constexpr int kPlMaxW = 17;                            // widest image the halo tile is sized for (45x17 stage of the ONT window)
-constexpr int kPlHaloRows = kPlBM + 2 * kPlMaxW + 2;   // 292
+constexpr int kPlHaloRows = kPlBM + 2 * kPlMaxW + 2;   // 164
 constexpr int kPlHaloBytes = (kPlHaloRows + 1) * kPlRowB;  // + the zero row
-constexpr int kPlBBytes = 64 * kPlRowB;
 constexpr int kPlHaloLoads = (kPlHaloRows * 16 + kPlThreads - 1) / kPlThreads;  // 16-byte pieces per thread
 constexpr uint32_t kPlOob = 0xffffff00u;               // buffer offset beyond every activation tensor (loads return 0, stores vanish)
 
 struct PlaneConvParams {
     const void *x;        // plane activations [M][C/64][2][64] fp16
-    const void *w;        // [Cout/64][C/64][9 taps][64 couts][16 pieces of 16 B]: pieces 0-7 = hi of channels 8g..8g+7, 8-15 = lo
+    const void *wf;       // weights in fragment order: [Cout/64][C/64][9 taps][2 cout halves][4 k-steps][hi | lo][64 lanes] x 16 B
     const float *bias;    // [Cout]
     const void *res;      // residual, plane layout of the output (RES)
     void *out;            // plane activations [M][Cout/64][2][64]
@@ -76,8 +72,7 @@ struct PlaneConvParams {
     const float *c1post = nullptr;   // conv1's [64] per-channel 2^-k (its fragments are packed times 2^k)
     int Hin = 0, Win = 0;
     uint32_t mg_hw = 0, mg_w = 0;    // fast_div magics of H * W and W (c3_gemm.h)
-    const void *wf = nullptr;        // conv3x3_duo_kernel (c3_conv3d.h): the weights in fragment order
-    int skew = 0;                    // conv3x3_duo_kernel: units of 1024 cycles the second workgroup of a CU starts later
+    int skew = 0;                    // units of 1024 cycles the second workgroup of a CU (the later half of the grid) starts later (probe knob)
 };
 
 // split four fp32 values into their fp16 pieces and store them behind `off` (hi plane) / `off + 128` (lo plane)
@@ -101,7 +96,7 @@ __device__ __forceinline__ f32x4 load_planes4(const __amdgpu_buffer_rsrc_t rsrc,
 // workgroups (wave 0) at phase boundaries into p.res ([2][256] x {tag, clock}).
 // SRC8 (C = 64 only; the first residual block behind the 8-channel conv1): conv1's output never exists in HBM.
 //   1  the INPUT halo rows are computed here from the int8 windows (conv1 + BatchNorm + ReLU, split into the two fp16 pieces,
-//      written straight into the LDS halo tile): 292 rows x 64 channels = 10 groups of 32 pixels over the 8 waves, 20 matrix
+//      written straight into the LDS halo tile): 165 rows x 64 channels = 6 groups of 32 pixels over the 4 waves, 20 matrix
 //      instructions of 32 cycles per group against conv1_i8_f16_kernel's weight fragments (kept in LDS), taps requested
 //      during the previous tile's last chunk;
 //   2  the RESIDUAL (= conv1's output at the tile's own pixels) is computed in the accumulators' own layout -- conv1 with the
@@ -111,8 +106,7 @@ __device__ __forceinline__ f32x4 load_planes4(const __amdgpu_buffer_rsrc_t rsrc,
 // 150 MB of HBM traffic per 256 windows (its output written once and read twice).
 // SPPF (last convolution of the network, 12 x 5 windows): PyramidPolling (clair3/model.py:245-279: 3x3, 2x2 and 1x1 max-pooling
 // bins over the 12 x 5 window, W padded on the right) is this kernel's epilogue.  Tiles are aligned to WINDOWS for that -- a tile
-// starts every 4 windows = 240 pixels and its last 16 rows are computed and dropped (the same 94 % the 240 tiles of 256
-// workgroups use today; 256 windows = 64 x 4 tiles = one per CU) -- so every bin of a window lies inside one tile: the ReLU'd
+// starts every 2 windows = 120 pixels and its last 8 rows are computed and dropped (256 windows = 128 x 4 tiles = two per CU) -- so every bin of a window lies inside one tile: the ReLU'd
 // fp32 tile goes back into LDS, thread (window, channel, level) takes the maxima of its bins over 60 LDS values and stores
 // them.  No plane output (its only reader was the pooling kernel), no pooling launch, no atomics.
 // C1 (with SRC8): channels of the windows, 8 or 9 (--enable_dwell_time adds the dwell channel).  Nine-byte pixels have no aligned
@@ -128,18 +122,15 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     constexpr int NT1 = C1 == 8 ? 5 : 6;  // conv1 k-steps of 16
     static_assert(SRC8 == 0 || C == 64, "conv1 feeds the 64-channel block only");
     static_assert(SRC8 != 2 || RES, "SRC8 = 2 replaces the residual read");
-    constexpr int NS = C / 64;     // input slabs = output column tiles
-    constexpr int PIXB = 4 * C;    // bytes per pixel
-    constexpr int NCH = 9 * NS;    // weight chunks per tile
+    constexpr int NS = C / 64;   // input slabs = output column tiles
+    constexpr int PIXB = 4 * C;  // bytes per pixel
+    constexpr int NCH = 9 * NS;  // weight chunks per tile
     constexpr int kC1WBytes = NT1 * 2 * 2 * 64 * 16;
-    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 3 * kPlBBytes + 768 + (SRC8 ? kC1WBytes + 512 : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[kPlHaloBytes + 768 + (SRC8 ? kC1WBytes + 512 : 0)];
     char *const halo = smem;
-    char *const bbuf = smem + kPlHaloBytes;
-    // this workgroup's 64 bias values (it keeps its column tile): read from LDS in the epilogue.  As global loads there they were
-    // waited for at once -- and with them, the counter being in-order, the halo rows and residual pieces requested just before
-    float *const bias_lds = reinterpret_cast<float *>(smem + kPlHaloBytes + 3 * kPlBBytes);
-    float *const post_lds = bias_lds + 64, *const pre_lds = bias_lds + 128;  // this column tile's 64 powers of two 2^-k / 2^k
-    char *const c1w_lds = smem + kPlHaloBytes + 3 * kPlBBytes + 768;
+    float *const bias_lds = reinterpret_cast<float *>(smem + kPlHaloBytes);
+    float *const post_lds = bias_lds + 64, *const pre_lds = bias_lds + 128;
+    char *const c1w_lds = smem + kPlHaloBytes + 768;
     float *const c1b_lds = reinterpret_cast<float *>(c1w_lds + kC1WBytes);
     float *const c1post_lds = c1b_lds + 64;
 
@@ -151,10 +142,9 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     const int T = kPlBM + 2 * W + 2;  // halo rows in use; row T is the zero row
     const int G = gridDim.x;
 
-    // PERSISTENT: workgroup w walks the tiles of virtual blocks w, w + G, w + 2G, ... (XCD-aware order).  The host launches
-    // either one workgroup per tile or G with (G / 8) % NS == 0, so the column tile tn -- and with it the weight stream --
-    // is the same for every tile of a workgroup: the weight pipeline simply keeps running across tile boundaries.
-    const int tile_stride = SPPF ? (kPlBM / HW) * HW : kPlBM;  // SPPF: whole windows per tile (4 x 60 pixels)
+    // PERSISTENT: workgroup w walks the tiles of virtual blocks w, w + G, ... (XCD-aware order); G is a multiple of 8 NS (or
+    // the tile count), so a workgroup keeps its column tile tn -- and with it its weight stream -- for every tile it takes.
+    const int tile_stride = SPPF ? (kPlBM / HW) * HW : kPlBM;  // SPPF: whole windows per tile (2 x 60 pixels)
     int v = blockIdx.x;
     int tile = xcd_tile_index(v, p.tiles);
     const int tn = tile % NS;
@@ -165,15 +155,16 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (uint32_t)((int64_t)p.M * PIXB), 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(RES ? p.res : p.out), 0, (uint32_t)((int64_t)p.M * PIXB), 0x00020000);
+    // this workgroup's weight stream: NCH chunks of 16 KB in fragment order
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.wf)) + (size_t)tn * NCH * 16384, 0, (uint32_t)(NCH * 16384), 0x00020000);
+    const uint32_t w_voff = (uint32_t)(wn * 8192 + lane * 16);
 
-    // `on` = false: the ten loads are still issued, at an out-of-range offset (zeros, no traffic).  A request under `if (on)` would
-    // make hipcc size every later s_waitcnt vmcnt(N) for the path WITHOUT these loads -- and on the path with them the next wait
-    // for a weight chunk then also waits for all ten of them (one in-order counter)
     auto halo_issue = [&](pl_u32x4 (&h)[kPlHaloLoads], int mbase, int slab, bool on = true) __attribute__((always_inline)) {
         const int m_lo = mbase - W - 1;
-        const uint32_t lim = on ? (uint32_t)p.M : 0u;  // (one scalar select: as a condition on every load `on` became control flow around each of them)
+        const uint32_t lim = on ? (uint32_t)p.M : 0u;
         int tid_ = tid;
-        asm volatile("" : "+v"(tid_));  // the ten row numbers are recomputed here, not carried (and spilled: reloads that wait for the loads just issued) across the tile loop
+        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int j = 0; j < kPlHaloLoads; ++j) {
             const int idx = tid_ + kPlThreads * j;
@@ -186,7 +177,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     };
     auto halo_write = [&](const pl_u32x4 (&h)[kPlHaloLoads]) __attribute__((always_inline)) {
         int tid_ = tid;
-        asm volatile("" : "+v"(tid_));  // the ten LDS addresses are recomputed here, not carried (and spilled) across the tile loop
+        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int j = 0; j < kPlHaloLoads; ++j) {
             const int idx = tid_ + kPlThreads * j;
@@ -194,36 +185,29 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             if (row < T) *reinterpret_cast<pl_u32x4 *>(halo + row * kPlRowB + pos * 16) = h[j];
         }
     };
-    const char *const wbase = reinterpret_cast<const char *>(p.w) + (size_t)tn * NCH * 16384 + tid * 16;
-    constexpr int NBP = 1024 / kPlThreads;  // 16-byte pieces of a weight chunk per thread
-    auto b_issue = [&](pl_u32x4 (&b)[NBP], int cc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NBP; ++j) b[j] = *reinterpret_cast<const pl_u32x4 *>(wbase + (size_t)cc * 16384 + j * (kPlThreads * 16));
-    };
-    const int bw_off = (tid >> 4) * kPlRowB + (tid & 15) * 16;  // kPlThreads / 16 rows further per j
-    auto b_write = [&](const pl_u32x4 (&b)[NBP], int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NBP; ++j) *reinterpret_cast<pl_u32x4 *>(bbuf + buf * kPlBBytes + bw_off + j * (kPlThreads / 16) * kPlRowB) = b[j];
+    // the weight ring: k-step ks of the chunk in flight sits in wq[ks] (hi piece, lo piece); it is refilled with the same
+    // k-step of the NEXT chunk right behind the matrix instructions that read it
+    pl_u32x4 wq[4][2];
+    auto w_issue = [&](int ks, int cc) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        const uint32_t so = (uint32_t)(cc * 16384 + ks * 2048);
+        wq[ks][0] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff, so, 0));
+        wq[ks][1] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff, so + 1024, 0));
     };
     auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
     };
 
     const int lrow[2] = {wm * 64 + frow, wm * 64 + 32 + frow};
-    const int b_rd = (wn * 32 + frow) * kPlRowB + kh * 16;
     const int cb0 = wn * 32 + 4 * kh;  // first of this lane's output channels inside the 64-channel slab tn
 
-    // ---- conv1 inside this kernel (SRC8).  Lane (pixel m = lane & 31 of a 32-pixel group, tap half kh): k-step t holds taps
-    // 2 t / 2 t + 1 in the two lane halves, 8 channels each (c3_conv1.h: the int8 bytes b become exact fp16 values b / 128 with
-    // one v_perm_b32 + one v_pk_add_f16 per pair; the weights are two fp16 pieces of 1.28 W').
+    // ---- conv1 inside this kernel (SRC8): see c3_conv3.h -- the same arithmetic, lane for lane
     typedef uint32_t c1u2 __attribute__((ext_vector_type(2)));
     const int c1_rowB = p.Win * C1;
     const __amdgpu_buffer_rsrc_t x8rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.x8)) - (SRC8 ? c1_rowB + C1 : 0), 0,
         SRC8 ? (uint32_t)((int64_t)(p.M / (p.H * p.W)) * p.Hin * c1_rowB + c1_rowB + C1) : 0u, 0x00020000);
     auto c1_request = [&](int pix, c1u2 (&d)[NT1]) __attribute__((always_inline)) {
-        // the per-lane tap geometry is recomputed here every time: left to itself hipcc keeps it (15 registers) alive across the
-        // whole tile loop, and the 248-register main loop then spills the halo registers
         int kh_ = kh;
         asm volatile("" : "+v"(kh_));
         const bool valid = (unsigned)pix < (unsigned)p.M;
@@ -231,8 +215,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         const int oy = fast_div(r, p.mg_w), ox = r - oy * W;
         const uint32_t base = (uint32_t)(((b * p.Hin + 2 * oy) * p.Win + 2 * ox) * C1);
         if constexpr (C1 == 9) {
-            // k-step t = (row ky = t >> 1, half u = t & 1): lane half kh_ takes bytes 16 u + 8 kh_ .. + 7 of the row's 27 (+ 5)
-            const bool left_out = ox == 0, right_out = 2 * ox + 1 >= p.Win;  // pixel 0 / pixel 2 of the row lies outside the window
+            const bool left_out = ox == 0, right_out = 2 * ox + 1 >= p.Win;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int ky = t >> 1, u = t & 1;
@@ -240,21 +223,21 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
                 bool ok = valid && (unsigned)iy < (unsigned)p.Hin;
                 uint32_t off = base + (uint32_t)(ky * c1_rowB + 16 * u) + (uint32_t)(8 * kh_);
                 int shl = 0, shr = 0;
-                if (u == 0) {  // bytes 0-7: pixel 0; bytes 8-15: last channel of pixel 0, then pixel 1
+                if (u == 0) {
                     if (left_out) {
                         if (kh_) off += 1, shl = 8;
                         else ok = false;
                     }
-                } else if (kh_) {  // bytes 24-26: pixel 2, then pad: fetched as bytes 19-26 (the piece ends with the row's last byte)
+                } else if (kh_) {
                     if (right_out) ok = false;
                     else off -= 5, shr = 40;
-                } else {           // bytes 16-23: two channels of pixel 1, then pixel 2
+                } else {
                     if (right_out) off -= 6, shr = 48;
                 }
                 const c1u2 raw = __builtin_bit_cast(c1u2, __builtin_amdgcn_raw_buffer_load_b64(x8rsrc, ok ? off : 0x80000000u, 0, 0));
-                uint64_t v = (uint64_t)raw[0] | ((uint64_t)raw[1] << 32);
-                v = (v << shl) >> shr;
-                d[t] = c1u2{(uint32_t)v, (uint32_t)(v >> 32)};
+                uint64_t vv = (uint64_t)raw[0] | ((uint64_t)raw[1] << 32);
+                vv = (vv << shl) >> shr;
+                d[t] = c1u2{(uint32_t)vv, (uint32_t)(vv >> 32)};
             }
             return;
         }
@@ -273,7 +256,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const uint32_t x = d[h] ^ 0x80808080u;
-            const uint32_t p01 = __builtin_amdgcn_perm(0x48484848u, x, 0x04010400u);  // [x.b0, 0x48, x.b1, 0x48]
+            const uint32_t p01 = __builtin_amdgcn_perm(0x48484848u, x, 0x04010400u);
             const uint32_t p23 = __builtin_amdgcn_perm(0x48484848u, x, 0x04030402u);
             const h2 nine = {(_Float16)-9.0f, (_Float16)-9.0f};
             o[2 * h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, p01) + nine);
@@ -281,7 +264,6 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         }
         return o;
     };
-    // conv1 of one 32-pixel group for column block cb (32 output channels): acc = sum over 5 k-steps, two weight pieces each
     auto c1_block = [&](const c1u2 (&d)[NT1], int cb) __attribute__((always_inline)) {
         f32x16 c;
 #pragma unroll
@@ -297,18 +279,18 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         return c;
     };
     float omax = 0.f;
-    // SRC8 = 1: halo rows 32 g .. 32 g + 31 (pixel m_lo + row) for g = wave and wave + 8
+    // SRC8 = 1: halo rows 32 g .. 32 g + 31 (pixel m_lo + row) for g = wave and wave + 4 (six groups cover the 165 rows)
     c1u2 c1d[2][NT1];
     auto c1_halo_request = [&](int mbase) __attribute__((always_inline)) {
         const int m_lo = mbase - W - 1;
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) c1_request(m_lo + 32 * (wave + 8 * gi) + frow, c1d[gi]);  // groups >= 10: rows beyond T, dropped below
+        for (int gi = 0; gi < 2; ++gi) c1_request(32 * (wave + 4 * gi) < T ? m_lo + 32 * (wave + 4 * gi) + frow : -0x40000000, c1d[gi]);
     };
     auto c1_halo_write = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-            const int row = 32 * (wave + 8 * gi) + frow;
-            if (32 * (wave + 8 * gi) >= T) continue;  // wave-uniform
+            const int row = 32 * (wave + 4 * gi) + frow;
+            if (32 * (wave + 4 * gi) >= T) continue;  // wave-uniform
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const f32x16 c = c1_block(c1d[gi], cb);
@@ -331,7 +313,6 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             }
         }
     };
-    // SRC8 = 2: the residual of this wave's two 32 x 32 blocks (pixels m0 + lrow[i], channels 32 wn .. 32 wn + 31)
     auto c1_res_request = [&](int mbase) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) c1_request(mbase + lrow[i], c1d[i]);
@@ -340,7 +321,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     int tr_n = 0;
     auto trace = [&](int tag) __attribute__((always_inline)) {
         if constexpr (ABL & 64) {
-            if ((blockIdx.x == 0 || blockIdx.x == 301) && tid == 0 && tr_n < 250) {
+            if ((blockIdx.x == 0 || blockIdx.x == 256) && tid == 0 && tr_n < 250) {
                 long long *tb = reinterpret_cast<long long *>(const_cast<void *>(p.res)) + ((blockIdx.x ? 1 : 0) * 256 + tr_n) * 2;
                 tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
                 ++tr_n;
@@ -348,17 +329,16 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         }
     };
     trace(1);
-    // ---- prologue: zero row, first halo slab, weight chunks 0 and 1 -> LDS, chunk 2 -> registers
-    // Weight chunks: THREE LDS buffers (buffer = tap % 3) and THREE register sets (set = tap % 3; 9 taps per slab, so both
-    // rotations repeat in every slab and tile and are compile-time constants in the unrolled tap loop).  Chunk g is requested
-    // at the top of chunk g - 3, written to LDS in the middle of chunk g - 2 (behind that chunk's only barrier) and first read at
-    // the end of chunk g - 1, when its first fragments are prefetched -- so the fragment pipeline runs ACROSS chunk boundaries
-    // and no matrix instruction ever waits for an LDS read issued right in front of it.  (With two buffers and the barrier at
-    // the chunk boundary the compiler's schedule exposed two LDS round trips plus the barrier per chunk: 2400 cycles per chunk
-    // for 1536 cycles of matrix work on the two waves of a SIMD.)
+    // ---- prologue: zero row, first halo slab, the first chunk of the weight ring
+    // (the long-latency requests go out first -- halo rows / window taps and the weight ring -- and only then the small tables that
+    // are copied into LDS: a copy waits for its load, and every request behind that wait would start a memory latency late)
     pl_u32x4 hreg[SRC8 == 1 ? 1 : kPlHaloLoads];
-    pl_u32x4 rb[3][NBP];
-    if (tid < 64) {  // visible behind the prologue's barrier
+    if constexpr (SRC8 == 1) c1_halo_request(m0);
+    else halo_issue(hreg, m0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w_issue(ks, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < 64) {
         bias_lds[tid] = p.bias[tn * 64 + tid], post_lds[tid] = p.post[tn * 64 + tid];
         if constexpr (SRC8 == 2) pre_lds[tid] = p.pre[tn * 64 + tid];
     }
@@ -367,12 +347,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             *reinterpret_cast<pl_u32x4 *>(c1w_lds + i * 16) = *reinterpret_cast<const pl_u32x4 *>(reinterpret_cast<const char *>(p.c1w) + i * 16);
         if (tid < 64) c1b_lds[tid] = p.c1b[tid], c1post_lds[tid] = p.c1post[tid];
     }
-    if constexpr (SRC8 == 1) c1_halo_request(m0);
-    else halo_issue(hreg, m0, 0);
-    b_issue(rb[0], 0);
-    b_issue(rb[1], 1);
-    b_issue(rb[2], 2);
     if (tid < 16) *reinterpret_cast<pl_u32x4 *>(halo + T * kPlRowB + tid * 16) = pl_u32x4{0u, 0u, 0u, 0u};
+    // the two workgroups of a CU run half a tile apart: the later half of the grid (the second workgroup every CU receives)
+    // waits here, its loads in flight, while the first half is already in its tap loop
+    if (p.skew > 0 && blockIdx.x >= (unsigned)(G >> 1))
+        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(16);
     trace(2);
     if constexpr (SRC8 == 1) {
         lds_barrier();  // conv1's weight fragments and bias are in LDS
@@ -380,14 +359,12 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     } else {
         halo_write(hreg);
     }
-    b_write(rb[0], 0);
-    b_write(rb[1], 1);
     lds_barrier();
     trace(3);
 
-    // fragment registers, two stages; stage 0 holds k-step 0 / 2, stage 1 k-step 1 / 3 of the current chunk
-    pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
-    const char *asrc[2];  // this lane's two halo rows for the current tap (+ the k-half offset)
+    // operand registers of the pixels, two stages; stage 0 holds k-step 0 / 2, stage 1 k-step 1 / 3 of the current chunk
+    pl_u32x4 xh[2][2], xl[2][2];
+    const char *asrc[2];
     uint32_t mask[2] = {0u, 0u};
     auto set_asrc = [&](int tap) __attribute__((always_inline)) {
         const int toff = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
@@ -397,10 +374,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             asrc[i] = halo + r * kPlRowB + kh * 16;
         }
     };
-    auto frags = [&](int buf, int ks, int st) __attribute__((always_inline)) {
-        const char *const bsrc = bbuf + buf * kPlBBytes + b_rd;
-        wh[st] = *reinterpret_cast<const pl_u32x4 *>(bsrc + ks * 32);
-        wl[st] = *reinterpret_cast<const pl_u32x4 *>(bsrc + 128 + ks * 32);
+    auto frags = [&](int ks, int st) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(asrc[i] + ks * 32);
@@ -409,11 +383,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
     };
 
     for (;;) {
-        // SRC8 = 2: this tile's residual taps, requested first thing: the tap-mask arithmetic below runs while they arrive.  (Held
-        // any longer -- requested under the previous tile's epilogue, next to its 40 halo registers -- they pushed the kernel
-        // into scratch, with spill stores waiting on just-issued loads: 70 instead of 53 us.)
         if constexpr (SRC8 == 2) c1_res_request(m0);
-        // tap validity of this lane's two output pixels: bit t set when tap t = (dh + 1) * 3 + (dw + 1) lies inside the window
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + lrow[i];
@@ -431,8 +401,6 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 
         f32x16 acc[2];
         if constexpr (SRC8 == 2) {
-            // the accumulators start from the residual: relu(conv1 + bias) times THIS layer's 2^k of the channel (undone with
-            // the rest of the sum by `post` in the epilogue), same (pixel, channel) per element
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f32x16 c = c1_block(c1d[i], wn);
@@ -452,64 +420,46 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         }
-        // first fragments of the tile's first chunk (the halo rows and LDS buffer 0 are in place behind a barrier)
         set_asrc(0);
-        frags(0, 0, 0);
+        frags(0, 0);
 
-        // chunk cc = slab * 9 + tap, on LDS buffer tap % 3.  The last tap of a slab also fetches the next halo (next slab, or
-        // slab 0 of this workgroup's next tile) into registers during its matrix phase.
 #pragma unroll 1
         for (int slab = 0; slab < NS; ++slab)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int cc = slab * 9 + tap;
             const bool last = cc == NCH - 1;
-            if constexpr (!(ABL & 1)) b_issue(rb[tap % 3], cc + 3 < NCH ? cc + 3 : cc + 3 - NCH);  // set tap % 3 went to LDS two chunks ago
-            constexpr int kHaloTap = C3_HALO_TAP;  // the tap under whose matrix phase the next slab's halo rows are requested
+            const int ccn = last ? 0 : cc + 1;  // the ring refills with the next chunk of this workgroup's (cyclic) stream
+            constexpr int kHaloTap = 8;
             if (tap == kHaloTap) {
-                // NS = 1 (C = 64): the only switch is the one to the next tile, and its halo rows are requested AFTER the tap loop
-                // (below) -- they have the whole epilogue to arrive, and the 40 registers they land in are not held under the
-                // last chunk's matrix phase, where the kernel's register demand peaks
                 if constexpr (NS > 1 && !(ABL & 2)) {
                     const bool lastslab = slab == NS - 1;
                     halo_issue(hreg, lastslab ? m0n : m0, lastslab ? 0 : slab + 1, !lastslab || more);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);  // the global loads stay ahead of the matrix phase they fly under
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int st = ks & 1;
-                // request the NEXT k-step's fragments (for k-step 3: k-step 0 of the next chunk, unless the halo rows are
-                // about to change), then this k-step's matrix instructions -- in that order, pinned
                 if (ks < 3) {
-                    frags(tap % 3, ks + 1, st ^ 1);
+                    frags(ks + 1, st ^ 1);
                 } else if (tap != 8) {
                     set_asrc(tap + 1);
-                    frags((tap + 1) % 3, 0, 0);
+                    frags(0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 8)) {
-                    // the three piece products, smallest first, the two pixel blocks interleaved (two independent chains)
-                    acc[0] = mma(acc[0], wh[st], xl[st][0]);
-                    acc[1] = mma(acc[1], wh[st], xl[st][1]);
-                    acc[0] = mma(acc[0], wl[st], xh[st][0]);
-                    acc[1] = mma(acc[1], wl[st], xh[st][1]);
-                    acc[0] = mma(acc[0], wh[st], xh[st][0]);
-                    acc[1] = mma(acc[1], wh[st], xh[st][1]);
+                    acc[0] = mma(acc[0], wq[ks][0], xl[st][0]);
+                    acc[1] = mma(acc[1], wq[ks][0], xl[st][1]);
+                    acc[0] = mma(acc[0], wq[ks][1], xh[st][0]);
+                    acc[1] = mma(acc[1], wq[ks][1], xh[st][1]);
+                    acc[0] = mma(acc[0], wq[ks][0], xh[st][0]);
+                    acc[1] = mma(acc[1], wq[ks][0], xh[st][1]);
                 } else {
-                    acc[0][ks] += __uint_as_float(wh[st][0] ^ xl[st][0][1] ^ xh[st][1][2] ^ wl[st][3]);  // keep the reads alive
+                    acc[0][ks] += __uint_as_float(wq[ks][0][0] ^ xl[st][0][1] ^ xh[st][1][2] ^ wq[ks][1][3]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks == 1) {
-                    // the chunk's one barrier: every wave is past the previous chunk, whose LDS buffer (tap + 2) % 3 now takes
-                    // chunk cc + 2 (requested at the top of the previous chunk); it is first read at the end of chunk cc + 1
-                    // (a bare s_barrier: nothing of this wave has to drain -- the reads in flight are this chunk's own prefetch, and
-                    // its last LDS writes are a whole chunk old, behind reads that have long returned)
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if constexpr (!(ABL & 1)) b_write(rb[(tap + 2) % 3], (tap + 2) % 3);
-                }
+                w_issue(ks, ccn);
             }
             if constexpr (NS > 1)
             if (tap == 8 && !last) {  // slab switch inside the tile
@@ -517,18 +467,15 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
                 if constexpr (!(ABL & 2)) halo_write(hreg);
                 lds_barrier();
                 set_asrc(0);
-                frags(0, 0, 0);
+                frags(0, 0);
             }
             trace(10 + tap);
         }
 
-        // ---- epilogue.  Weights were the first operand: acc[i][e] = output pixel (lane & 31) of block i, channel
-        // (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the wave's 32.  The tile crosses LDS once (the halo region is free now:
-        // 256 rows x 272 B of fp32) so that every global access of the epilogue is a full 16 bytes of 8 consecutive
-        // channels, 8 lanes per 128-byte plane row: (pixel, channel group) items, residual added, ReLU, split, two stores.
+        // ---- epilogue (c3_conv3.h): the tile crosses LDS once, (pixel, 8-channel) items, residual, ReLU, split, two stores
         if constexpr (NS == 1) {
             if constexpr (SRC8 == 1) {
-                c1_halo_request(more ? m0n : -0x40000000);  // (no next tile: every pixel out of range, the taps are requested at an out-of-range offset)
+                c1_halo_request(more ? m0n : -0x40000000);
             } else if constexpr (!(ABL & 2)) {
                 halo_issue(hreg, m0n, 0, more);
             }
@@ -536,10 +483,8 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         lds_barrier();  // all waves are done with the halo rows
         trace(30);
         if constexpr (ABL & 4) {
-            if (acc[0][0] == 12345.f && acc[1][3] == 1.f) p.range_flag[1] = 1u;  // keep the accumulators alive
+            if (acc[0][0] == 12345.f && acc[1][3] == 1.f) p.range_flag[1] = 1u;
         } else {
-        // this thread's four (pixel, 8-channel group) items; the residual pieces are requested NOW, all eight at once, and
-        // fly while the tile crosses LDS
         uint32_t ioff[4];
         pl_u32x4 rh[4], rl[4];
 #pragma unroll
@@ -568,7 +513,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = tid + kPlThreads * j;
-            const int pr = idx >> 3, g = idx & 7;  // pixel of the tile, group of 8 channels
+            const int pr = idx >> 3, g = idx & 7;
             const uint32_t off = ioff[j];
             f32x4 a = *reinterpret_cast<const f32x4 *>(halo + pr * kPlRowB + g * 32);
             f32x4 b = *reinterpret_cast<const f32x4 *>(halo + pr * kPlRowB + g * 32 + 16);
@@ -582,11 +527,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a[e] = __int_as_float(max(__float_as_int(a[e]), 0));  // ReLU on the bit pattern
+                a[e] = __int_as_float(max(__float_as_int(a[e]), 0));
                 b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
             }
             omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-            if constexpr (SPPF) {  // the finished values go back to their place in the LDS tile for the pooling pass
+            if constexpr (SPPF) {
                 *reinterpret_cast<f32x4 *>(halo + pr * kPlRowB + g * 32) = a;
                 *reinterpret_cast<f32x4 *>(halo + pr * kPlRowB + g * 32 + 16) = b;
                 continue;
@@ -599,15 +544,13 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
             __builtin_amdgcn_raw_buffer_store_b128(lo, orsrc, off + 128, 0, 0);
         }
         if constexpr (SPPF) {
-            // thread (channel c = tid & 63, window w = (tid >> 6) & 3 of the tile, level half = tid >> 8): half 0 takes the nine
-            // 3x3 bins (rows 4 apart, column pairs {0,1} {2,3} {4,pad}), half 1 the four 2x2 bins (rows 6 apart, columns {0,1,2}
-            // {3,4,pad}) and the 1x1 bin.  The padded bins include F.pad's zero in their maximum: values are >= 0 after the ReLU
-            // anyway.  A wave reads 64 consecutive channels of one pixel per instruction: conflict-free.
+            // thread (channel c = tid & 63, window w = (tid >> 6) & 1 of the tile, level half = tid >> 7): half 0 takes the nine
+            // 3x3 bins, half 1 the four 2x2 bins and the 1x1 bin (c3_conv3.h)
             lds_barrier();
-            const int sc = tid & 63, sw = (tid >> 6) & 3, half = tid >> 8;
-            const int wb = m0 / HW + sw;  // window index
+            const int sc = tid & 63, sw = (tid >> 6) & 1, half = tid >> 7;
+            const int wb = m0 / HW + sw;
             const float *src = reinterpret_cast<const float *>(halo + (sw * HW) * kPlRowB) + sc;
-            constexpr int RS = kPlRowB / 4;  // floats between consecutive pixels
+            constexpr int RS = kPlRowB / 4;
             float mx[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) mx[k] = 0.f;
@@ -640,8 +583,9 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_planes_kernel(PlaneConv
         trace(33);
         v = vn, m0 = m0n;
     }
-    if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
+    if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);
 }
+
 
 // ------------------------------------------------------------------------------------------ plane utilities
 // plane activations -> fp32 NHWC (parity tests: c3_debug_fetch)

@@ -140,22 +140,18 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             HIP_TRY(hipGetLastError());
         } else {
             const bool res = l % 3 == 2;
-            // two workgroups of 128-pixel tiles per CU with the weights in fragment order (c3_conv3d.h), or -- C3HIP_CONV_DUO=0 -- one
-            // 512-thread workgroup of 256-pixel tiles (c3_conv3.h); the rows are bit-identical
-            const bool duo = m->conv_duo && m->pconv_wf[l] != nullptr;
-            const int BM = duo ? kDuBM : kPlBM;
             PlaneConvParams cp;
-            cp.x = m->act[l - 1], cp.w = m->pconv_w[l], cp.wf = m->pconv_wf[l], cp.bias = m->conv_b[l], cp.res = res ? m->act[l - 2] : nullptr, cp.out = m->act[l];
-            cp.range_flag = m->range_flag, cp.post = m->pconv_post[l], cp.pre = m->pconv_pre[l], cp.skew = m->conv_skew;
+            cp.x = m->act[l - 1], cp.wf = m->pconv_w[l], cp.bias = m->conv_b[l], cp.res = res ? m->act[l - 2] : nullptr, cp.out = m->act[l];
+            cp.range_flag = m->range_flag, cp.post = m->pconv_post[l], cp.pre = m->pconv_pre[l];
             cp.M = M, cp.H = hh[l], cp.W = ww[l];
             TRY(div_magic(hh[l] * ww[l], (int64_t)M + 2 * kPlBM, &cp.mg_hw));
             TRY(div_magic(ww[l], hh[l] * ww[l], &cp.mg_w));
-            const int tiles_m = (M + BM - 1) / BM;
+            const int tiles_m = (M + kPlBM - 1) / kPlBM;
             cp.tiles = tiles_m * (Cout / 64);
             const bool src8 = fuse1 && (l == 1 || l == 2);
-            // PyramidPolling as the epilogue of the last convolution (SPPF): 12 x 5 windows, whole windows per tile (4 / 2 of them)
+            // PyramidPolling as the epilogue of the last convolution (c3_conv3.h SPPF): 12 x 5 windows, two whole windows per tile
             const bool sppf = l == 8 && sppf_ok;
-            const int wpt = BM / 60;  // windows per tile
+            constexpr int wpt = kPlBM / 60;  // windows per tile
             if (sppf) {
                 cp.spp = m->spp;
                 cp.tiles = (int)((n + wpt - 1) / wpt) * (Cout / 64);
@@ -168,37 +164,31 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             // SRC8: + conv1 for the halo rows of a tile in groups of 32 (res1a) / the tile's own pixels (res1b), two piece products of
             // K = 80 (96 for 9 channels)
             const double tiles_x = sppf ? (double)((n + wpt - 1) / wpt) : (double)tiles_m;  // pixel tiles the launch really runs
-            const int c1_rows = l == 1 ? (BM + 2 * ww[l] + 2 + 31) / 32 * 32 : BM;
-            ps.mfma(2.0 * tiles_x * BM * (double)Cout * 9.0 * cin * 3 + (src8 ? 2.0 * tiles_m * c1_rows * 64.0 * (m->C == 8 ? 80.0 : 96.0) * 2 : 0.0), true);
-            // persistent: one workgroup per tile when they all fit (one 512-thread / two 256-thread workgroups per CU), else as many as
-            // fit rounded down so that a workgroup's tiles share their column tile
+            const int c1_rows = l == 1 ? (kPlBM + 2 * ww[l] + 2 + 31) / 32 * 32 : kPlBM;
+            ps.mfma(2.0 * tiles_x * kPlBM * (double)Cout * 9.0 * cin * 3 + (src8 ? 2.0 * tiles_m * c1_rows * 64.0 * (m->C == 8 ? 80.0 : 96.0) * 2 : 0.0), true);
+            // persistent: one workgroup per tile when they all fit (two 256-thread workgroups, <= 70 KB of LDS each, per CU), else as
+            // many as fit, rounded down so that a workgroup's tiles share their column tile (c3_conv3.h)
             int g = cp.tiles;
-            const int slots = duo ? m->wg_slots : m->wg_slots / 2, unit = 8 * (Cout / 64);
+            const int slots = m->wg_slots, unit = 8 * (Cout / 64);
             if (g > slots) g = std::max(unit, slots / unit * unit);
-            const dim3 grid(g), block(duo ? kDuThreads : kPlThreads);
-#define C3_CONV_LAUNCH(...)                                                                      \
-    do {                                                                                         \
-        if (duo) hipLaunchKernelGGL((conv3x3_duo_kernel<__VA_ARGS__>), grid, block, 0, s, cp);   \
-        else hipLaunchKernelGGL((conv3x3_planes_kernel<__VA_ARGS__>), grid, block, 0, s, cp);    \
-    } while (0)
+            const dim3 grid(g), block(kPlThreads);
             if (Cout == 64 && src8 && m->C == 9) {
-                if (res) C3_CONV_LAUNCH(64, true, 0, 2, false, 9);
-                else C3_CONV_LAUNCH(64, false, 0, 1, false, 9);
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true, 0, 2, false, 9>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false, 0, 1, false, 9>), grid, block, 0, s, cp);
             } else if (Cout == 64 && src8) {
-                if (res) C3_CONV_LAUNCH(64, true, 0, 2);
-                else C3_CONV_LAUNCH(64, false, 0, 1);
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true, 0, 2>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false, 0, 1>), grid, block, 0, s, cp);
             } else if (Cout == 64) {
-                if (res) C3_CONV_LAUNCH(64, true);
-                else C3_CONV_LAUNCH(64, false);
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<64, true>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<64, false>), grid, block, 0, s, cp);
             } else if (Cout == 128) {
-                if (res) C3_CONV_LAUNCH(128, true);
-                else C3_CONV_LAUNCH(128, false);
+                if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<128, true>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<128, false>), grid, block, 0, s, cp);
             } else {
-                if (sppf) C3_CONV_LAUNCH(256, true, 0, 0, true);
-                else if (res) C3_CONV_LAUNCH(256, true);
-                else C3_CONV_LAUNCH(256, false);
+                if (sppf) hipLaunchKernelGGL((conv3x3_planes_kernel<256, true, 0, 0, true>), grid, block, 0, s, cp);
+                else if (res) hipLaunchKernelGGL((conv3x3_planes_kernel<256, true>), grid, block, 0, s, cp);
+                else hipLaunchKernelGGL((conv3x3_planes_kernel<256, false>), grid, block, 0, s, cp);
             }
-#undef C3_CONV_LAUNCH
             HIP_TRY(hipGetLastError());
         }
         cin = Cout;
@@ -270,7 +260,7 @@ static int run_fa_fp32(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, f
 
 static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float *y) {
     if (fa_planes_ok(m)) {
-        m->choice_fa = m->conv_duo ? "planes-f16x3-duo" : "planes-f16x3";
+        m->choice_fa = "planes-f16x3";
         return run_fa_planes(m, s, x, n, y);
     }
     m->choice_fa = "fp32-mfma";

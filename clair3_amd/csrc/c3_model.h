@@ -36,7 +36,6 @@
 #include "c3_lstm_fused.h"
 #include "c3_host.h"
 #include "c3_conv3.h"
-#include "c3_conv3d.h"
 #include "c3_dense.h"
 
 using namespace c3;
@@ -137,8 +136,7 @@ struct c3_model {
     float *conv1_w16_post = nullptr;  // its [64] per-channel 2^-k
     float *conv1_wfrag16 = nullptr;  // conv1 as fragments of conv1_i8_f16_kernel / conv3x3_planes_kernel's SRC8 forms (C = 8 or 9)
     float *conv1_post = nullptr;     // their [64] per-channel 2^-k
-    float *pconv_wf[9] = {};  // the same chunks in fragment order (conv3x3_duo_kernel, c3_conv3d.h)
-    float *pconv_w[9] = {};  // stride-1 convs: conv3x3_planes_kernel chunks [Cout/64][Cin/64][9][64][16 pieces of 16 B];
+    float *pconv_w[9] = {};  // stride-1 convs: conv3x3_planes_kernel chunks in fragment order [Cout/64][Cin/64][9][2][4][2][64 lanes x 16 B];
                              // stride-2 convs: dense_planes_glds_kernel chunks [Cout/128][9 Cin/64][128][16 pieces]
     float *pconv_pre[9] = {}, *pconv_post[9] = {};  // [Cout] the output channels' powers of two 2^k / 2^-k (c3_pack.h row_scales)
     // shared FC tail
@@ -164,8 +162,6 @@ struct c3_model {
                               // full, so the recurrences stay on full tiles and the projection launches half as many, twice as long workgroups
     int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
     bool lock_sources = false;  // c3_model_set_lock_sources: c3_predict may page-lock the caller's windows for the duration of a call
-    bool conv_duo = true;     // the stride-1 convolutions as two workgroups per CU (c3_conv3d.h); env C3HIP_CONV_DUO=0: one (c3_conv3.h)
-    int conv_skew = 0;        // start offset of a CU's second workgroup, units of 1024 cycles; env C3HIP_CONV_SKEW
     int wg_slots = 512;       // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
 
     void *decode_dev = nullptr;  // scratch of c3_outcome_maxima

@@ -83,8 +83,6 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_FP32")) m->f16_ok = atoi(e) == 0;  // start on the fp32-MFMA forms (what the range guard falls back to)
     if (const char *e = getenv("C3HIP_CONV1_FUSED")) m->conv1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_SPP_FUSED")) m->spp_fused = atoi(e) != 0;
-    if (const char *e = getenv("C3HIP_CONV_DUO")) m->conv_duo = atoi(e) != 0;
-    if (const char *e = getenv("C3HIP_CONV_SKEW")) m->conv_skew = atoi(e);
     if (const char *e = getenv("C3HIP_HALF_TILES")) m->half_tiles = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
     {
@@ -265,7 +263,6 @@ int c3_model_destroy(c3_model *m) {
         if (m->conv_w[l]) (void)hipFree(m->conv_w[l]);
         if (m->conv_b[l]) (void)hipFree(m->conv_b[l]);
         if (m->pconv_w[l]) (void)hipFree(m->pconv_w[l]);
-        if (m->pconv_wf[l]) (void)hipFree(m->pconv_wf[l]);
         if (m->pconv_pre[l]) (void)hipFree(m->pconv_pre[l]);
         if (m->pconv_post[l]) (void)hipFree(m->pconv_post[l]);
     }

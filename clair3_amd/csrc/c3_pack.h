@@ -475,8 +475,10 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin, const FaC
         if (mx < 16384.f) TRY(upload(m, &m->conv1_wfrag16, pf16));  // else: conv1 stays on the tiled GEMM
     }
     if (kConvStride[l] == 1 && Cin == Cout && Cin % 64 == 0) {
-        // conv3x3_planes_kernel: chunk (column tile tn, input slab, tap) = 64 couts x 256 B; piece g < 8 = hi of channels
-        // 64 slab + 8 g .. + 7, g >= 8 = lo of channels 8 (g - 8) ..; times the output channel's power of two (row_scales)
+        // conv3x3_planes_kernel (c3_conv3.h): chunk (column tile tn, input slab, tap) = 64 couts x 64 channels x 2 pieces = 16 KB in
+        // FRAGMENT order -- [cout half wn][k-step][piece hi | lo][lane] x 16 B: lane (n = lane & 31, kh = lane >> 5) holds channels
+        // 64 slab + 8 (2 ks + kh) .. + 7 of cout 64 tn + 32 wn + n, times the output channel's power of two (row_scales) -- so a wave's
+        // matrix operand of one k-step is one contiguous kilobyte per piece, loaded straight into registers
         const int NS = Cin / 64;
         std::vector<float> sc, post;
         row_scales(pw.data(), Cout, (size_t)ldb, sc, post);
@@ -487,35 +489,18 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin, const FaC
         for (int tn = 0; tn < NS; ++tn)
             for (int slab = 0; slab < NS; ++slab)
                 for (int tap = 0; tap < 9; ++tap)
-                    for (int n = 0; n < 64; ++n)
-                        for (int g = 0; g < 16; ++g)
-                            for (int j = 0; j < 8; ++j) {
-                                const int co = tn * 64 + n, ci = slab * 64 + 8 * (g & 7) + j;
-                                const float v = pw[(size_t)co * ldb + (size_t)tap * Cin + ci] * sc[co];  // exact
-                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
-                                const _Float16 piece = g < 8 ? h0 : h1;
-                                memcpy(&q16[((((((size_t)tn * NS + slab) * 9 + tap) * 64 + n) * 16 + g) * 8) + j], &piece, 2);
-                            }
-        TRY(upload(m, &m->pconv_w[l], pk));
-        // conv3x3_duo_kernel (c3_conv3d.h): the same 16 KB chunks in FRAGMENT order -- [wn][k-step][piece][lane] x 16 B: lane
-        // (n = lane & 31, kh = lane >> 5) of cout half wn holds channels 8 (2 ks + kh) .. + 7 of cout 32 wn + n, so a wave's
-        // matrix operand of one k-step is one contiguous kilobyte per piece, loaded straight into registers
-        std::vector<float> pf(pk.size());
-        uint16_t *f16 = reinterpret_cast<uint16_t *>(pf.data());
-        for (int tn = 0; tn < NS; ++tn)
-            for (int slab = 0; slab < NS; ++slab)
-                for (int tap = 0; tap < 9; ++tap)
                     for (int wn = 0; wn < 2; ++wn)
                         for (int ks = 0; ks < 4; ++ks)
                             for (int lane = 0; lane < 64; ++lane)
                                 for (int j = 0; j < 8; ++j) {
-                                    const int n = 32 * wn + (lane & 31), g = 2 * ks + (lane >> 5);
-                                    const size_t src = ((((((size_t)tn * NS + slab) * 9 + tap) * 64 + n) * 16 + g) * 8) + j;  // hi; lo = piece g + 8
+                                    const int co = tn * 64 + 32 * wn + (lane & 31), ci = slab * 64 + 8 * (2 * ks + (lane >> 5)) + j;
+                                    const float v = pw[(size_t)co * ldb + (size_t)tap * Cin + ci] * sc[co];  // exact
+                                    const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
                                     const size_t dst = (((((((size_t)tn * NS + slab) * 9 + tap) * 2 + wn) * 4 + ks) * 2) * 64 + lane) * 8 + j;
-                                    f16[dst] = q16[src];
-                                    f16[dst + 64 * 8] = q16[src + 8 * 8];
+                                    memcpy(&q16[dst], &h0, 2);
+                                    memcpy(&q16[dst + 64 * 8], &h1, 2);
                                 }
-        TRY(upload(m, &m->pconv_wf[l], pf));
+        TRY(upload(m, &m->pconv_w[l], pk));
     }
     if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kDnBN == 0) {
         // dense_planes_glds_kernel: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
