@@ -26,11 +26,16 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         const double fl = 2.0 * n * (FC * 128.0 * m->nb + 128.0 * m->nout);
         ProfScope ps(m, s, tag_tail, fl, 4.0 * ((double)S * n * FC + n * m->nout));
         ps.mfma(2.0 * ((n + 15) / 16 * 16) * m->nb * (FC * 128.0 + 128.0 * 48.0), false);
-        ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
-        if (l4_f16) rp.pre = m->l4_pre, rp.post = m->l4_post;
-        hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
-        HIP_TRY(hipGetLastError());
         Tail2Params tp{m->l4dbg, m->w5f, m->b5, m->whf, m->bh48, y, (int)n, m->nb, m->row};
+        if (m->tail_fused) {  // the split-K sum inside the tail kernel: two launches behind the last convolution / recurrence, not three
+            tp.part = m->part, tp.S = S, tp.bias4 = m->l4_b, tp.l4out = m->l4dbg;
+            if (l4_f16) tp.pre = m->l4_pre, tp.post = m->l4_post;
+        } else {
+            ReduceParams rp{m->part, m->l4_b, m->l4dbg, (int)n, FC, S};
+            if (l4_f16) rp.pre = m->l4_pre, rp.post = m->l4_post;
+            hipLaunchKernelGGL(splitk_reduce_selu_kernel, dim3((unsigned)((n * FC + 255) / 256)), dim3(256), 0, s, rp);
+            HIP_TRY(hipGetLastError());
+        }
         const dim3 grid((unsigned)((n + 15) / 16), m->nb);
         if (FC == 256)
             hipLaunchKernelGGL(fc_tail_mfma_kernel<256>, grid, dim3(256), 0, s, tp);

@@ -162,6 +162,8 @@ struct c3_model {
                               // full, so the recurrences stay on full tiles and the projection launches half as many, twice as long workgroups
     int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
     bool lock_sources = false;  // c3_model_set_lock_sources: c3_predict may page-lock the caller's windows for the duration of a call
+    bool tail_fused = false;  // the split-K sum of L4 inside fc_tail_mfma_kernel (c3_tail.h) instead of its own launch: on for the pileup network (+0.7 %:
+                              // 15 partials of 128 features), off for full alignment (-1 %: four branch workgroups re-read 28 partials of 256); env C3HIP_TAIL_FUSED
     int wg_slots = 512;       // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
 
     void *decode_dev = nullptr;  // scratch of c3_outcome_maxima
@@ -239,7 +241,8 @@ static int launch_gemm(hipStream_t s, const typename Loader::Params &lp, const f
 // order by the reduce kernel, so a window's probabilities are bit-identical whatever batch it travels in.
 static int l4_splits(const c3_model *m) {
     const int nk = m->K4 / kBK;
-    const int want = m->kind == C3_KIND_PILEUP ? 15 : 28;  // measured against 22 / 30 / 33 (pileup) and 14 / 56 (full alignment)
+    static const int env = getenv("C3HIP_L4_SPLITS") ? atoi(getenv("C3HIP_L4_SPLITS")) : 0;  // A/B knob
+    const int want = env > 0 ? env : m->kind == C3_KIND_PILEUP ? 15 : 28;  // measured against 22 / 30 / 33 (pileup) and 14 / 56 (full alignment)
     int best = 1;
     for (int s = 1; s <= nk && s <= want; ++s)
         if (nk % s == 0) best = s;

@@ -83,6 +83,8 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_FP32")) m->f16_ok = atoi(e) == 0;  // start on the fp32-MFMA forms (what the range guard falls back to)
     if (const char *e = getenv("C3HIP_CONV1_FUSED")) m->conv1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_SPP_FUSED")) m->spp_fused = atoi(e) != 0;
+    m->tail_fused = kind == C3_KIND_PILEUP;
+    if (const char *e = getenv("C3HIP_TAIL_FUSED")) m->tail_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HALF_TILES")) m->half_tiles = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
     {

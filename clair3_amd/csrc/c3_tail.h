@@ -56,6 +56,14 @@ struct Tail2Params {
     const float *bh;   // [NB][48]
     float *y;          // [B][ldy]: the row's probabilities first (ldy > nout when decoder columns follow, c3_decode.h)
     int B, NB, ldy;
+    // the split-K sum inside this kernel (then x is not read): x[b][k] = selu((bias4[k] pre[k] + sum_s part[s][b][k]) post[k]), the
+    // partials added in the fixed order s = 0..S-1 -- splitk_reduce_selu_kernel's arithmetic, bit for bit -- by every workgroup
+    // for its own 16 windows (the NB branch workgroups of a window group repeat it: S x 16 x FC floats each, a few hundred KB out
+    // of L2); branch 0 also leaves x in l4out for c3_debug_fetch
+    const float *part = nullptr;  // [S][B][FC]
+    const float *bias4 = nullptr, *pre = nullptr, *post = nullptr;
+    float *l4out = nullptr;
+    int S = 0;
 };
 
 template <int FC>
@@ -91,12 +99,40 @@ __global__ __launch_bounds__(256) void fc_tail_mfma_kernel(Tail2Params p) {
         hb = p.bh[br * 48 + wave * 16 + col];
     }
     // the 16 activation rows -> LDS (rows beyond B repeat the last window; their results are never written)
+    if (p.part) {
+        const int64_t total = (int64_t)p.B * FC;
+#pragma unroll
+        for (int i = 0; i < 16 * FC / 4 / 256; ++i) {
+            const int idx = tid + 256 * i;
+            const int t = idx / (FC / 4), c4 = idx - t * (FC / 4);
+            const int b = b0 + t < p.B ? b0 + t : p.B - 1;
+            const float *src = p.part + (int64_t)b * FC + 4 * c4;
+            const f32x4v b4 = *reinterpret_cast<const f32x4v *>(p.bias4 + 4 * c4);
+            const f32x4v pre = p.pre ? *reinterpret_cast<const f32x4v *>(p.pre + 4 * c4) : f32x4v{1.f, 1.f, 1.f, 1.f};
+            const f32x4v post = p.post ? *reinterpret_cast<const f32x4v *>(p.post + 4 * c4) : f32x4v{1.f, 1.f, 1.f, 1.f};
+            f32x4v v = p.pre ? b4 * pre : b4;
+            for (int s0 = 0; s0 < p.S; s0 += 8) {  // 8 independent loads in flight (the last batch clamps its surplus), summed in order
+                f32x4v tt[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tt[u] = *reinterpret_cast<const f32x4v *>(src + (int64_t)(s0 + u < p.S ? s0 + u : p.S - 1) * total);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + u < p.S) v += tt[u];
+            }
+            f32x4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = selu_f(p.post ? v[e] * post[e] : v[e]);
+            *reinterpret_cast<f32x4v *>(&xs[t][4 * c4]) = o;
+            if (br == 0 && b0 + t < p.B && p.l4out) *reinterpret_cast<f32x4v *>(p.l4out + (int64_t)b * FC + 4 * c4) = o;
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 16 * FC / 4 / 256; ++i) {
         const int idx = tid + 256 * i;
         const int t = idx / (FC / 4), c4 = idx - t * (FC / 4);
         const int b = b0 + t < p.B ? b0 + t : p.B - 1;
         *reinterpret_cast<f32x4v *>(&xs[t][4 * c4]) = *reinterpret_cast<const f32x4v *>(p.x + (int64_t)b * FC + 4 * c4);
+    }
     }
     f32x4v acc[2];
 #pragma unroll
