@@ -40,7 +40,41 @@ _RANK = {indel: _CHAIN_RANK[_KLASS[indel]] for indel in (True, False)}
 # so one gather-multiply gives the 23 of them bit for bit): the zygosity / gt21 index of every entry in list order
 _Z24 = np.array([1] * 4 + [2] * 6 + [1, 1] + [2] * 4 + [2] + [2] * 4 + [2, 2])
 _G24 = np.array(list(dec.HOMO_SNP_GT21) + list(dec.HETERO_SNP_GT21) + [15, 10] + [16, 17, 18, 19] + [15] + [11, 12, 13, 14] + [10, 20])
-_WALK_PATIENCE = 12  # rejected candidates of a row before RowPrinter._hopeless sorts out the rest of its walk
+# the entries of the nine lists in the order the loop's if / elif chain and .index() break ties: (chain rank, index).  A STABLE
+# sort of a row's values, taken in this order, by falling probability is the walk of output_from's loop
+_CHAIN = {indel: np.lexsort((_INDEX[indel], _RANK[indel])) for indel in (True, False)}
+_KLASS_C = {indel: _KLASS[indel][_CHAIN[indel]] for indel in (True, False)}
+_INDEX_C = {indel: _INDEX[indel][_CHAIN[indel]] for indel in (True, False)}
+
+
+def class_lists_of_rows(y, indel):
+    """dec.class_list for classes 1..9 laid end to end (the order of _KLASS / _INDEX), for ALL rows of ``y`` at once: (R, 804)
+    float32 with the indel-length heads, (R, 23) without.  The same float32 products in the same order and association as
+    clair3/CallVariants.py:526-659 (element-wise float32 multiplication is the same IEEE operation on a column as on a scalar), so
+    row r equals the concatenation of dec.class_list(k, ...) of that row bit for bit (tests/test_decode_dropin.py)."""
+    y = np.asarray(y, dtype=np.float32)
+    g, z = y[:, :21], y[:, 21:24]
+    if not indel:
+        return z[:, _Z24] * g[:, _G24]
+    p1, p2 = y[:, 24:57], y[:, 57:90]
+    hv, ht = z[:, 1], z[:, 2]
+    o = 16  # VariantLength.index_offset
+    c = lambda v: v[:, None]  # noqa: E731
+    v0 = p1[:, o] * p2[:, o]
+    return np.concatenate([
+        c(v0 * hv) * g[:, dec._HS],                                                  # 1 :579-581
+        c(v0 * ht) * g[:, dec._TS],                                                  # 2 :582-584
+        p1[:, o + dec._I16] * p2[:, o + dec._I16] * c(hv * g[:, 15]),                # 3 :303-308, :587-590
+        p1[:, o - dec._I16] * p2[:, o - dec._I16] * c(hv * g[:, 10]),                # 4 :331-336, :613-616
+        (c(p1[:, o]) * p2[:, o + dec._L4]) * g[:, 16 + dec._B4] * c(ht),             # 5 :311-316, :600-606
+        p1[:, o + dec._II] * p2[:, o + dec._IJ] * c(ht * g[:, 15]),                  # 6 :318-328
+        (p1[:, o - dec._L4] * c(p2[:, o])) * g[:, 11 + dec._B4] * c(ht),             # 7 :339-345, :627-633
+        p1[:, o - dec._DI] * p2[:, o - dec._DJ] * c(ht * g[:, 10]),                  # 8 :348-359
+        p1[:, o - dec._XI] * p2[:, o + dec._XJ] * c(ht * g[:, 20]),                  # 9 :362-371
+    ], axis=1)
+
+
+_CLASS_START = np.cumsum((0,) + dec._CLASS_LEN[True][1:])  # start of class k's list, laid end to end, at [k - 1]
 _PLAIN = {ord(ch): None for ch in "ACGTNacgtn,."}  # what convert_iupac_to_n leaves alone (shared/utils.py:27-40)
 
 
@@ -102,6 +136,7 @@ class RowPrinter:
         self.info = "P" if c.pileup else "F"
         self.max_len = cv.VariantLength.max
         self.taken = self.retried = self.handed_back = 0  # rows printed here / of those after rejections / rows left to output_with
+        self._dead_cache = {}
 
     # ------------------------------------------------------------------------------------------------ one pass of output_from
     def _alleles(self, cls, pos, ref, look):
@@ -330,6 +365,7 @@ class RowPrinter:
         fast = (known & ~((cls > 0) & shared)).tolist()
         cls = cls.tolist()
         out = [FALLBACK] * n
+        walks = []
         for i in range(n):
             if not fast[i]:
                 continue
@@ -348,85 +384,115 @@ class RowPrinter:
             if alleles is not None:
                 out[i] = self._row(c, alleles[0], alleles[1], prob[i], chromosome, position, depth, d)
                 continue
-            found = self._next_candidate(batch_Y[i], cols[i, 9 + bi[i]], c, pos[i], ref, look)
-            if found is FALLBACK:
-                continue
-            self.retried += 1
-            if found is None:  # nothing above the homo-reference probability is offered by the reads (:735-740)
-                out[i] = self._row(0, acgt, acgt, cols[i, 9 + bi[i]], chromosome, position, depth, d)
-            else:
-                c, alleles, p = found
-                out[i] = self._row(c, alleles[0], alleles[1], p, chromosome, position, depth, d)
+            walks.append((i, c, ref, look, chromosome, position, depth, d, acgt))
+        if walks:
+            # the rows whose first candidate the reads do not offer: their class lists in ONE pass over the batch, in chain order
+            indel = self.cfg.add_indel_length
+            idx = np.fromiter((w[0] for w in walks), dtype=np.int64, count=len(walks))
+            values = class_lists_of_rows(batch_Y[idx, :self.width], indel)[:, _CHAIN[indel]]
+            homo = cols[idx, 9 + bi[idx]]
+            above = values > homo[:, None]
+            for j, (i, c, ref, look, chromosome, position, depth, d, acgt) in enumerate(walks):
+                found = self._next_candidate(values[j], above[j], c, pos[i], ref, look)
+                if found is FALLBACK:
+                    continue
+                self.retried += 1
+                if found is None:  # nothing above the homo-reference probability is offered by the reads (:735-740)
+                    out[i] = self._row(0, acgt, acgt, homo[j], chromosome, position, depth, d)
+                else:
+                    c, alleles, p = found
+                    out[i] = self._row(c, alleles[0], alleles[1], p, chromosome, position, depth, d)
         back = sum(1 for v in out if v is FALLBACK)
         self.handed_back += back
         self.taken += n - back
         return out
 
-    def _hopeless(self, entries, look):
-        """For a row that keeps rejecting candidates: which of the walk's entries (positions in the nine lists laid end to end)
-        _alleles is certain to reject, from sixteen insertion and sixteen deletion lookups instead of one pass per entry.
-        What _alleles does per class (the line numbers there): a homo insertion / deletion and an ACGT + insertion / deletion
-        are rejected exactly when the lookup for their length comes back empty; an insertion-and-deletion when either does;
-        two insertions / two deletions are rejected exactly when the reads offer fewer than two alleles of that kind; SNPs are
-        always left to _alleles."""
-        cap = self.max_len
-        lengths = [(n if n < cap else None) for n in range(1, cap + 1)]
-        no_ins = np.array([len(look.ins(n)) == 0 for n in lengths])
-        no_del = np.array([len(look.dele(n)) == 0 for n in lengths])
-        dead = np.zeros(len(_KLASS[True]), dtype=bool)
-        o = np.cumsum((0,) + dec._CLASS_LEN[True][1:])  # start of class k's list at o[k - 1]
+    def _dead(self, d):
+        """Which entries of the nine lists laid end to end (indel-length rows) _alleles is CERTAIN to reject for a row whose
+        alt_info dictionary is ``d``, from one pass over its keys.  What _alleles does per class (the line numbers there): a
+        homo insertion / deletion and an ACGT + insertion / deletion are rejected exactly when the lookup for their length comes
+        back empty; an insertion-and-deletion when either does; two insertions / two deletions are rejected exactly when the
+        reads offer fewer than two alleles of that kind; SNPs are always left to _alleles.  And a lookup
+        (clair3/CallVariants.py:117-201, no bases to ignore) comes back empty exactly when the reads hold neither an allele of the
+        proposed length (+ the reference base for insertions; the last length, >= 16, proposes none: :783, :884) nor any allele of
+        1 .. maximum_variant_length_that_need_infer bases.  Returns (dead in list order, dead in chain order)."""
+        cap, infer = self.max_len, self.cfg.maximum_variant_length_that_need_infer
+        ilen, dlen = [], []
+        for key in d:
+            t = key[0]
+            if t == "I":
+                ilen.append(len(key) - 1)
+            elif t == "D":
+                dlen.append(len(key) - 1)
+        n_ins = sum(1 for L in ilen if 1 <= L <= infer)
+        n_del = sum(1 for L in dlen if 1 <= L <= infer)
+        # the answer depends on the dictionary only through "0, 1 or more alleles in range" per kind and -- with none in range -- the
+        # lengths of the out-of-range ones: a handful of distinct cases per job, each worked out once
+        key = (min(n_ins, 2), min(n_del, 2), tuple(sorted(set(ilen))) if n_ins == 0 else (), tuple(sorted(set(dlen))) if n_del == 0 else ())
+        hit = self._dead_cache.get(key)
+        if hit is not None:
+            return hit
+        lengths = np.arange(1, cap + 1)
+        no_ins = np.full(cap, n_ins == 0)
+        no_del = np.full(cap, n_del == 0)
+        if n_ins == 0 and ilen:
+            no_ins &= ~np.isin(lengths + 1, ilen)
+            no_ins[cap - 1] = True
+        if n_del == 0 and dlen:
+            no_del &= ~np.isin(lengths, dlen)
+            no_del[cap - 1] = True
+        o = _CLASS_START
+        dead = np.zeros(o[9], dtype=bool)
         dead[o[2]:o[3]] = no_ins                                      # 3 homo_Ins: entry = length - 1
         dead[o[3]:o[4]] = no_del                                      # 4 homo_Del
         dead[o[4]:o[5]] = np.repeat(no_ins, 4)                        # 5 hetero_ACGT_Ins: entry = 4 (length - 1) + base
         dead[o[6]:o[7]] = np.repeat(no_del, 4)                        # 7 hetero_ACGT_Del
         dead[o[8]:o[9]] = np.logical_or.outer(no_del, no_ins).ravel()  # 9 hetero_InsDel: entry = 16 (deletion - 1) + insertion - 1
-        if self.cfg.maximum_variant_length_that_need_infer >= cap + 1:
+        if infer >= cap + 1:
             # every proposed length (< 16, + the reference base for insertions) lies inside the general range of the lookups, so a
             # second allele for a proposed pair can only be one that return_multi would offer as well: with fewer than two alleles
             # of the kind in range both the proposals (:838-848, :929-944) and return_multi (:849-855, :945-950) come back short
-            if len(look.ins(None, "", True)) < 2:
+            if n_ins < 2:
                 dead[o[5]:o[6]] = True                                # 6 hetero_InsIns
-            if len(look.dele(None, "", True)) < 2:
+            if n_del < 2:
                 dead[o[7]:o[8]] = True                                # 8 hetero_DelDel
-        return dead[entries].tolist()
+        hit = self._dead_cache[key] = (dead, dead[_CHAIN[True]])
+        return hit
 
-    def _next_candidate(self, y, homo_ref, cls0, pos0, ref, look):
+    def _next_candidate(self, values, above, cls0, pos0, ref, look):
         """The passes of output_from's loop after its first candidate (class cls0, entry pos0) was rejected: -> (class,
         alleles, maximum probability) of the first candidate the reads offer, None when the loop ends on the homo-reference
         probability, FALLBACK when the accepted maximum is shared by two classes.
+        ``values``: the row's nine lists laid end to end IN CHAIN ORDER (_CHAIN), ``above``: values > the homo-reference probability.
         Each pass of the loop takes the maximum over homo_Ref and the nine lists, returns the reference call when that is
         homo_Ref (:735), else looks up the first class of the chain that holds it at its first index and zeroes that entry
-        on rejection -- i.e. it walks the entries above homo_Ref by (probability falling, chain rank, index)."""
-        c = self.cfg
-        indel = c.add_indel_length
-        g, z = y[:21], y[21:24]
-        if indel:
-            p1, p2 = y[24:57], y[57:90]
-            values = np.concatenate([dec.class_list(k, g, z, p1, p2, True) for k in range(1, 10)])
-        else:
-            values = z[_Z24] * g[_G24]
-        keep = np.nonzero(values > homo_ref)[0]
-        values = values[keep]
-        order = np.lexsort((_INDEX[indel][keep], _RANK[indel][keep], -values.astype(np.float64)))
+        on rejection -- i.e. it walks the entries above homo_Ref by (probability falling, chain rank, index): a stable sort of
+        the chain-ordered entries by falling probability."""
+        indel = self.cfg.add_indel_length
+        keep = np.flatnonzero(above)
+        v = values[keep]
+        order = np.argsort(-v, kind="stable")
         keep = keep[order]
-        values, klass, index = values[order], _KLASS[indel][keep].tolist(), _INDEX[indel][keep].tolist()
-        skip = None
-        for j in range(len(klass)):
-            k, e = klass[j], index[j]
-            if j == 0 and (k != cls0 or e != pos0):
-                return FALLBACK  # the device's first decision is not the head of the walk: leave the row to the reference
-            if skip is not None and skip[j]:
-                continue
-            alleles = None if j == 0 else self._alleles(k, e, ref, look)
+        v = v[order]
+        klass, index = _KLASS_C[indel][keep], _INDEX_C[indel][keep]
+        if len(keep) == 0 or klass[0] != cls0 or index[0] != pos0:
+            return FALLBACK  # the device's first decision is not the head of the walk: leave the row to the reference
+        if indel:  # entries no lookup can satisfy are stepped over without asking (SNP entries are never among them)
+            dead = self._dead(look.d)[1][keep]  # (in chain order, like `keep`)
+            todo = np.flatnonzero(~dead[1:]) + 1
+        else:
+            todo = range(1, len(keep))
+        klass, index = klass.tolist(), index.tolist()
+        for j in todo:
+            k = klass[j]
+            alleles = self._alleles(k, index[j], ref, look)
             if alleles is None:
-                if j == _WALK_PATIENCE and indel:
-                    skip = self._hopeless(keep, look)
                 continue
-            v = values[j]
+            p = v[j]
             t = j + 1
-            while t < len(klass) and values[t] == v:  # untried entries with the same probability: flags of other classes (:742-750)
+            while t < len(klass) and v[t] == p:  # untried entries with the same probability: flags of other classes (:742-750)
                 if klass[t] != k:
                     return FALLBACK
                 t += 1
-            return k, alleles, v
+            return k, alleles, p
         return None

@@ -258,10 +258,32 @@ def test_output_modes_and_odd_inputs(indel, ref):
     assert sink.output_file.getvalue() == unpatched(pos, alt, y, cfg, None)
 
 
-def test_hopeless_entries_are_exactly_the_ones_the_lookup_rejects(ref):
-    """RowPrinter._hopeless (the shortcut of a long rejection walk) against RowPrinter._alleles entry by entry, on alt_info
+@pytest.mark.parametrize("indel", [True, False])
+def test_class_lists_of_a_whole_batch_are_the_per_row_lists(indel):
+    """vcf_rows.class_lists_of_rows (every class list of every row of a batch in one pass) against decode.class_list row by row,
+    which the test above pins to the reference's lists: the same bits, laid end to end in class order"""
+    from clair3_amd import decode, vcf_rows
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "decode_indel.npz" if indel else "decode_noindel.npz"))
+    rng = np.random.default_rng(5)
+    extra = rng.random((64, g["y"].shape[1])).astype(np.float32) ** 6  # peaky rows, many near-zero products (subnormals included)
+    y = np.concatenate([g["y"], extra])
+    got = vcf_rows.class_lists_of_rows(y, indel)
+    assert got.dtype == np.float32 and got.shape == (len(y), len(vcf_rows._KLASS[indel]))
+    for r, row in enumerate(y):
+        p1, p2 = (row[24:57], row[57:90]) if indel else (0, 0)
+        want = np.concatenate([np.asarray(decode.class_list(k, row[:21], row[21:24], p1, p2, indel), dtype=np.float32) for k in range(1, 10)])
+        assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), r
+    # and the chain order is the (chain rank, index) order the walk's stable sort relies on
+    c = vcf_rows._CHAIN[indel]
+    keys = list(zip(vcf_rows._RANK[indel][c].tolist(), vcf_rows._INDEX[indel][c].tolist()))
+    assert keys == sorted(keys)
+
+
+def test_dead_entries_are_exactly_the_ones_the_lookup_rejects(ref):
+    """RowPrinter._dead (the entries a rejection walk steps over without asking, read off the key lengths of the row's alt_info
+    dictionary) against RowPrinter._alleles -- i.e. the reference's own lookups -- entry by entry, on alt_info
     dictionaries with no / one / several insertions and deletions of every length, lengths beyond the inference range included:
-    an entry of classes 3-9 is marked hopeless exactly when the per-entry lookup rejects it"""
+    an entry of classes 3-9 is marked dead exactly when the per-entry lookup rejects it"""
     from clair3_amd import decode, vcf_rows
     cv, _ = ref
     cfg = config(cv, False, True)
@@ -279,8 +301,8 @@ def test_hopeless_entries_are_exactly_the_ones_the_lookup_rejects(ref):
         if trial % 3 == 0:
             d["XC"] = 5
         d["RA"] = 9
-        look = vcf_rows._Lookups(cv, d, cfg.maximum_variant_length_that_need_infer)
-        dead = pr._hopeless(np.arange(n_entries), look)
+        dead = pr._dead(d)[0]
+        assert np.array_equal(pr._dead(d)[1], dead[vcf_rows._CHAIN[True]])
         for e in range(n_entries):
             k, pos = int(vcf_rows._KLASS[True][e]), int(vcf_rows._INDEX[True][e])
             if k <= 2:
