@@ -36,7 +36,19 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
         m = re.search(r"Total time elapsed: ([0-9.]+) s", log)
         assert rc == 0 and f"Total processed positions : {n}" in log, log[-2000:]
         res[tag] = {"loop_seconds": float(m.group(1)), "process_wall_seconds": round(wall, 2), "windows_per_s_in_the_loop": round(n / float(m.group(1)))}
-    res["vcf_identical"] = refloop.compare_vcfs(os.path.join(d, "libc3hip.vcf"), os.path.join(d, "reference_modules_pytorch.vcf"))["identical_text"]
+    # libc3hip's VCF against the reference modules' (PyTorch): identical text, rows whose QUAL / GQ differ in the last digit
+    # (probabilities that agree to ~1e-6 on either side of a rounding boundary) and rows whose CALL differs -- each of those
+    # listed, so that a near-tie can be told from a defect (tests/test_reference_loop_gpu.py proves near-ties record by record)
+    cmp_ = refloop.compare_vcfs(os.path.join(d, "libc3hip.vcf"), os.path.join(d, "reference_modules_pytorch.vcf"))
+    res["vcf_identical"] = cmp_["identical_text"]
+    res["vcf_records"] = [cmp_["records_a"], cmp_["records_b"]]
+    res["vcf_qual_last_digit_only"] = cmp_["qual_only"]
+    res["vcf_max_qual_diff"] = cmp_["max_qual_diff"]
+    res["vcf_call_differs"] = [[list(k), a, b] for k, a, b in cmp_["call_differs"][:20]]
+    res["vcf_only_in_one"] = [cmp_["only_a"], cmp_["only_b"]]
+    if indel:
+        cmp2 = refloop.compare_vcfs(os.path.join(d, "libc3hip_decoder_columns.vcf"), os.path.join(d, "libc3hip.vcf"))
+        res["vcf_decoder_columns_vs_plain_identical"] = [cmp2["identical_text"], cmp2["records_a"], cmp2["records_b"]]
     out[name] = {"windows": n, "tensor_files": files, "cpu_threads": threads, **res}
     print(name, json.dumps(out[name]), flush=True)
 print(json.dumps(out))
