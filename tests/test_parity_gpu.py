@@ -4,6 +4,7 @@
   * size-independent properties at the full BASELINE.json sizes.
 Gate (BASELINE.json north_star): probabilities within 1e-4 (fp32), genotype/zygosity labels identical.
 """
+import os
 import time
 
 import numpy as np
@@ -42,6 +43,18 @@ def test_extension_is_loaded_and_sees_the_gpu():
     assert _lib.device_count() >= 1
     free_b, total_b = _lib.mem_info(0)
     assert total_b > 100 * 2 ** 30 and 0 < free_b <= total_b  # 288 GB HBM3E part
+
+
+def test_the_binary_on_this_box_was_built_from_this_tree():
+    """libc3hip.so is git-ignored and travels to the GPU box prebuilt: c3_version() carries a hash of the sources it was compiled
+    from (clair3_amd/build.py source_hash), so a stale binary cannot pass the GPU suite against newer sources unnoticed; and
+    the library mapped into THIS process is the in-tree one (not a copy in site-packages)"""
+    from clair3_amd import build
+    version = _lib.lib().c3_version().decode()
+    assert "gfx950" in version and ("srchash:" + build.source_hash()) in version, (version, build.source_hash())
+    with open("/proc/self/maps") as f:
+        mapped = {line.split()[-1] for line in f if "libc3hip.so" in line}
+    assert mapped == {os.path.realpath(_lib.LIB_PATH)}, mapped
 
 
 @pytest.mark.parametrize("name", CASES)
