@@ -19,7 +19,10 @@ files = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 ref = refloop.reference_root()
 out = {}
+only = os.environ.get("C3_WT_ONLY")  # "pileup" / "full_alignment": one of the two jobs
 for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMENT, 8, True, False), ("pileup", syn.PILEUP, 18, False, True)):
+    if only and only != name:
+        continue
     d = tempfile.mkdtemp(prefix="c3_worker_")
     n = per_file * files * (3 if pileup else 1)
     lst = refloop.write_job(d, kind, [per_file * (3 if pileup else 1)] * files, channels=channels)
@@ -46,6 +49,12 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
     res["vcf_max_qual_diff"] = cmp_["max_qual_diff"]
     res["vcf_call_differs"] = [[list(k), a, b] for k, a, b in cmp_["call_differs"][:20]]
     res["vcf_only_in_one"] = [cmp_["only_a"], cmp_["only_b"]]
+    if cmp_["call_differs"]:
+        # every differing call must be a near-tie of the reference's own joint outcome probabilities -- the proof of
+        # tests/test_reference_loop_gpu.py (reference module on the CPU and the library on the GPU on the loop's own batch)
+        from tests.test_reference_loop_gpu import explain_call_differences, file_window
+        job = dict(ck=ck, kind=kind, channels=channels, indel=indel, window=file_window(d, [per_file * (3 if pileup else 1)] * files))
+        res["vcf_call_differs_explained"] = explain_call_differences(job, cmp_["call_differs"], ref)
     if indel:
         cmp2 = refloop.compare_vcfs(os.path.join(d, "libc3hip_decoder_columns.vcf"), os.path.join(d, "libc3hip.vcf"))
         res["vcf_decoder_columns_vs_plain_identical"] = [cmp2["identical_text"], cmp2["records_a"], cmp2["records_b"]]
