@@ -47,7 +47,12 @@ CASES = [
     ("fa_trained_like", syn.FULL_ALIGNMENT, 8, True, 6, True, 6, "realistic", 16, "int8"),
     ("fa_dwell_trained_like", syn.FULL_ALIGNMENT, 9, True, 7, False, 7, "realistic", 8, "int8"),
     ("pileup_trained_like", syn.PILEUP, 18, False, 8, True, 8, "realistic", 32, "int8"),
+    # the BASELINE.json sizes themselves (configs[1] / configs[2]: B = 1024 pileup, B = 256 full alignment): the rows of the real
+    # reference modules for every window of the benchmark batches' shapes; Y_ref only (no .info / VCF strings for these)
+    ("pileup_baseline_1024", syn.PILEUP, 18, False, 9, False, 9, "realistic", 1024, "int8"),
+    ("fa_baseline_256", syn.FULL_ALIGNMENT, 8, True, 10, False, 10, "realistic", 256, "int8"),
 ]
+BASELINE_SIZE = {"pileup_baseline_1024", "fa_baseline_256"}
 TRAINED_LIKE = {"fa_trained_like", "fa_dwell_trained_like", "pileup_trained_like"}
 # matrix depth of the full-alignment cases that are not ONT (shared/param_f.py:11: hifi / ilmn = 55 rows)
 DEPTH = {"fa_hifi_depth55": 55}
@@ -139,21 +144,30 @@ def reference_decode(kind, indel, y, pos, alt):
 def main():
     torch.set_num_threads(1)
     manifest = {}
+    only = None  # `--only name,name`: (re)generate just these cases and keep every other entry of the manifest as it is
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
     for case in CASES:
         name, kind, ch, indel, wseed, peaked, xseed, recipe, batch, xdt = case
+        if only is not None and name not in only:
+            continue
         sd, x = case_inputs(case)
         y = reference_forward(kind, ch, indel, sd, x)
         out = {"y_ref": y.astype(np.float32)}
-        pos, alt = synthetic_info(batch, seed=1000 + xseed)
-        try:
-            rows = reference_decode(kind, indel, y, pos, alt)
-        except Exception as e:  # decode goldens are a "next" row; never block the model goldens on them
-            print(f"[warn] reference batch_output failed for {name}: {e!r}")
-            rows = ""
+        pos, alt, rows = [], [], ""
+        if name not in BASELINE_SIZE:
+            pos, alt = synthetic_info(batch, seed=1000 + xseed)
+            try:
+                rows = reference_decode(kind, indel, y, pos, alt)
+            except Exception as e:  # decode goldens are a "next" row; never block the model goldens on them
+                print(f"[warn] reference batch_output failed for {name}: {e!r}")
+                rows = ""
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
         manifest[name] = dict(kind=kind, channels=ch, add_indel_length=indel, weight_seed=wseed, peaked=peaked,
                               input_seed=xseed, recipe=recipe, batch=batch, x_dtype=xdt, x_sha=digest(x),
-                              trained_like=name in TRAINED_LIKE,
+                              trained_like=name in TRAINED_LIKE, baseline_size=name in BASELINE_SIZE,
                               depth=(int(x.shape[1]) if kind == syn.FULL_ALIGNMENT else None),
                               sd_sha=sd_digest(sd), y_sha=digest(y), positions=pos, alt_info=alt, vcf_rows=rows,
                               torch=torch.__version__)
