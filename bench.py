@@ -105,8 +105,11 @@ def run_workload(name, args, rank, world, local):
     kind, batch, channels, indel, flop_w, bytes_w, cfg = WORKLOADS[name]
     if args.batch:
         batch = args.batch
+    if os.environ.get("C3_BENCH_DEVICE"):  # every rank on ONE device: the N > 1 code path on a one-GPU box (tests/test_comm_gpu.py), never a measurement
+        local = int(os.environ["C3_BENCH_DEVICE"])
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    ctl = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")  # where the tensors of control-plane collectives live
     model, sd = build_model(kind, channels, indel, local)
     x_host = syn.make_windows(kind, batch, seed=1000 + rank, channels=channels)
     x = torch.from_numpy(x_host).to(dev)  # inputs resident in HBM before the timed region
@@ -180,7 +183,7 @@ def run_workload(name, args, rank, world, local):
             fence()
             elapsed = time.perf_counter() - t0
             if world > 1:
-                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed = float(t.item())
             blocks.append(elapsed)
@@ -210,7 +213,7 @@ def run_workload(name, args, rank, world, local):
     elapsed, in_flight, own = (multi, S, multi_own) if multi <= single else (single, 1, single_own)
     per_rank = None
     if world > 1:  # every rank's own K-step time (before the MAX), so the driver can see N ranks at work
-        t = torch.tensor([med(own)], dtype=torch.float64, device=dev)
+        t = torch.tensor([med(own)], dtype=torch.float64, device=ctl)
         parts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         per_rank = [batch * args.steps / float(p.item()) for p in parts]

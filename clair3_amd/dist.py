@@ -31,7 +31,10 @@ def init_from_env(backend=None):
         import torch.distributed as dist
         if not dist.is_initialized():
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # C3_DIST_BACKEND: the control plane of a job whose ranks cannot form an RCCL group of their own -- the two-ranks-on-one-GPU
+                # arrangement of tests/test_comm_gpu.py (real RCCL refuses two ranks on one device); the rows then still travel on
+                # c3_gather_rows (RowExchange), everything else on gloo
+                backend = os.environ.get("C3_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend == "nccl":
@@ -124,6 +127,11 @@ def gather_counts(y_local, counts, dst=0):
     world, rank = dist.get_world_size(), dist.get_rank()
     if y_local.shape[0] != counts[rank]:
         raise ValueError(f"rank {rank} holds {y_local.shape[0]} rows, expected {counts[rank]}")
+    home = y_local.device
+    if y_local.is_cuda and dist.get_backend() != "nccl":  # device rows under a host control plane (gloo): the fallback goes through the host
+        y_local = y_local.cpu()
+        out = gather_counts(y_local, counts, dst=dst)
+        return out.to(home) if out is not None else None
     width, pad = y_local.shape[1], max(max(counts), 1)
     send = torch.zeros((pad, width), dtype=y_local.dtype, device=y_local.device)
     send[: y_local.shape[0]] = y_local
@@ -279,9 +287,11 @@ class RowExchange:
             self.fallback_reason = "rows are not on GPUs"
 
     def _cuda_job(self):
+        """rows live on GPUs (the direct path moves device memory): a GPU job under torch.distributed -- whatever carries the
+        control plane (the id broadcast and the agreement all-reduce use host tensors when the backend is not nccl)"""
         import torch
         import torch.distributed as dist
-        return torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+        return torch.cuda.is_available() and dist.is_initialized()
 
     def _all_ok(self, ok):
         """every rank learns whether EVERY rank succeeded (one 1-element all-reduce on the control plane)"""

@@ -97,3 +97,30 @@ def test_two_ranks_gather_rows_over_the_send_recv_path(tmp_path):
     m.load_state_dict(sd)
     single = job.run_job(m, lst, batch_size=100)
     assert y.shape == (n, 90) and np.array_equal(y, single["rows"])
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` -- the command the driver's scaling run uses, launched the way it launches it -- executes end to end with
+    two ranks on the lease's ONE device: gloo as the control plane (C3_DIST_BACKEND), both ranks on device 0 (C3_BENCH_DEVICE), the
+    rows of every 8 steps gathered to rank 0 on c3_gather_rows through the stand-in for librccl.  Not a measurement (two ranks
+    share one GPU): what is checked is that the N > 1 path runs -- barriers, the MAX over ranks, the guarded first gather, the
+    per-rank rates -- and prints the one parseable line with the gather on the direct path."""
+    import json
+    env = dict(os.environ, C3HIP_RCCL_LIB=_stub(), C3_DIST_BACKEND="gloo", C3_BENCH_DEVICE="0", OMP_NUM_THREADS="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", C3_BENCH_FULL=str(tmp_path / "full.json"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "9", "--warmup", "2",
+           "--repeats", "2", "--workload", "full_alignment"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert len(lines[0]) <= 4096
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 9
+    assert line["config"]["windows_per_step"] == 512 and line["value"] > 0
+    assert abs(line["value"] - 512 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3  # whole-job windows / MAX-over-ranks time
+    mg = line["multi_gpu"]
+    assert mg["gather"] == "rccl_direct" and mg["rccl_ranks_seen"] == 2 and mg["ranks"] == 2, mg
+    assert len(mg["per_rank_windows_per_s"]) == 2 and all(v > 0 for v in mg["per_rank_windows_per_s"])
+    assert "roofline" in line and "cpu_baseline" not in line  # the CPU baseline is an N = 1 leg
