@@ -95,6 +95,7 @@ struct RcclApi {
 struct c3_comm {
     ncclComm_t nccl = nullptr;  // null when world == 1
     int rank = 0, world = 1, device = 0;
+    bool aborted = false;  // c3_comm_abort: from then on a world of one, whatever rank the caller still names as destination
 };
 
 extern "C" {
@@ -155,6 +156,7 @@ int c3_comm_destroy(c3_comm *c) {
 
 int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int64_t *counts, float *all_dev, int dst, void *stream) {
     if (!c || !counts) return fail("null argument");
+    if (c->aborted) dst = 0;  // (the caller's destination rank no longer exists: the gather of an aborted communicator is the local copy)
     if (dst < 0 || dst >= c->world || row_floats <= 0) return fail("bad arguments (dst %d of %d ranks, %d floats per row)", dst, c->world, row_floats);
     for (int r = 0; r < c->world; ++r)
         if (counts[r] < 0) return fail("negative row count for rank %d", r);
@@ -217,7 +219,7 @@ int c3_comm_abort(c3_comm *c) {
         RcclApi &r = RcclApi::get();
         const ncclResult_t rc = r.CommAbort(c->nccl);
         c->nccl = nullptr;
-        c->world = 1, c->rank = 0;  // whatever is asked of this handle from now on is local: a world of one, whose only rank is 0
+        c->world = 1, c->rank = 0, c->aborted = true;  // whatever is asked of this handle from now on is local: a world of one, whose only rank is 0
         if (rc != ncclSuccess) return fail("ncclCommAbort failed: %s", r.GetErrorString(rc));
     }
     return 0;
