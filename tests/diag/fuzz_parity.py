@@ -51,7 +51,11 @@ while time.time() < t_end:
         y_t = torch_port.forward(kind, torch_port.to_torch(sd), x[idx], indel).numpy()
         err_t = float(np.abs(y_t - y_o).max())
         if err <= 3.0 * err_t + 2e-5:
-            print(f"sensitive window: kind={kind} n={n} seed={seed} weights={flags}: |dY| {err:.2e}, fp32 PyTorch itself {err_t:.2e} from the oracle", flush=True)
+            # the contract's own distance: against the fp32 rows of the reference arithmetic (torch_port = the ATen operators the
+            # reference modules call), next to both distances from the exact (fp64) rows
+            err_ref = float(np.abs(y[idx] - y_t).max())
+            print(f"sensitive window: kind={kind} indel={indel} n={n} seed={seed} recipe={recipe} weights={flags}: |Y_hip - Y_exact| {err:.2e}, "
+                  f"|Y_fp32_pytorch - Y_exact| {err_t:.2e}, |Y_hip - Y_fp32_pytorch| {err_ref:.2e} (the 1e-4 gate of the contract is on this one)", flush=True)
             n_sensitive += 1
             err = 0.0
     if not (err < 1e-4) or not np.isfinite(y).all() or not lab:
