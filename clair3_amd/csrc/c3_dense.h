@@ -1,8 +1,5 @@
 // c3_dense.h -- C = A (plane activations, c3_conv3.h) x W^T + bias on v_mfma_f32_32x32x16_f16, fp16x3 products.
 //
-//   dense_planes_glds_kernel   the two stride-2 convolutions of Clair3_F (conv3, conv5; clair3/model.py:382-387) as implicit
-//                              GEMMs on plane activations, 128 x 128 tiles, both operands streaming global -> LDS (LDS-DMA) in
-//                              64-channel chunks; epilogue of the plane pipeline (bias, ReLU, split into fp16 pieces, range flag);
 //   dense_planes_wres_kernel   the LSTM2 input projection of Clair3_P (clair3/model.py:96-107,132-133: gx2 = h1 W_ih2^T + b_ih +
 //                              b_hh for both directions at once; M = 33 B rows of 256 features -> 1280 gate pre-activations)
 //                              with its weights resident in registers (K = 256);
@@ -13,7 +10,8 @@
 // Common ground: LSTM1 / the convolutions write their outputs as planes (hi / lo fp16 pieces, 64-channel slabs of 256 B), so
 // both operands reach LDS as plain 16-byte copies; one workgroup (512 threads = 8 waves) per CU, persistent; fragment reads
 // run one k-step ahead of the matrix instructions (pinned order, as in conv3x3_planes_kernel).
-// tools/dense_probe.hip times all three on their shapes with parts switched off (the ABL template bits).
+// tools/dense_probe.hip times both on their shape (and the stride-2 convolutions of c3_conv3s2.h, which ran on a third kernel of this
+// family -- both operands through LDS-DMA -- until round 4) with parts switched off (the ABL template bits).
 #pragma once
 #include "c3_conv3.h"
 
@@ -24,18 +22,14 @@ constexpr int kDnABytes = kDnBM * kPlRowB, kDnBBytes = kDnBN * kPlRowB;  // one 
 constexpr int kDnStage = kDnABytes + kDnBBytes;                           // 69 632 B; two stages
 
 struct DensePlanesParams {
-    const void *a;      // plane activations [M][K/64][hi 64 | lo 64] fp16   (convolution: [B][Hin][Win][Cin/64][hi | lo])
+    const void *a;      // plane activations [M][K/64][hi 64 | lo 64] fp16
     const void *w;      // [N/128][K/64][128 rows][16 pieces of 16 B]: pieces 0-7 = hi of k 8g..8g+7 of the chunk, 8-15 = lo; times 2^s
-                        // (convolution: k chunk kc = tap * (Cin/64) + slab, tap = kh * 3 + kw)
     const float *bias;  // [N]
-    float *c;           // [M][N] fp32   (convolution: plane activations [M][N/64][hi | lo], bias + ReLU)
+    float *c;           // [M][N] fp32
     const float *post;  // [N] 2^-k of every output row / channel: its weights are packed times 2^k (c3_pack.h row_scales)
     int M, N, K;
     int tiles_n, tiles;  // N / 128, ceil(M / 128) * tiles_n
-    // dense_planes_glds_kernel: 3x3 / pad 1 / stride `stride` convolution as an implicit GEMM, M = B * Ho * Wo output pixels, K = 9 * Cin
-    int Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0, stride = 1;
     uint32_t *range_flag = nullptr;
-    uint32_t mg_hw = 0, mg_w = 0;  // fast_div magics of Ho * Wo and Wo (c3_gemm.h)
 };
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -231,256 +225,6 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_pipe_kernel(DenseP
         v += G;
         if (v < p.tiles) tile_mn(v, m0, tn);
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// dense_planes_glds_kernel -- the stride-2 convolutions with both operand streams going global -> LDS DIRECTLY (LDS-DMA:
-// `buffer_load_dwordx4 ... offen lds`), no staging registers and no ds_write.
-//
-// Why: with both operands staged through registers (the pipe kernel above, which these layers ran on until round 3) a
-// 64-channel chunk is 64 KB of ds_write_b128, and a wave's ds_write_b128 occupies the LDS store path for 13 cycles
-// (MI355X_MICROARCH.md, LDS table) -- 8 waves x 8 stores x 13 = 832 cycles per chunk, next to 768 cycles of fragment reads, for
-// 1536 cycles of matrix work per SIMD.  An LDS-DMA load writes its wave's 1 KiB at full width and uses neither the store path
-// nor a register.  What the hardware dictates (tools/glds_probe.hip): lane L's 16 bytes land at [M0 + 16 L] -- lane-linear,
-// whatever the lane's source address -- and a lane whose buffer offset is out of range writes zeros (= the padding taps).  So
-// the LDS image cannot be padded; rows are 256 B apart and the 16-byte piece q of row r is kept at slot q ^ (r & 15) instead (the
-// involution is applied to the SOURCE address by the loading lane and to the read address by the reading lane): the
-// ds_read_b128 of 16 consecutive rows covers all 64 banks once.  Two stages of 64 KB; the eight requests of chunk g + 1 are
-// issued in the first two k-steps of chunk g and waited for (vmcnt(0)) at the chunk's one barrier.  Same chunk order, same
-// products per accumulator as the register-staged form: bit-identical outputs.
-// Measured (tools/dense_probe.hip, B = 256; conv3 / conv5): register-staged 34.0 / 32.6 us, this kernel 31.6 / 29.9 us.  What is
-// left, by ablation: the matrix instructions alone (with the epilogue) take 20.2 / 19.5 us; the requests alone, never waited
-// for, 21.7 / 17.6 us -- 244 / 283 MB per launch out of L2 at ~16 TB/s, i.e. the L2 -> LDS stream of a 128 x 128 tile (96 FLOP per
-// byte) is as long as its matrix work, and the two share the LDS (64 KB of DMA writes next to 192 KB of fragment reads per
-// chunk); the wait itself costs 1.7 us, the epilogue 6 / 3 us.  Only fewer bytes per FLOP would move it: 256 x 128 tiles would
-// take 25 % off the stream, but conv5 has exactly 240 tiles of 128 x 128 for 256 CUs and conv3's 207 tiles of 256 rows would
-// fill 81 % of the chip -- what its 414 tiles in two rounds do today.
-constexpr int kGlRow = 256, kGlOp = kDnBM * kGlRow, kGlStage = 2 * kGlOp;  // 65 536 B per stage: A rows, then W rows
-
-// ABL (tools/dense_probe.hip only; 0 in the product): 1 no DMA requests inside the chunk loop, 2 no wait for them at the barrier,
-// 4 no matrix instructions, 8 no fragment reads, 16 no epilogue, 32 no barriers.
-template <int ABL = 0>
-__global__ __launch_bounds__(kDnThreads, 2) void dense_planes_glds_kernel(DensePlanesParams p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * kGlStage + 4096];
-    float *bias_lds = reinterpret_cast<float *>(smem + 2 * kGlStage);  // N <= 512 output channels
-    float *post_lds = bias_lds + 512;
-    for (int i = threadIdx.x; i < p.N && i < 512; i += kDnThreads) bias_lds[i] = p.bias[i], post_lds[i] = p.post[i];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 64 x 32 outputs each
-    const int frow = lane & 31, kh = lane >> 5;
-    const int NK = p.K / 64;
-    const int G = gridDim.x;
-    const int rowb = p.Cin * 4;  // bytes per input pixel
-    const int nsin = p.Cin / 64;
-
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(p.a), 0, (uint32_t)((int64_t)(p.M / (p.Ho * p.Wo)) * p.Hin * p.Win * rowb), 0x00020000);
-    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, (uint32_t)((int64_t)p.M * p.N * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, (uint32_t)((int64_t)p.N * p.K * 4), 0x00020000);
-
-    // DMA geometry: instruction j of this wave fills rows 16 wave + 4 j .. + 3 of an operand (1 KiB); lane L is slot L & 15 of row
-    // 16 wave + 4 j + (L >> 4) and fetches the piece that belongs there: (L & 15) ^ (row & 15)
-    const int drow = lane >> 4;  // row inside the instruction's four
-    int rbase[4] = {0, 0, 0, 0};
-    uint32_t rmask[4] = {0u, 0u, 0u, 0u};
-    auto row_info = [&](int m0) __attribute__((always_inline)) {
-        const int hw = p.Ho * p.Wo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + 16 * wave + 4 * j + drow;
-            uint32_t mk = 0;
-            int base = 0;
-            if (m < p.M) {
-                const int b = fast_div(m, p.mg_hw), rem = m - b * hw;
-                const int oh = fast_div(rem, p.mg_w), ow = rem - oh * p.Wo;
-                const int ih0 = oh * p.stride - 1, iw0 = ow * p.stride - 1;
-                base = ((b * p.Hin + ih0) * p.Win + iw0) * rowb;
-                mk = tap_mask9(ih0, iw0, p.Hin, p.Win);
-            }
-            rbase[j] = base, rmask[j] = mk;
-        }
-    };
-    auto tile_mn = [&](int v, int &m0, int &tn) __attribute__((always_inline)) {
-        const int tile = xcd_tile_index(v, p.tiles);
-        const int tm = tile / p.tiles_n;
-        tn = tile - tm * p.tiles_n;
-        m0 = tm * kDnBM;
-    };
-    typedef void __attribute__((address_space(3))) *lds_ptr;
-    // request instruction j (A rows and W rows 16 wave + 4 j ..) of chunk kc of tile (m0 implied by rbase / rmask, tn) into `stage`
-    auto dma1 = [&](int j, int tn, int kc, bool on, int stage) __attribute__((always_inline)) {
-        const int r16 = 4 * j + drow;                       // row & 15 (16 wave is a multiple of 16)
-        const uint32_t piece = (uint32_t)((lane & 15) ^ r16) * 16u;
-        const int tap = kc / nsin, slab = kc - tap * nsin;
-        const int kh3 = tap / 3, kw3 = tap - 3 * kh3;
-        const uint32_t aoff = (on && ((rmask[j] >> tap) & 1u)) ? (uint32_t)(rbase[j] + (kh3 * p.Win + kw3) * rowb + slab * 256) + piece : kPlOob;
-        const uint32_t woff = on ? (uint32_t)(((tn * NK + kc) * kDnBN + 16 * wave + r16) * 256) + piece : kPlOob;
-        char *dst = smem + stage * kGlStage + (16 * wave + 4 * j) * kGlRow;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr)dst, 16, aoff, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(dst + kGlOp), 16, woff, 0, 0, 0);
-    };
-    auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
-        if constexpr (ABL & 4) {
-            c[0] += __uint_as_float(w[0] ^ x[0]), c[5] += __uint_as_float(w[3] ^ x[3]);
-            return c;
-        } else {
-            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
-        }
-    };
-    // fragment addresses: logical piece q (hi: 2 ks + kh, lo: 8 + 2 ks + kh) of row R sits at slot q ^ (R & 15); R & 15 = frow & 15
-    // for every row this lane reads.  Eight addresses per operand (stage 0); the stage bit is flipped in place at chunk ends.
-    uint32_t va[4][2], vw[4][2];
-    {
-        const int x = frow & 15;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t slot = (uint32_t)(((8 * h + 2 * ks + kh) ^ x) * 16);
-                va[ks][h] = (uint32_t)((wm * 64 + frow) * kGlRow) + slot;            // second row block: + 32 rows (immediate)
-                vw[ks][h] = (uint32_t)(kGlOp + (wn * 32 + frow) * kGlRow) + slot;
-            }
-    }
-
-    int v = blockIdx.x;
-    if (v >= p.tiles) return;
-    int m0, tn;
-    tile_mn(v, m0, tn);
-    row_info(m0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dma1(j, tn, 0, true, 0);
-    int vq = v, tnq = tn, kq = 0;  // (tile, chunk) of the chunk in flight / requested last
-    auto advance = [&]() __attribute__((always_inline)) {  // -> the chunk after (vq, kq); returns whether it exists
-        if (++kq == NK) {
-            kq = 0, vq += G;
-            if (vq < p.tiles) {
-                int m0q;
-                tile_mn(vq, m0q, tnq);
-                row_info(m0q);
-            }
-        }
-        return vq < p.tiles;
-    };
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    int g = 0;  // chunks done: the current chunk sits in stage g & 1
-    float omax = 0.f;
-    f32x16 acc[2];
-    auto chunk = [&](bool first) __attribute__((always_inline)) {
-        const bool req = advance();  // the next chunk is requested during this one, into the other stage
-        const int nstage = (g + 1) & 1;
-        pl_u32x4 xh[2][2], xl[2][2], wh[2], wl[2];
-        auto frags = [&](int ks, int st) __attribute__((always_inline)) {
-            if constexpr (ABL & 8) {
-                const pl_u32x4 f = {va[ks][0], vw[ks][1], 0x3c003c00u, 0x3c003c00u};
-                wh[st] = wl[st] = xh[st][0] = xh[st][1] = xl[st][0] = xl[st][1] = f;
-                return;
-            }
-            wh[st] = *reinterpret_cast<const pl_u32x4 *>(smem + vw[ks][0]);
-            wl[st] = *reinterpret_cast<const pl_u32x4 *>(smem + vw[ks][1]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(smem + va[ks][0] + i * 32 * kGlRow);
-                xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(smem + va[ks][1] + i * 32 * kGlRow);
-            }
-        };
-        frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int st = ks & 1;
-            if (ks < 3) frags(ks + 1, st ^ 1);
-            // the next chunk's eight requests in the first two k-steps: two k-steps of matrix work for them to land in (two requests
-            // per k-step measured 1.7 us slower per launch, all eight in the first 0.9 us slower)
-            if constexpr (!(ABL & 1))
-                if (ks < 2) dma1(2 * ks, tnq, kq, req, nstage), dma1(2 * ks + 1, tnq, kq, req, nstage);
-            __builtin_amdgcn_sched_barrier(0);
-            if (first && ks == 0) {
-                f32x16 zero;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) zero[e] = 0.f;
-                acc[0] = mma(zero, wh[st], xl[st][0]);
-                acc[1] = mma(zero, wh[st], xl[st][1]);
-            } else {
-                acc[0] = mma(acc[0], wh[st], xl[st][0]);
-                acc[1] = mma(acc[1], wh[st], xl[st][1]);
-            }
-            acc[0] = mma(acc[0], wl[st], xh[st][0]);
-            acc[1] = mma(acc[1], wl[st], xh[st][1]);
-            acc[0] = mma(acc[0], wh[st], xh[st][0]);
-            acc[1] = mma(acc[1], wh[st], xh[st][1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // this wave's reads of the stage are done and its DMA pieces of the next chunk have landed; behind the barrier
-        // everybody's have
-        if constexpr (ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) va[ks][h] ^= (uint32_t)kGlStage, vw[ks][h] ^= (uint32_t)kGlStage;
-        ++g;
-    };
-    // the finished tile leaves through the stage its last chunk occupied ((g - 1) & 1: its readers are behind the barrier, and
-    // the chunk in flight lands in the other stage): 128 rows x 512 B of fp32, the 16-byte unit u of row r at u ^ (r & 31)
-    auto epilogue = [&](int pm0, int ptn) __attribute__((always_inline)) {
-        const int cb0 = wn * 32 + 4 * kh;
-        char *stg = smem + ((g - 1) & 1) * kGlStage;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + ptn * kDnBN + cb0 + 8 * q);
-                const f32x4 sv = *reinterpret_cast<const f32x4 *>(post_lds + ptn * kDnBN + cb0 + 8 * q);
-                f32x4 val = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], sv[e], bv[e]);
-                const int r = wm * 64 + i * 32 + frow, u = (cb0 + 8 * q) >> 2;
-                *reinterpret_cast<f32x4 *>(stg + r * 512 + ((u ^ frow) << 4)) = val;
-            }
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = tid + kDnThreads * j;
-            const int r = idx >> 4, c8 = idx & 15;  // row of the tile, group of 8 columns
-            const int m = pm0 + r;
-            f32x4 a = *reinterpret_cast<const f32x4 *>(stg + r * 512 + (((2 * c8) ^ (r & 31)) << 4));
-            f32x4 b = *reinterpret_cast<const f32x4 *>(stg + r * 512 + (((2 * c8 + 1) ^ (r & 31)) << 4));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[e] = __int_as_float(max(__float_as_int(a[e]), 0));  // ReLU on the bit pattern
-                b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
-            }
-            omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-            u32x2 pa[2], pb[2];
-            split2_f16(a, pa);
-            split2_f16(b, pb);
-            const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
-            const int n = ptn * kDnBN + c8 * 8;  // channel: slab n >> 6, hi piece at 2 (n & 63), lo piece 128 bytes further
-            const uint32_t off = m < p.M ? (uint32_t)m * (uint32_t)(p.N * 4) + (uint32_t)((n >> 6) * 256 + (n & 63) * 2) : kPlOob;
-            __builtin_amdgcn_raw_buffer_store_b128(hi, crsrc, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(lo, crsrc, off + 128, 0, 0);
-        }
-        lds_barrier();  // the staged tile has been read: the DMA of the chunk after next may overwrite it
-    };
-    for (;;) {
-        chunk(true);
-        for (int kc = 1; kc < NK; ++kc) chunk(false);
-        if constexpr (ABL & 16) {
-            if (acc[0][0] == 12345.f && acc[1][3] == 1.f) omax = 1e30f;  // keep the accumulators alive
-        } else {
-            epilogue(m0, tn);
-        }
-        v += G;
-        if (v >= p.tiles) break;
-        tile_mn(v, m0, tn);
-    }
-    if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);  // also taken for NaN
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

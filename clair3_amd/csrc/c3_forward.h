@@ -133,15 +133,21 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             ep.post = m->conv1_w16_post, ep.range_flag = m->range_flag;
             TRY((launch_gemm<Conv1Loader<4>, EPI_BIAS_RELU_PLANES, 128, 64, 2>(s, lp, m->conv_w[0], 96, M, Cout, 3, 1, ep, m->conv1_w16)));
         } else if (kConvStride[l] == 2) {
-            DensePlanesParams dp;
-            dp.a = m->act[l - 1], dp.w = m->pconv_w[l], dp.bias = m->conv_b[l], dp.c = m->act[l], dp.post = m->pconv_post[l];
-            dp.M = M, dp.N = Cout, dp.K = 9 * cin, dp.tiles_n = Cout / kDnBN, dp.tiles = (M + kDnBM - 1) / kDnBM * dp.tiles_n;
-            dp.Hin = hh[l], dp.Win = ww[l], dp.Cin = cin, dp.Ho = hh[l + 1], dp.Wo = ww[l + 1], dp.stride = 2, dp.range_flag = m->range_flag;
-            TRY(div_magic(hh[l + 1] * ww[l + 1], (int64_t)M + 2 * kDnBM, &dp.mg_hw));
-            TRY(div_magic(ww[l + 1], hh[l + 1] * ww[l + 1], &dp.mg_w));
-            ps.mfma(2.0 * ((M + kDnBM - 1) / kDnBM * kDnBM) * (double)Cout * 9.0 * cin * 3, true);
-            const int grid = std::min(dp.tiles, m->wg_slots / 2);  // one 512-thread workgroup (136 KB of LDS) per CU
-            hipLaunchKernelGGL(dense_planes_glds_kernel<0>, dim3(grid), dim3(kDnThreads), 0, s, dp);
+            S2ConvParams sp;
+            sp.a = m->act[l - 1], sp.wf = m->pconv_w[l], sp.bias = m->conv_b[l], sp.post = m->pconv_post[l], sp.c = m->act[l], sp.range_flag = m->range_flag;
+            sp.M = M, sp.N = Cout, sp.NK = 9 * cin / 64, sp.tiles_n = Cout / kS2BN, sp.tiles = (M + kS2BM - 1) / kS2BM * sp.tiles_n;
+            sp.Hin = hh[l], sp.Win = ww[l], sp.Cin = cin, sp.Ho = hh[l + 1], sp.Wo = ww[l + 1];
+            TRY(div_magic(hh[l + 1] * ww[l + 1], (int64_t)M + 2 * kS2BM, &sp.mg_hw));
+            TRY(div_magic(ww[l + 1], hh[l + 1] * ww[l + 1], &sp.mg_w));
+            ps.mfma(2.0 * ((M + kS2BM - 1) / kS2BM * kS2BM) * (double)Cout * 9.0 * cin * 3, true);
+            // more tiles than CUs: two 512-thread workgroups (66 KB of LDS, 128 registers a lane) per CU; otherwise one, with twice the registers
+            const bool pair = sp.tiles > m->wg_slots / 2;
+            int g = sp.tiles;
+            const int slots = pair ? m->wg_slots : m->wg_slots / 2, unit = 8 * sp.tiles_n;
+            if (g > slots) g = std::max(unit, slots / unit * unit);
+            if (pair) hipLaunchKernelGGL((conv3x3_s2_planes_kernel<0, true>), dim3(g), dim3(kS2Threads), 0, s, sp);
+            else
+                hipLaunchKernelGGL((conv3x3_s2_planes_kernel<0, false>), dim3(g), dim3(kS2Threads), 0, s, sp);
             HIP_TRY(hipGetLastError());
         } else {
             const bool res = l % 3 == 2;

@@ -36,6 +36,7 @@
 #include "c3_lstm_fused.h"
 #include "c3_host.h"
 #include "c3_conv3.h"
+#include "c3_conv3s2.h"
 #include "c3_dense.h"
 
 using namespace c3;
@@ -137,7 +138,7 @@ struct c3_model {
     float *conv1_wfrag16 = nullptr;  // conv1 as fragments of conv1_i8_f16_kernel / conv3x3_planes_kernel's SRC8 forms (C = 8 or 9)
     float *conv1_post = nullptr;     // their [64] per-channel 2^-k
     float *pconv_w[9] = {};  // stride-1 convs: conv3x3_planes_kernel chunks in fragment order [Cout/64][Cin/64][9][2][4][2][64 lanes x 16 B];
-                             // stride-2 convs: dense_planes_glds_kernel chunks [Cout/128][9 Cin/64][128][16 pieces]
+                             // stride-2 convs: conv3x3_s2_planes_kernel chunks, the same fragment order [Cout/64][9 Cin/64][2][4][2][64 lanes x 16 B]
     float *pconv_pre[9] = {}, *pconv_post[9] = {};  // [Cout] the output channels' powers of two 2^k / 2^-k (c3_pack.h row_scales)
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout (fp32 form)

@@ -502,27 +502,32 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin, const FaC
                                 }
         TRY(upload(m, &m->pconv_w[l], pk));
     }
-    if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kDnBN == 0) {
-        // dense_planes_glds_kernel: chunk (column tile of 128, kc = tap * Cin/64 + slab) = 128 couts x 256 B, pieces as above
+    if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kS2BN == 0) {
+        // conv3x3_s2_planes_kernel (c3_conv3s2.h): column tiles of 64 couts, chunk kc = tap * Cin/64 + slab = 16 KB in the FRAGMENT order of
+        // the stride-1 layers above -- [cout half wn][k-step][piece hi | lo][lane] x 16 B, lane (n = lane & 31, kh = lane >> 5) holding
+        // channels 64 slab + 8 (2 ks + kh) .. + 7 of cout 64 tn + 32 wn + n, times the output channel's power of two
         const int NS = Cin / 64, NKc = 9 * NS;
         std::vector<float> sc, post;
         row_scales(pw.data(), Cout, (size_t)ldb, sc, post);
         TRY(upload(m, &m->pconv_pre[l], sc));
         TRY(upload(m, &m->pconv_post[l], post));
-        std::vector<float> pk((size_t)Cout * NKc * 64);
-        uint16_t *q16 = reinterpret_cast<uint16_t *>(pk.data());
-        for (int tn = 0; tn < Cout / kDnBN; ++tn)
+        std::vector<float> pf((size_t)Cout * NKc * 64);
+        uint16_t *f16 = reinterpret_cast<uint16_t *>(pf.data());
+        for (int tn = 0; tn < Cout / 64; ++tn)
             for (int kc = 0; kc < NKc; ++kc)
-                for (int r = 0; r < kDnBN; ++r)
-                    for (int g = 0; g < 16; ++g)
-                        for (int j = 0; j < 8; ++j) {
-                            const int tap = kc / NS, slab = kc % NS;
-                            const float v = pw[(size_t)(tn * kDnBN + r) * ldb + (size_t)tap * Cin + slab * 64 + 8 * (g & 7) + j] * sc[tn * kDnBN + r];  // exact
-                            const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
-                            const _Float16 piece = g < 8 ? h0 : h1;
-                            memcpy(&q16[(((((size_t)tn * NKc + kc) * kDnBN + r) * 16 + g) * 8) + j], &piece, 2);
-                        }
-        TRY(upload(m, &m->pconv_w[l], pk));
+                for (int wn = 0; wn < 2; ++wn)
+                    for (int ks = 0; ks < 4; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int tap = kc / NS, slab = kc % NS;
+                                const int co = tn * 64 + 32 * wn + (lane & 31), ci = slab * 64 + 8 * (2 * ks + (lane >> 5)) + j;
+                                const float v = pw[(size_t)co * ldb + (size_t)tap * Cin + ci] * sc[co];  // exact
+                                const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                const size_t dst = ((((((size_t)tn * NKc + kc) * 2 + wn) * 4 + ks) * 2) * 64 + lane) * 8 + j;
+                                memcpy(&f16[dst], &h0, 2);
+                                memcpy(&f16[dst + 64 * 8], &h1, 2);
+                            }
+        TRY(upload(m, &m->pconv_w[l], pf));
     }
     return 0;
 }

@@ -10,6 +10,7 @@
 static std::string g_err;
 static int fail(const char *, ...) { return -1; }
 #include "c3_dense.h"
+#include "c3_conv3s2.h"
 using namespace c3;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -92,7 +93,7 @@ int main(int argc, char **argv) {
         }
     }
     {   // ---- the stride-2 convolutions (conv3: 45 x 17 x 64 -> 23 x 9 x 128; conv5: 23 x 9 x 128 -> 12 x 5 x 256), B = 256 windows
-        const int Bc = 256;
+        for (int Bc : {256, 1000}) {
         const int shapes[2][6] = {{45, 17, 64, 23, 9, 128}, {23, 9, 128, 12, 5, 256}};
         for (int si = 0; si < 2; ++si) {
             const int Hin = shapes[si][0], Win = shapes[si][1], Cin = shapes[si][2], Ho = shapes[si][3], Wo = shapes[si][4], Co = shapes[si][5];
@@ -105,31 +106,36 @@ int main(int argc, char **argv) {
             // any fp16-looking bytes will do for timing: reuse the random pieces generated above
             for (size_t off = 0; off < abytes; off += ha.size() * 2) CK(hipMemcpy((char *)ca + off, ha.data(), std::min(ha.size() * 2, abytes - off), hipMemcpyHostToDevice));
             for (size_t off = 0; off < wbytes; off += hw.size() * 2) CK(hipMemcpy((char *)cw + off, hw.data(), std::min(hw.size() * 2, wbytes - off), hipMemcpyHostToDevice));
-            DensePlanesParams cp;
-            cp.a = ca, cp.w = cw, cp.bias = dbias, cp.post = dbias, cp.c = (float *)cc;
-            cp.M = Mc, cp.N = Co, cp.K = Kc, cp.tiles_n = Co / kDnBN, cp.tiles = (Mc + kDnBM - 1) / kDnBM * cp.tiles_n;
-            cp.Hin = Hin, cp.Win = Win, cp.Cin = Cin, cp.Ho = Ho, cp.Wo = Wo, cp.stride = 2;
             auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) / (uint64_t)d) + 1); };
-            cp.mg_hw = magic(Ho * Wo), cp.mg_w = magic(Wo);
-            const int gc = cp.tiles < 256 ? cp.tiles : 256;
             const double gf = 2.0 * Mc * Co * (double)Kc * 3 * 1e-9;
-            printf("stride-2 convolution %dx%dx%d -> %dx%dx%d, B = %d: M=%d N=%d K=%d, %d tiles on %d workgroups, %.1f GFLOP executed\n", Hin, Win, Cin, Ho, Wo, Co, Bc, Mc, Co, Kc,
-                   cp.tiles, gc, gf);
+            printf("stride-2 convolution %dx%dx%d -> %dx%dx%d, B = %d: M=%d N=%d K=%d, %.1f GFLOP executed\n", Hin, Win, Cin, Ho, Wo, Co, Bc, Mc, Co, Kc, gf);
             auto rep = [&](const char *name, float us) { printf("  %-66s %7.1f us  %6.0f TF executed\n", name, us, gf / us * 1e3); };
-#define RUNG(abl, name) rep(name, time_us([&] { hipLaunchKernelGGL((dense_planes_glds_kernel<abl>), dim3(gc), dim3(kDnThreads), 0, 0, cp); }, 20))
-            RUNG(0, "LDS-DMA kernel (the product)");
-            RUNG(2, "  - the wait for the requests (wrong results)");
-            RUNG(1, "  - the requests in the loop");
-            RUNG(16, "  - epilogue");
-            RUNG(8, "  - fragment reads");
-            RUNG(4, "  - matrix instructions");
-            RUNG(9, "  - requests - fragment reads (matrix instructions + barriers)");
-            RUNG(41, "  matrix instructions only (no requests, reads, barriers)");
-            RUNG(12, "  requests + barriers only");
-            RUNG(14, "  requests + barriers only, never waited for (request throughput)");
-            RUNG(46, "  requests only, no waits, no barriers");
-#undef RUNG
+            if (Co % kS2BN == 0) {
+                S2ConvParams sp;
+                sp.a = ca, sp.wf = cw, sp.bias = dbias, sp.post = dbias, sp.c = cc, sp.range_flag = nullptr;
+                sp.M = Mc, sp.N = Co, sp.NK = Kc / 64, sp.tiles_n = Co / kS2BN, sp.tiles = (Mc + kS2BM - 1) / kS2BM * sp.tiles_n;
+                sp.Hin = Hin, sp.Win = Win, sp.Cin = Cin, sp.Ho = Ho, sp.Wo = Wo, sp.mg_hw = magic(Ho * Wo), sp.mg_w = magic(Wo);
+                const int unit = 8 * sp.tiles_n;
+                const int g1 = sp.tiles > 256 ? 256 / unit * unit : sp.tiles, g2 = sp.tiles > 512 ? 512 / unit * unit : sp.tiles;
+                printf(" weights straight into registers (c3_conv3s2.h): %d tiles of 128 x 128, workgroups of 512 threads\n", sp.tiles);
+#define RUNS(abl, pair, gs, name) rep(name, time_us([&] { hipLaunchKernelGGL((conv3x3_s2_planes_kernel<abl, pair>), dim3(gs), dim3(kS2Threads), 0, 0, sp); }, 20))
+                RUNS(0, false, g1, "one workgroup per CU, two sets of fragment registers");
+                RUNS(0, true, g1, "one workgroup per CU, one set of fragment registers");
+                RUNS(0, true, g2, "two workgroups per CU (one set of fragment registers)");
+                RUNS(0, false, g1, "one workgroup per CU, two sets of fragment registers (again)");
+                RUNS(1, false, g1, "  - the pixel requests in the loop");
+                RUNS(2, false, g1, "  - the weight loads");
+                RUNS(16, false, g1, "  - epilogue");
+                RUNS(8, false, g1, "  - fragment reads");
+                RUNS(4, false, g1, "  - matrix instructions");
+                RUNS(11, false, g1, "  matrix instructions + barriers only");
+                RUNS(14, false, g1, "  pixel requests + barriers only");
+                RUNS(13, false, g1, "  weight loads + barriers only");
+                RUNS(31, false, g1, "  barriers only (prologue + launch)");
+#undef RUNS
+            }
             (void)hipFree(ca), (void)hipFree(cw), (void)hipFree(cc);
+        }
         }
     }
     CK(hipDeviceSynchronize());
