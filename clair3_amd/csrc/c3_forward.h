@@ -142,6 +142,7 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             ps.mfma(2.0 * ((M + kS2BM - 1) / kS2BM * kS2BM) * (double)Cout * 9.0 * cin * 3, true);
             // more tiles than CUs: two 512-thread workgroups (66 KB of LDS, 128 registers a lane) per CU; otherwise one, with twice the registers
             const bool pair = sp.tiles > m->wg_slots / 2;
+            m->choice_s2[l == 3 ? 0 : 1] = pair ? "two-workgroups-per-cu" : "one-workgroup-per-cu";
             int g = sp.tiles;
             const int slots = pair ? m->wg_slots : m->wg_slots / 2, unit = 8 * sp.tiles_n;
             if (g > slots) g = std::max(unit, slots / unit * unit);
@@ -274,7 +275,7 @@ static int run_fa(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, float 
         m->choice_fa = "planes-f16x3";
         return run_fa_planes(m, s, x, n, y);
     }
-    m->choice_fa = "fp32-mfma";
+    m->choice_fa = "fp32-mfma", m->choice_s2[0] = m->choice_s2[1] = "-";
     return run_fa_fp32(m, s, x, n, y);
 }
 

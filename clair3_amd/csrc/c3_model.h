@@ -184,6 +184,7 @@ struct c3_model {
 
     // which kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
     const char *choice_lstm1 = "-", *choice_proj2 = "-", *choice_lstm2 = "-", *choice_fa = "-";
+    const char *choice_s2[2] = {"-", "-"};  // conv3, conv5: one or two workgroups per CU (c3_conv3s2.h PAIR)
 
     bool prof = false;
     std::vector<ProfRec> recs;

@@ -237,7 +237,7 @@ int c3_model_describe(c3_model *m, char *buf, int n) {
     if (m->kind == C3_KIND_PILEUP)
         snprintf(buf, (size_t)n, "sharing=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d", m->sharing, m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok);
     else
-        snprintf(buf, (size_t)n, "sharing=%d conv_stack=%s on_fp32=%d", m->sharing, m->choice_fa, (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d conv_stack=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->choice_fa, m->choice_s2[0], m->choice_s2[1], (int)!m->f16_ok);
     return 0;
 }
 

@@ -615,6 +615,23 @@ def describe(m):
     return buf.value.decode()
 
 
+def test_stride2_convolution_forms_are_bit_identical(oracle_mod):
+    """conv3 / conv5 (c3_conv3s2.h) run two workgroups per CU with one set of fragment registers when the layer has more 128 x 128 tiles than
+    the chip has CUs (conv3 from 159 windows on, conv5 from 274) and one workgroup per CU with two sets below: same chunk order, same
+    products per accumulator -- a window's row must not depend on which form its batch selected, ragged last tiles included"""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, False, seed=131)
+    x = syn.make_fa_windows(300 + 5, channels=8, seed=132)
+    m = make_model(syn.FULL_ALIGNMENT, 8, False, sd)
+    y = m.wait(m.submit(x, slot=0))  # one forward pass over all 305
+    assert "conv3=two-workgroups-per-cu conv5=two-workgroups-per-cu" in describe(m)
+    util.assert_rows_match(y[:24], oracle_mod.fa_forward(sd, x[:24], False), what="full alignment, two workgroups per CU")
+    for lo, n, want in ((0, 200, "conv3=two-workgroups-per-cu conv5=one-workgroup-per-cu"), (200, 105, "conv3=one-workgroup-per-cu conv5=one-workgroup-per-cu"),
+                        (77, 1, "conv3=one-workgroup-per-cu conv5=one-workgroup-per-cu"), (5, 273, "conv3=two-workgroups-per-cu conv5=one-workgroup-per-cu")):
+        y_part = m.wait(m.submit(x[lo:lo + n], slot=0))
+        assert want in describe(m), describe(m)
+        assert np.array_equal(y_part, y[lo:lo + n]), f"rows {lo}..{lo + n} differ between the forms of the stride-2 convolutions"
+
+
 def test_lstm_tile_shapes_are_bit_identical(monkeypatch, oracle_mod):
     """both recurrences run 16 windows per workgroup or, while that leaves CUs without a workgroup, 8 (on rows {0,1,4,5,...} of the
     matrix tile; c3_lstm_fused.h / c3_kernels.h OPT bit 2): same matrix instructions per window, same cell arithmetic per unit --
