@@ -20,6 +20,7 @@ threads = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 ref = refloop.reference_root()
 out = {}
 only = os.environ.get("C3_WT_ONLY")  # "pileup" / "full_alignment": one of the two jobs
+legs = os.environ.get("C3_WT_LEGS")  # e.g. "libc3hip_decoder_columns": these legs alone, timing only (no VCF comparison)
 for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMENT, 8, True, False), ("pileup", syn.PILEUP, 18, False, True)):
     if only and only != name:
         continue
@@ -32,6 +33,8 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
     for tag, kw in (("libc3hip", dict(hip=True)), ("libc3hip_decoder_columns", dict(hip=True, decoder=True)), ("reference_modules_pytorch", dict(hip=False))):
         if tag == "libc3hip_decoder_columns" and not indel:
             continue
+        if legs and tag not in legs.split(","):
+            continue
         vcf = os.path.join(d, tag + ".vcf")
         t0 = time.perf_counter()
         rc, log = refloop.run_worker(ref, lst, ck, vcf, pileup, indel, cpu_threads=threads, **kw)
@@ -39,6 +42,10 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
         m = re.search(r"Total time elapsed: ([0-9.]+) s", log)
         assert rc == 0 and f"Total processed positions : {n}" in log, log[-2000:]
         res[tag] = {"loop_seconds": float(m.group(1)), "process_wall_seconds": round(wall, 2), "windows_per_s_in_the_loop": round(n / float(m.group(1)))}
+    if legs:
+        out[name] = {"windows": n, "tensor_files": files, "cpu_threads": threads, **res}
+        print(name, json.dumps(out[name]), flush=True)
+        continue
     # libc3hip's VCF against the reference modules' (PyTorch): identical text, rows whose QUAL / GQ differ in the last digit
     # (probabilities that agree to ~1e-6 on either side of a rounding boundary) and rows whose CALL differs -- each of those
     # listed, so that a near-tie can be told from a defect (tests/test_reference_loop_gpu.py proves near-ties record by record)
