@@ -11,16 +11,20 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
     const int FC = m->FC, K4 = m->K4;
     const int nk_total = K4 / kBK;
     const int S = l4_splits(m);
-    const bool l4_f16 = m->f16_ok && m->l4_w16;
+    const bool l4_f16 = m->f16_ok && m->l4_wf;
     {
         ProfScope ps(m, s, tag_l4, 2.0 * n * FC * K4, 4.0 * (n * K4 + (double)FC * K4 + (double)S * n * FC));
-        DenseLoaderParams lp{a, lda};
-        EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
-        ps.mfma(2.0 * ((n + 127) / 128 * 128) * FC * K4 * (l4_f16 ? 3 : 1), l4_f16);
-        if (l4_f16)  // partials carry l4_wscale
-            TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64, 2>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep, m->l4_w16)));
-        else
+        if (l4_f16) {  // partials carry the features' powers of two (l4_pre)
+            L4Params lp{a, lda, m->l4_wf, m->part, (int)n, FC, K4 / 64, S, (int)((n + kL4BM - 1) / kL4BM), FC / kL4BN};
+            ps.mfma(2.0 * lp.m_tiles * kL4BM * FC * K4 * 3, true);
+            hipLaunchKernelGGL(l4_stream_kernel<0>, dim3((unsigned)(lp.m_tiles * lp.n_tiles * S)), dim3(kL4Threads), 0, s, lp);
+            HIP_TRY(hipGetLastError());
+        } else {
+            DenseLoaderParams lp{a, lda};
+            EpilogueParams ep{m->part, nullptr, nullptr, FC, n * FC};
+            ps.mfma(2.0 * ((n + 127) / 128 * 128) * FC * K4, false);
             TRY((launch_gemm<DenseLoader<4>, EPI_PARTIAL, 128, 64>(s, lp, m->l4_w, K4, (int)n, FC, nk_total / S, S, ep)));
+        }
     }
     {
         const double fl = 2.0 * n * (FC * 128.0 * m->nb + 128.0 * m->nout);

@@ -37,6 +37,7 @@
 #include "c3_host.h"
 #include "c3_conv3.h"
 #include "c3_conv3s2.h"
+#include "c3_l4.h"
 #include "c3_dense.h"
 
 using namespace c3;
@@ -142,7 +143,7 @@ struct c3_model {
     float *pconv_pre[9] = {}, *pconv_post[9] = {};  // [Cout] the output channels' powers of two 2^k / 2^-k (c3_pack.h row_scales)
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout (fp32 form)
-    float *l4_w16 = nullptr;                 // the same as two fp16 pieces [2][FC][K4], every feature row times its power of two
+    float *l4_wf = nullptr;                  // the same as two fp16 pieces in fragment order (c3_l4.h), every feature row times its power of two
     float *l4_pre = nullptr, *l4_post = nullptr;  // [FC] 2^k / 2^-k
     float *b5 = nullptr;
     float *w5f = nullptr, *whf = nullptr, *bh48 = nullptr;  // L5 / head weights as fragments of fc_tail_mfma_kernel (c3_tail.h)
@@ -242,7 +243,7 @@ static int launch_gemm(hipStream_t s, const typename Loader::Params &lp, const f
 // It is a constant of the model, NOT a function of the batch size: the partial sums are added in a fixed
 // order by the reduce kernel, so a window's probabilities are bit-identical whatever batch it travels in.
 static int l4_splits(const c3_model *m) {
-    const int nk = m->K4 / kBK;
+    const int nk = m->K4 % 64 == 0 ? m->K4 / 64 : m->K4 / kBK;  // l4_stream_kernel (c3_l4.h) walks chunks of 64 inputs, the fp32 form chunks of kBK
     static const int env = getenv("C3HIP_L4_SPLITS") ? atoi(getenv("C3HIP_L4_SPLITS")) : 0;  // A/B knob
     const int want = env > 0 ? env : m->kind == C3_KIND_PILEUP ? 15 : 28;  // measured against 22 / 30 / 33 (pileup) and 14 / 56 (full alignment)
     int best = 1;

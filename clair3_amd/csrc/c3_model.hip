@@ -253,7 +253,7 @@ int c3_model_destroy(c3_model *m) {
     (void)hipDeviceSynchronize();
     free_workspace(m);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
-                   m->l4_w, m->l4_b, m->l4_w16, m->b5, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias, m->conv1_w16,
+                   m->l4_w, m->l4_b, m->l4_wf, m->b5, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias, m->conv1_w16,
                    m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_pw, m->proj2_pwr, m->proj2_post, m->conv1_post,
                    m->conv1_w16_post, m->l4_pre, m->l4_post};
     for (float *p : ws)

@@ -77,7 +77,28 @@ static int pack_tail(c3_model *m, const TensorMap &tm, const std::vector<int> *l
     {
         std::vector<float> sc, post;
         row_scales(w, FC, (size_t)K4, sc, post);
-        TRY(upload_split_pieces(m, &m->l4_w16, w4, FC, sc));
+        if (K4 % 64 == 0 && FC % kL4BN == 0) {
+            // l4_stream_kernel (c3_l4.h): column tiles of 64 features, chunks of 64 inputs, 16 KB each in the FRAGMENT order of the
+            // convolutions -- [feature half wn][k-step][piece hi | lo][lane] x 16 B, lane (n = lane & 31, kh = lane >> 5) holding inputs
+            // 64 kc + 8 (2 ks + kh) .. + 7 of feature 64 tn + 32 wn + n, times the feature's power of two
+            const int nk = K4 / 64;
+            std::vector<float> pf((size_t)FC * K4);
+            uint16_t *f16 = reinterpret_cast<uint16_t *>(pf.data());
+            for (int tn = 0; tn < FC / 64; ++tn)
+                for (int kc = 0; kc < nk; ++kc)
+                    for (int wn = 0; wn < 2; ++wn)
+                        for (int ks = 0; ks < 4; ++ks)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int f = tn * 64 + 32 * wn + (lane & 31), k = kc * 64 + 8 * (2 * ks + (lane >> 5)) + j;
+                                    const float v = w[(size_t)f * K4 + k] * sc[f];  // exact
+                                    const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                    const size_t dst = ((((((size_t)tn * nk + kc) * 2 + wn) * 4 + ks) * 2) * 64 + lane) * 8 + j;
+                                    memcpy(&f16[dst], &h0, 2);
+                                    memcpy(&f16[dst + 64 * 8], &h1, 2);
+                                }
+            TRY(upload(m, &m->l4_wf, pf));
+        }
         TRY(upload(m, &m->l4_pre, sc));
         TRY(upload(m, &m->l4_post, post));
     }
