@@ -168,8 +168,13 @@ def run_workload(name, args, rank, world, local):
         for _ in range(args.warmup):
             step()
         gatherer.flush()
-        blocks, own = [], []
-        for _ in range(max(1, args.repeats)):  # every block: EXACTLY K steps between two fences, MAX over ranks
+        blocks, own, outs = [], [], []
+        for rep in range(max(1, args.repeats)):  # every block: EXACTLY K steps between two fences, MAX over ranks
+            if rep:  # the W untimed steps again in front of every later block: the fences and the bookkeeping between two blocks are an
+                     # idle gap after which a 7 ms block (the driver's 20 steps) would start on clocks that have begun to fall
+                for _ in range(args.warmup):
+                    step()
+                gatherer.flush()
             fence()
             t0 = time.perf_counter()
             out = None
@@ -187,7 +192,9 @@ def run_workload(name, args, rank, world, local):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed = float(t.item())
             blocks.append(elapsed)
-            if rank == 0:
+            outs.append(out)
+        if rank == 0:  # checked behind the last block: nothing but the fences stands between two timed blocks
+            for out in outs:
                 assert out is not None and out.shape[1] == (90 if indel else 24) and out.shape[0] % n_total == 0 and out.shape[0] > 0
                 assert bool(torch.isfinite(out).all())
         return blocks, own
