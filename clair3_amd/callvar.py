@@ -67,7 +67,7 @@ def _make_batch_generator(original):
                 or model is None or PREFETCH_DEPTH <= 0):
             yield from original(gen_cls, args, batch_size=batch_size)
             return
-        want = bool(predict.DECODER_COLUMNS and model.add_indel_length)
+        want = bool(predict.DECODER_COLUMNS)
         if want != model._decode_cols:
             model.decode_columns(want)
         yield from transport.lookahead_batches(model, transport.iter_tensor_files(args.output_tensor_can_fn_list), batch_size,
@@ -85,9 +85,10 @@ PREFETCH_DEPTH = int(os.environ.get("C3HIP_PREFETCH_DEPTH", "2"))
 
 def install(worker=True, gpu_wrapper=True, decoder=False):
     """Patch the imported (or importable) reference modules in place.  Returns the list of rebound names.
-    decoder=True additionally makes the full-alignment rows carry the decoder columns of libc3hip and
+    decoder=True additionally makes the rows of either network carry the decoder columns of libc3hip and
     rebinds clair3.CallVariants.possible_outcome_probabilites_from / batch_output to read them
-    (clair3_amd/decode.py): same VCF text, ~6x the decode rate per host core on rows with the indel-length heads."""
+    (clair3_amd/decode.py): same VCF text, ~6x the decode rate per host core on rows with the indel-length heads, ~2x on
+    the 24-probability rows of the pileup network."""
     done = []
     import clair3.model as ref_model
     ref_model.Clair3_P, ref_model.Clair3_F = Clair3_P, Clair3_F

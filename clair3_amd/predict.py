@@ -59,7 +59,7 @@ def _select_device(use_gpu=True):
     return "cuda:0"
 
 
-# set by callvar.install(decoder=True): rows of models with the indel-length heads also carry the decoder columns
+# set by callvar.install(decoder=True): the rows (24 or 90 probabilities) also carry the decoder columns
 # (clair3_amd/decode.py) that the rebound batch_output consumes
 DECODER_COLUMNS = False
 
@@ -67,7 +67,7 @@ DECODER_COLUMNS = False
 def _hip_predict(model, device, X):
     """_torch_predict(model, device, X) (clair3/CallVariantsFromCffi.py:48-52): numpy windows in, numpy
     float32 (B, 24|90) probabilities out; H2D, forward and D2H are done by libc3hip (pinned staging).
-    With DECODER_COLUMNS the 90-column rows are followed by model.DECODE_COLS decoder columns."""
+    With DECODER_COLUMNS the rows are followed by model.DECODE_COLS decoder columns."""
     if device is not None and model._device is not None and _device_index(device) != model._device:
         model.to(device)
     ent = _PENDING.pop(id(X), None)
@@ -75,7 +75,7 @@ def _hip_predict(model, device, X):
         # submitted ahead by the rebound batch generator (worker.lookahead_batches), alone or in a group of consecutive
         # batches: the rows are on their way or here
         return ent[1].take(ent[3], ent[4])
-    want = bool(DECODER_COLUMNS and model.add_indel_length)
+    want = bool(DECODER_COLUMNS)
     if want != model._decode_cols:
         model.decode_columns(want)
     return model.predict_numpy(np.asarray(X))

@@ -31,8 +31,6 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
     refloop.write_checkpoint(ck + ".pt", kind, channels, indel)
     res = {}
     for tag, kw in (("libc3hip", dict(hip=True)), ("libc3hip_decoder_columns", dict(hip=True, decoder=True)), ("reference_modules_pytorch", dict(hip=False))):
-        if tag == "libc3hip_decoder_columns" and not indel:
-            continue
         if legs and tag not in legs.split(","):
             continue
         vcf = os.path.join(d, tag + ".vcf")
@@ -62,7 +60,7 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
         from tests.test_reference_loop_gpu import explain_call_differences, file_window
         job = dict(ck=ck, kind=kind, channels=channels, indel=indel, window=file_window(d, [per_file * (3 if pileup else 1)] * files))
         res["vcf_call_differs_explained"] = explain_call_differences(job, cmp_["call_differs"], ref)
-    if indel:
+    if "libc3hip_decoder_columns" in res:
         cmp2 = refloop.compare_vcfs(os.path.join(d, "libc3hip_decoder_columns.vcf"), os.path.join(d, "libc3hip.vcf"))
         res["vcf_decoder_columns_vs_plain_identical"] = [cmp2["identical_text"], cmp2["records_a"], cmp2["records_b"]]
     out[name] = {"windows": n, "tensor_files": files, "cpu_threads": threads, **res}

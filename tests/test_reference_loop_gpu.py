@@ -160,14 +160,17 @@ def test_blocking_calls_without_the_lookahead_generator(ref, jobs):
     check("full_alignment", job, got, out, "hip_blocking")
 
 
-def test_decoder_columns_through_the_reference_loop(ref, jobs):
-    """install(decoder=True): 121-column rows through the loop's shared memory into its forked decode workers, the rebound
-    batch_output reading the device's decoder columns there -- same VCF text as the reference's enumeration"""
-    job = jobs("full_alignment")
+@pytest.mark.parametrize("name", ["full_alignment", "pileup"])
+def test_decoder_columns_through_the_reference_loop(name, ref, jobs):
+    """install(decoder=True): 121-column (full alignment) / 55-column (pileup, 24 probabilities) rows through the loop's shared memory
+    into its forked decode workers, the rebound batch_output reading the device's decoder columns there -- same VCF text as the
+    reference's enumeration"""
+    kind, channels, indel, pileup, dwell, sizes = CASES[name]
+    job = jobs(name)
     got = os.path.join(job["dir"], "hip_decoder.vcf")
-    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, False, True, hip=True, decoder=True)
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, hip=True, decoder=True)
     assert rc == 0, out[-3000:]
-    s = check("full_alignment", job, got, out, "hip_decoder")
+    s = check(name, job, got, out, "hip_decoder")
     # and against the run without the columns on the same device rows: character for character
     plain = os.path.join(job["dir"], "hip.vcf")
     if os.path.exists(plain):
@@ -193,7 +196,7 @@ def test_gpu_wrapper_slot_probe_on_the_device(ref):
     assert "would start" in r.stdout
 
 
-@pytest.mark.parametrize("name,decoder", [("pileup", False), ("full_alignment", False), ("full_alignment", True)])
+@pytest.mark.parametrize("name,decoder", [("pileup", False), ("pileup", True), ("full_alignment", False), ("full_alignment", True)])
 def test_legacy_stdin_worker_on_libc3hip(name, decoder, ref, tmp_path):
     """the reference's other worker, ``clair3.py CallVariants --tensor_fn PIPE`` (clair3/CallVariants.py:1456-1621: text
     tensors on stdin, int32 pileup windows, batches of predictBatchSize, decode on a thread beside the next load): install()
