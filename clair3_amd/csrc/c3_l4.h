@@ -3,24 +3,24 @@
 //
 // The shapes are all K: 1024 windows x 128 features x 10 560 inputs (pileup; 43 MB of fp32 activations read once) and 256 x 256 x 3 584
 // (full alignment).  Until round 4 they ran on the tiled GEMM (c3_gemm.h: 128 x 64 tiles, 32-float chunks, both operands through registers
-// and ds_write, one chunk of each in flight): 19.2 / 8.1 us.  This kernel keeps three chunks of both operands in flight and never moves a
-// weight through LDS: 8.1 -> 6.7 us for full alignment (9.0 against 10.2 us in the step) -- and the SAME 17 us (20 in the step) for the pileup
-// shape.  tools/l4_probe.hip (profiles/r04_n_l4_probe.txt) says why: a plain read of the 43 MB takes 7.4 us, but a workgroup walks its 11
-// chunks in lock step -- without any load the kernel still takes 9.4 us (3 of launch, 0.55 us per chunk: 768 matrix cycles per SIMD, the
-// fragment reads and a barrier), the activation loads add 3 us, the weight loads (64 KB per chunk and CU through the vector memory pipe,
-// half of it L1 hits) 4 us, and neither hides under the other; more slices make it worse (S = 33: two rounds of workgroups), fewer leave
-// CUs idle; one accumulator per k-step, a group-major activation layout ([step][window][320]: perfectly linear reads) changed nothing.
-// Here
+// and ds_write, one chunk of each in flight): 19.2 / 8.1 us.  Here
 //  * a workgroup (512 threads = 8 waves as 2 x 4) owns 64 windows x 128 features x one K slice; the grid is (window tiles) x (feature
 //    tiles) x S, dealt to the XCDs in contiguous runs of slices so that an XCD's L2 holds the ~2 weight slices its workgroups share;
 //  * the ACTIVATIONS (fp32 rows) are requested kL4Depth chunks of 64 inputs ahead: thread t holds 8 consecutive inputs of row t >> 3 per
 //    chunk in flight, splits them into fp16 pieces once (not once per reading wave) and writes them as a plane row -- hi 64 | lo 64, piece q
 //    of row r at slot q ^ (r & 15), the layout of c3_conv3s2.h -- into one of two 16 KB stages;
-//  * the WEIGHTS never touch LDS: packed in fragment order (c3_pack.h: [FC/64][K4/64][feature half][k-step][piece][lane] x 16 B, the packing
-//    of the convolutions), loaded straight into a register ring kL4Depth chunks ahead (a chunk's twelve matrix instructions are ~0.35 us,
-//    an L2 / Infinity Cache round trip is longer: one chunk ahead left every chunk waiting for its weights);
-//  * one barrier per chunk; per chunk and wave 12 matrix instructions (one 32 x 32 accumulator: lo x hi, hi x lo, hi x hi per k-step; one
-//    accumulator per k-step changed nothing, tools/l4_probe.hip).
+//  * the WEIGHTS, packed in fragment order (c3_pack.h: [FC/64][K4/64][feature half][k-step][piece][lane] x 16 B, the packing of the
+//    convolutions), come by LDS-DMA two chunks ahead into three 32 KB stages -- lane-linear landing IS fragment order -- and every wave
+//    reads its fragments from there: straight into registers (the first form of this kernel) the two waves of a feature block each
+//    fetched the same kilobytes through the vector memory pipe, 64 KB per chunk and CU next to 16 KB of activations;
+//  * one barrier per chunk, behind an explicit s_waitcnt vmcnt(8) (the requests of the NEXT chunk's weights are older than the eight
+//    operations issued since); per chunk and wave 12 matrix instructions (one 32 x 32 accumulator: lo x hi, hi x lo, hi x hi per k-step).
+// Measured (tools/l4_probe.hip, profiles/r04_n_l4_probe.txt, r04_s_*): full alignment 8.1 -> 6.3 us alone (10.2 -> 8.9 us in the step); pileup
+// 19.2 -> 15.4 us alone, 20.6 -> 17.7 us in the step.  Why not more: a plain read of the 43 MB takes 7.4 us, but a workgroup walks its 11
+// chunks in lock step -- without any load the kernel still takes 9.4 us (3 of launch, 0.55 us per chunk: 768 matrix cycles per SIMD, the
+// fragment reads and a barrier), and the two load streams add to that instead of hiding under it; more slices make it worse (S = 33: two
+// rounds of workgroups), fewer leave CUs idle; one accumulator per k-step, a step-major activation layout ([step][window][320]: perfectly
+// linear reads) changed nothing.
 // The partials carry the features' powers of two (c3_pack.h row_scales) exactly as before; splitk_reduce_selu_kernel / the tail kernel
 // add them in the fixed order s = 0..S-1, so a window's bits do not depend on the batch it travels in.
 #pragma once
@@ -30,7 +30,7 @@ namespace c3 {
 
 constexpr int kL4BM = 64, kL4BN = 128, kL4Threads = 512;
 constexpr int kL4Row = 256, kL4Stage = kL4BM * kL4Row;  // 16 KB per stage
-constexpr int kL4Depth = 3;                             // chunks of either operand in flight ahead of the one being used (ring slots are named
+constexpr int kL4Depth = 3;                             // activation chunks in flight ahead of the one being split; also the weight stages (slots named
                                                         // statically: chunk j lives in slot j % kL4Depth of both rings)
 
 struct L4Params {
@@ -42,10 +42,11 @@ struct L4Params {
     int m_tiles, n_tiles;  // ceil(n / 64), FC / 128
 };
 
-// ABL (probes only; 0 in the product): 1 no activation loads, 2 no weight loads, 4 no matrix instructions
+// ABL (probes only; 0 in the product): 1 no activation loads, 2 no weight requests, 4 no matrix instructions
+constexpr int kL4WStage = 32768;  // one 64-input chunk of the 128 features of a tile: two fragment-ordered 16 KB chunks (c3_pack.h)
 template <int ABL = 0>
 __global__ __launch_bounds__(kL4Threads, 2) void l4_stream_kernel(L4Params p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * kL4Stage];
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kL4Stage + 3 * kL4WStage];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 32 windows x 32 features each
@@ -60,10 +61,6 @@ __global__ __launch_bounds__(kL4Threads, 2) void l4_stream_kernel(L4Params p) {
 
     const __amdgpu_buffer_rsrc_t arsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a), 0, (uint32_t)((int64_t)p.n * p.lda * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.wf)) + ((size_t)(nt * 2 + (wn >> 1)) * p.nk + c0) * 16384, 0, (uint32_t)(cps * 16384), 0x00020000);
-    const uint32_t w_voff = (uint32_t)((wn & 1) * 8192 + lane * 16);
-
     // activations: thread t -> inputs 8 (t & 7) .. + 7 of row t >> 3 of every chunk
     const int ar = tid >> 3, ao = tid & 7;
     const uint32_t a_row = m0 + ar < p.n ? (uint32_t)(((int64_t)(m0 + ar) * p.lda + (int64_t)c0 * 64 + ao * 8) * 4) : kPlOob;
@@ -89,15 +86,22 @@ __global__ __launch_bounds__(kL4Threads, 2) void l4_stream_kernel(L4Params p) {
         *reinterpret_cast<pl_u32x4 *>(dst + a_dst) = hi;
         *reinterpret_cast<pl_u32x4 *>(dst + (a_dst ^ 128u)) = lo;  // piece 8 + ao: slot (ao ^ x) ^ 8
     };
-    pl_u32x4 wq[kL4Depth][4][2];
-    auto w_issue = [&](int d, int ks, int c) __attribute__((always_inline)) {  // k-step ks of chunk c -> ring slot d
-        if constexpr (ABL & 2) {
-            wq[d][ks][0] = pl_u32x4{(uint32_t)c, 1u, 2u, 3u}, wq[d][ks][1] = pl_u32x4{4u, 5u, 6u, (uint32_t)ks};
-            return;
+    const __amdgpu_buffer_rsrc_t wall = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wf), 0, (uint32_t)((int64_t)p.FC * p.nk * 256), 0x00020000);
+    typedef void __attribute__((address_space(3))) *lds_ptr;
+    // weight chunk c of both 64-feature tiles -> stage d, by LDS-DMA: lane L's 16 bytes land at M0 + 16 L, so a fragment-ordered kilobyte
+    // arrives in fragment order; wave w brings kilobytes 4 w .. 4 w + 3 of the 32; a chunk beyond the slice asks an out-of-range offset
+    auto w_dma = [&](int d, int c) __attribute__((always_inline)) {
+        if constexpr (ABL & 2) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = wave * 4 + i, t = j >> 4;
+            const uint32_t off = c < cps ? (uint32_t)(((nt * 2 + t) * p.nk + c0 + c) * 16384 + (j & 15) * 1024 + lane * 16) : kPlOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wall, (lds_ptr)(smem + 2 * kL4Stage + d * kL4WStage + j * 1024), 16, off, 0, 0, 0);
         }
-        const uint32_t so = (uint32_t)(c * 16384 + ks * 2048);  // beyond the slice: out of range, zeros
-        wq[d][ks][0] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff, so, 0));
-        wq[d][ks][1] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff, so + 1024, 0));
+    };
+    const uint32_t w_lds = (uint32_t)(2 * kL4Stage + (wn >> 1) * 16384 + (wn & 1) * 8192 + lane * 16);
+    auto w_frag = [&](int d, int ks, int piece) __attribute__((always_inline)) {
+        return *reinterpret_cast<const pl_u32x4 *>(smem + w_lds + d * kL4WStage + ks * 2048 + piece * 1024);
     };
     auto mma = [](f32x16 c, pl_u32x4 w, pl_u32x4 x) __attribute__((always_inline)) {
         if constexpr (ABL & 4) {
@@ -109,12 +113,13 @@ __global__ __launch_bounds__(kL4Threads, 2) void l4_stream_kernel(L4Params p) {
     };
 
     // ---- prologue: kL4Depth chunks of both operands requested (chunk by chunk: the loads come back in order), chunk 0 split into stage 0
+    // the requests of weight chunks 0 and 1 FIRST: the loads come back in order, so the wait for activation chunk 0 below covers them
+    w_dma(0, 0);
+    w_dma(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int d = 0; d < kL4Depth; ++d) {
-        a_issue(d, d);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) w_issue(d, ks, d);
-    }
+    for (int d = 0; d < kL4Depth; ++d) a_issue(d, d);
     a_split(0, 0);
     a_issue(0, kL4Depth);
     lds_barrier();
@@ -131,16 +136,24 @@ __global__ __launch_bounds__(kL4Threads, 2) void l4_stream_kernel(L4Params p) {
             xh[ks] = *reinterpret_cast<const pl_u32x4 *>(smem + (va0 ^ (uint32_t)(32 * ks)));
             xl[ks] = *reinterpret_cast<const pl_u32x4 *>(smem + (va0 ^ (uint32_t)(128 + 32 * ks)));
         }
+        // stage (c + 2) % 3 = (c - 1) % 3 was read in the chunk before this one: behind that chunk's barrier it is free
+        w_dma(next_slot == 0 ? 1 : next_slot == 1 ? 2 : 0, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            acc = mma(acc, wq[slot][ks][0], xl[ks]);
-            acc = mma(acc, wq[slot][ks][1], xh[ks]);
-            acc = mma(acc, wq[slot][ks][0], xh[ks]);
-            w_issue(slot, ks, c + kL4Depth);
+            const pl_u32x4 w0 = w_frag(slot, ks, 0), w1 = w_frag(slot, ks, 1);
+            acc = mma(acc, w0, xl[ks]);
+            acc = mma(acc, w1, xh[ks]);
+            acc = mma(acc, w0, xh[ks]);
         }
         // the next chunk's activations (requested kL4Depth chunks ago) -> the other stage; its slot is requested again
         a_split(next_slot, (c + 1) & 1);
         a_issue(next_slot, c + 1 + kL4Depth);
+        // the weight requests of chunk c + 1 (made one chunk ago) have landed for this wave once only the eight younger operations -- the
+        // two activation loads of the chunk before, this chunk's four requests and two loads -- are outstanding; behind the barrier
+        // everybody's have
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         lds_barrier();
         va0 ^= (uint32_t)kL4Stage;
     };

@@ -81,7 +81,7 @@ int main() {
             RUNL(0, "the kernel");
             if (k == 0) {
                 RUNL(1, "- activation loads");
-                RUNL(2, "- weight loads");
+                RUNL(2, "- weight requests");
                 RUNL(4, "- matrix instructions");
                 RUNL(3, "- both load streams");
                 snprintf(nm, sizeof nm, "S = %d: the kernel behind a rewrite of the matrix (minus the rewrite)", S);
