@@ -29,3 +29,31 @@ def test_short_line_from_a_committed_full_record():
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] >= 1
     assert line["pileup"]["batches_in_flight"] == 1 and "roofline" in line["pileup"]
     assert line["full_record"] == os.path.join("gpurun_out", "bench_full.json")
+
+
+def test_the_committed_final_collection_is_consistent():
+    """profiles/r04_final_*: the line the bench printed on the GPU box is one parseable line under 4 KB whose value / ms_per_step / roofline
+    describe the same leg; the roofline fraction recomputed from the rocprofv3 kernel statistics of the same box agrees within 3 %
+    (tools/roofline_check.py); the PMC traffic the line quotes is the committed pmc_traffic.json"""
+    import csv
+    for name in ("r04_final_bench.json", "r04_final_bench20.json"):
+        raw = open(os.path.join(ROOT, "profiles", name)).read().strip()
+        assert len(raw.splitlines()) == 1 and len(raw) <= 4096, (name, len(raw))
+        line = json.loads(raw)
+        assert line["n_gpus"] == 1 and line["config"]["batches_in_flight"] == 1 and line["higher_is_better"] is True
+        assert abs(line["value"] * line["ms_per_step"] / 1e3 / line["config"]["windows_per_step"] - 1) < 1e-3  # value = windows per step / step time
+        roof = line["roofline"]
+        assert roof["bound"] == "mfma" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+        assert abs(roof["step_us_one_batch_in_flight"] / (1e3 * line["ms_per_step"]) - 1) < 1e-3
+        assert line["cpu_baseline"]["kind"] == "reference" and line["gt_concordance"]["gt21_differ"] == 0
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_final_bench.json")).read())
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "r04_final_pmc_traffic.json")))
+    assert abs(line["roofline"]["traffic"] / traffic["hbm_bytes_per_launch"] - 1) < 1e-3
+    # the same fraction from the profiler's averages: algorithmic FLOP of the convolution family / its launches' durations
+    stats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_final_kernel_stats_fa_one_in_flight.csv")))}
+    conv = {k: v for k, v in stats.items() if "conv3x3_planes_kernel" in k or "conv3x3_s2_planes_kernel" in k}
+    assert len(conv) == 8 and len({c for c, _ in conv.values()}) == 1  # eight launches per step, each once
+    conv_us = sum(avg for _, avg in conv.values()) / 1e3
+    flop = 449_418_240 * line["config"]["windows_per_step"]  # DESIGN.md 3: algorithmic FLOP of the convolution family per window (C = 8)
+    frac_csv = flop / (conv_us * 1e-6) / 2500e12
+    assert abs(frac_csv / line["roofline"]["frac"] - 1) < 0.03, (frac_csv, line["roofline"]["frac"])
