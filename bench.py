@@ -2,7 +2,7 @@
 """Throughput benchmark of the MI355X-native Clair3 inference path (BASELINE.json metric:
 candidate-windows/sec, pileup + full-alignment; GT-call concordance vs the reference arithmetic).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -19,12 +19,18 @@ probability rows travel to rank 0 in one RCCL gather per GATHER_EVERY steps (SUR
                   windows to probability rows landed in host memory (staging copy + H2D + kernels + D2H, one handle, a
                   ring of three slots), at the configured batch and at the reference's GPU batch of 1000
                   (clair3/CallVariantsFromCffi.py:265-269).  N = 1 only;
-  roofline        dominant kernel family, HIP-event timed per launch on the launch stream in a profiled pass over the
-                  same steps: achieved = ALGORITHMIC FLOP (2*MACs of the reference layer shapes) / kernel
-                  time; peak = the dense peak of the matrix instruction the family issues (2500 TFLOP/s for the 16-bit
-                  forms every contraction uses, 157.3 for the fp32 fallbacks); frac = achieved / peak; mfma_util = FLOP
-                  the matrix instructions EXECUTE (three fp16 piece products per fp32 product, tile padding) / time /
-                  peak; traffic / hbm_frac from the committed rocprofv3 PMC passes (profiles/pmc_traffic*.json);
+  roofline        dominant kernel family.  Its TIME is a share of the un-instrumented one-batch-in-flight step: a profiled
+                  pass over the same steps brackets every kernel launch with HIP events on the launch stream and gives the
+                  family's share of the sum of all kernels; kernel_us_per_step = share x ms_per_step, so it is <= the step
+                  by construction (bracketed launches are a few per cent longer than free-running ones; the raw event
+                  sums are in `events`).  achieved = ALGORITHMIC FLOP of the family (2*MACs of the reference layer
+                  shapes) / that time; peak = the dense peak of the matrix instruction the family issues
+                  (2500 TFLOP/s for the 16-bit forms every contraction uses, 157.3 for the fp32 fallbacks); frac =
+                  achieved / peak; whole_network_frac = FLOP of the WHOLE forward pass / ms_per_step / peak; mfma_util =
+                  FLOP the matrix instructions EXECUTE (three fp16 piece products per fp32 product, tile padding) / time /
+                  peak; traffic / fabric_frac_of_hbm_peak from the committed rocprofv3 PMC passes
+                  (profiles/pmc_traffic*.json): FETCH_SIZE / WRITE_SIZE count requests on the memory side of the L2 --
+                  Infinity-Cache hits included -- so they are FABRIC bytes, an upper bound of what reaches HBM;
   cpu_baseline    the reference CPU path on this node's host cores, rank 0, N = 1, bounded sample: kind "reference" = the
                   reference's own clair3/model.py modules called as its _torch_predict does (staged into the git-ignored
                   oracle/_ref by oracle/stage_reference.py; "port" = oracle/torch_port.py, the same ATen operators, when
@@ -397,42 +403,62 @@ def run_workload(name, args, rank, world, local):
     mf = sum(r["mfma_flops"] for r in dom)
     launches = sum(r["launches"] for r in dom)
     peak = max([r["mfma_peak_tflops"] for r in dom] + [0.0]) or 2500.0
-    achieved = fl / ms / 1e9 if ms > 0 else 0.0
-    step_ms_profiled = sum(r["total_ms"] for r in stats) / max(args.steps, 1)
-    traffic, traffic_note, hbm_frac = None, None, None
+    ms_all = max(sum(r["total_ms"] for r in stats), 1e-9)
+    step_ms_profiled = ms_all / max(args.steps, 1)
+    # The family's time is its SHARE (from the event-bracketed pass) of the un-instrumented step: bracketing every launch
+    # with events makes each a little longer (the eight convolution launches alone read longer than the whole free-running
+    # step), so the raw event sum is not a duration of the step the line reports -- the share of it is.
+    step_us = 1e3 * res["one_batch_in_flight"]["ms_per_step"]
+    share, fam_us = family_time(ms, ms_all, step_us)
+    fl_step, mf_step = fl / max(args.steps, 1), mf / max(args.steps, 1)
+    achieved = fl_step / fam_us / 1e6 if fam_us > 0 else 0.0  # FLOP / us / 1e6 = TFLOP/s
+    traffic, traffic_note, fabric_frac = None, None, None
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE.get(name, ""))
     if name in TRAFFIC_FILE and os.path.exists(tpath) and not args.batch:
-        # HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in their own runs by
-        # tools/gpu_round.sh pmc / pmcp; bench.py cannot run rocprof on itself)
+        # bytes on the memory side of the L2 from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in their
+        # own runs by tools/gpu_round.sh pmc_fa / pmc_p; bench.py cannot run rocprof on itself)
         with open(tpath) as fh:
             tj = json.load(fh)
-        traffic = tj["hbm_bytes_per_launch"]
-        step_bytes = tj.get("hbm_bytes_per_step")
-        traffic_note = {"source": "profiles/%s (%s)" % (TRAFFIC_FILE[name], tj.get("tag", "")), "unit": "bytes per launch of the dominant family (PMC)",
-                        "hbm_bytes_per_step_all_kernels": step_bytes,
+        traffic = tj.get("fabric_bytes_per_launch", tj.get("hbm_bytes_per_launch"))
+        step_bytes = tj.get("fabric_bytes_per_step", tj.get("hbm_bytes_per_step"))
+        traffic_note = {"source": "profiles/%s (%s): FETCH_SIZE x2 + WRITE_SIZE = requests on the memory side of the L2, Infinity-Cache hits "
+                                  "included (MI355X_MICROARCH.md): fabric bytes, an upper bound of HBM bytes" % (TRAFFIC_FILE[name], tj.get("tag", "")),
+                        "unit": "bytes per launch of the dominant family (PMC)",
+                        "fabric_bytes_per_step_all_kernels": step_bytes,
                         "algorithmic_bytes_per_step": bytes_w * batch,
-                        "ratio_to_algorithmic": (step_bytes / (bytes_w * batch)) if step_bytes else None}
+                        "ratio_to_algorithmic": (step_bytes / (bytes_w * batch)) if step_bytes else None,
+                        "l2_hit_rate": tj.get("l2_hit_rate")}
         if step_bytes:
-            hbm_frac = step_bytes / (res["one_batch_in_flight"]["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+            fabric_frac = step_bytes / (res["one_batch_in_flight"]["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+    whole_one = res["one_batch_in_flight"]["value"] / world * flop_w / (peak * 1e12)
     res["roofline"] = {
         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-        "mfma_util": (mf / ms / 1e9 / peak) if ms > 0 else None,
-        "traffic": traffic, "traffic_note": traffic_note, "hbm_frac": hbm_frac, "kernel": dom_name,
-        "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
-        "share_of_step_time": ms / max(sum(r["total_ms"] for r in stats), 1e-9),
-        "step_us_sum_of_kernels": 1e3 * step_ms_profiled,
-        "kernel_us_per_step": 1e3 * ms / max(args.steps, 1),  # the dominant family's kernels alone: <= ms_per_step of one batch in flight
-        "step_us_one_batch_in_flight": 1e3 * res["one_batch_in_flight"]["ms_per_step"],
+        "mfma_util": (mf_step / fam_us / 1e6 / peak) if fam_us > 0 else None,
+        "traffic": traffic, "traffic_note": traffic_note, "fabric_frac_of_hbm_peak": fabric_frac, "kernel": dom_name,
+        "avg_launch_us": fam_us * max(args.steps, 1) / max(launches, 1), "launches": launches,
+        "share_of_step_time": share,
+        "kernel_us_per_step": fam_us,  # the dominant family's share of the free-running step: <= ms_per_step of one batch in flight
+        "step_us_one_batch_in_flight": step_us,
+        "events": {"family_us_per_step": 1e3 * ms / max(args.steps, 1), "all_kernels_us_per_step": 1e3 * step_ms_profiled,
+                   "note": "raw HIP-event sums of the profiled pass (every launch bracketed): longer than the free-running step"},
         "kernel_variants": describe(model),
+        "whole_network_frac": whole_one, "whole_network_achieved": whole_one * peak,
         "whole_forward_frac": res["value"] / world * flop_w / (peak * 1e12),
-        "whole_forward_frac_one_in_flight": res["one_batch_in_flight"]["value"] / world * flop_w / (peak * 1e12),
+        "whole_forward_frac_one_in_flight": whole_one,
         "algorithmic_bytes_per_window": bytes_w,
         "hbm_algorithmic_gbs": res["value"] / world * bytes_w / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
-        "note": "achieved = ALGORITHMIC FLOP (direct 3x3 convolution / LSTM shapes of the reference, SURVEY 8d) / measured kernel time; "
-                "peak = dense peak of the matrix instruction in use (fp16 inputs, fp32 accumulate); every fp32 product is formed from "
-                "three fp16 piece products (fp16x3, DESIGN.md 1), so mfma_util ~ 3 x frac is what the matrix pipe actually executes",
+        "note": "achieved = ALGORITHMIC FLOP (direct 3x3 convolution / LSTM shapes of the reference, SURVEY 8d) of the family / its share of "
+                "the free-running step; peak = dense peak of the matrix instruction in use (fp16 inputs, fp32 accumulate); every fp32 product "
+                "is formed from three fp16 piece products (fp16x3, DESIGN.md 1), so mfma_util ~ 3 x frac is what the matrix pipe actually executes",
     }
     return res
+
+
+def family_time(family_event_ms, all_kernels_event_ms, step_us):
+    """(share, microseconds per step) of a kernel family: its share of the event-bracketed kernel time of the profiled pass,
+    applied to the FREE-RUNNING step -- never longer than the step it is a part of (tests/test_bench_line.py)."""
+    share = min(1.0, family_event_ms / max(all_kernels_event_ms, 1e-12))
+    return share, share * step_us
 
 
 def staged_reference():
@@ -648,14 +674,18 @@ def short_line(full, names, full_path):
     def roof(r):
         if not r:
             return None
-        out = {k: _r(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_util", "traffic", "hbm_frac",
+        out = {k: _r(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_util", "traffic",
                                          "avg_launch_us", "launches", "kernel_us_per_step", "step_us_one_batch_in_flight")}
+        out["whole_network_frac"] = _r(r.get("whole_network_frac", r.get("whole_forward_frac_one_in_flight")))
+        out["fabric_frac_of_hbm_peak"] = _r(r.get("fabric_frac_of_hbm_peak", r.get("hbm_frac")))
         out["kernel"] = "Clair3_F 3x3 convolution launches (fa.conv* / fa.res*)" if "convolution" in r.get("kernel", "") else \
                         "Clair3_P BiLSTM launches (p.lstm* / p.proj*)"
         tn = r.get("traffic_note") or {}
-        out["hbm_bytes_per_step"] = tn.get("hbm_bytes_per_step_all_kernels")
+        out["fabric_bytes_per_step"] = tn.get("fabric_bytes_per_step_all_kernels", tn.get("hbm_bytes_per_step_all_kernels"))
         out["algorithmic_bytes_per_step"] = tn.get("algorithmic_bytes_per_step")
-        out["traffic_source"] = tn.get("source")
+        out["l2_hit_rate"] = _r(tn.get("l2_hit_rate"))
+        src = tn.get("source") or ""
+        out["traffic_source"] = (src.split(":")[0] + ": L2 memory-side requests (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included") if src else None
         return out
 
     def cpu(c):
@@ -728,7 +758,8 @@ def short_line(full, names, full_path):
             o = sub(full[n], 0)
             c = {"value": o["value"], "ms_per_step": o["ms_per_step"], "batch_per_gpu": o["batch_per_gpu"], "batches_in_flight": 1}
             if o.get("roofline"):
-                c["roofline"] = {k: o["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_util", "hbm_bytes_per_step")}
+                c["roofline"] = {k: o["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_util", "kernel_us_per_step",
+                                                               "fabric_bytes_per_step")}
             if o.get("host_inclusive"):
                 c["host_inclusive"] = o["host_inclusive"]["value"]
             if o.get("cpu_baseline"):
@@ -738,6 +769,36 @@ def short_line(full, names, full_path):
             line[n] = c
     line["full_record"] = os.path.relpath(full_path, ROOT) if full_path else None
     return line
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` typed plainly, N > 1: no torchrun environment around this process, so it starts its own N
+    ranks -- exactly the command the module docstring names (one process per GPU, rendezvous on 127.0.0.1 at a free port) with
+    this process's own arguments -- and returns their exit code.  Only rank 0 writes to stdout (its ONE JSON line), which the
+    children inherit; torchrun's chatter goes to stderr."""
+    import socket
+    import subprocess
+    if not os.environ.get("C3_BENCH_DEVICE"):  # (C3_BENCH_DEVICE: every rank on one device -- the one-GPU code-path test)
+        try:
+            from clair3_amd import _lib
+            have = _lib.device_count()
+        except Exception as e:
+            print(f"[bench] --gpus {n}: cannot count HIP devices ({e!r})", file=sys.stderr)
+            return 2
+        if have < n:
+            print(f"[bench] --gpus {n} but this node shows {have} HIP device(s)", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -767,6 +828,9 @@ def main():
     if args.ref_gpu_worker:
         ref_gpu_worker(args.ref_gpu_worker[0], float(args.ref_gpu_worker[1]), int(args.ref_gpu_worker[2]))
         return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     from clair3_amd import dist as c3dist
     rank, world, local = c3dist.init_from_env()

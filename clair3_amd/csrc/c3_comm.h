@@ -93,9 +93,10 @@ struct RcclApi {
 }  // namespace c3
 
 struct c3_comm {
-    ncclComm_t nccl = nullptr;  // null when world == 1
+    ncclComm_t nccl = nullptr;  // null when world == 1 (unless C3HIP_FORCE_RCCL made a one-rank communicator)
     int rank = 0, world = 1, device = 0;
-    bool aborted = false;  // c3_comm_abort: from then on a world of one, whatever rank the caller still names as destination
+    int orig_rank = 0;     // the rank the handle was created with: the index of this process in the caller's counts[] for good
+    bool aborted = false;  // c3_comm_abort: from then on the gather is the local copy of this rank's own rows
 };
 
 extern "C" {
@@ -123,9 +124,14 @@ c3_comm *c3_comm_create(const void *id128, int rank, int world, int device) {
         return nullptr;
     }
     c3_comm *c = new c3_comm();
-    c->rank = rank, c->world = world, c->device = device;
-    if (world == 1) return c;  // nothing to talk to: c3_gather_rows is a device copy
-    if (!id128) {
+    c->rank = c->orig_rank = rank, c->world = world, c->device = device;
+    // C3HIP_FORCE_RCCL=1 (test knob): a world of ONE still goes through librccl -- dlopen + symbol binding, ncclGetUniqueId,
+    // ncclCommInitRank(nranks = 1), ncclCommCount, a grouped self ncclSend / ncclRecv in c3_gather_rows, ncclCommDestroy -- so
+    // that every call this file makes has met the REAL library on a one-GPU box before the day an 8-GPU node exists
+    const char *force = getenv("C3HIP_FORCE_RCCL");
+    const bool forced = world == 1 && force && atoi(force) > 0;
+    if (world == 1 && !forced) return c;  // nothing to talk to: c3_gather_rows is a device copy
+    if (!id128 && !forced) {
         fail("null unique id");
         delete c;
         return nullptr;
@@ -137,7 +143,24 @@ c3_comm *c3_comm_create(const void *id128, int rank, int world, int device) {
         return nullptr;
     }
     ncclUniqueId id;
-    memcpy(&id, id128, 128);
+    bool have_id = false;
+    if (id128) {
+        memcpy(&id, id128, 128);
+        for (int i = 0; i < 128 && !have_id; ++i) have_id = reinterpret_cast<const char *>(id128)[i] != 0;
+    }
+    if (!have_id) {  // forced one-rank communicator without an id from the caller: make one here
+        if (!forced) {
+            fail("all-zero unique id");
+            delete c;
+            return nullptr;
+        }
+        const ncclResult_t rid = r.GetUniqueId(&id);
+        if (rid != ncclSuccess) {
+            fail("ncclGetUniqueId failed: %s", r.GetErrorString(rid));
+            delete c;
+            return nullptr;
+        }
+    }
     const ncclResult_t rc = r.CommInitRank(&c->nccl, world, id, rank);
     if (rc != ncclSuccess) {
         fail("ncclCommInitRank failed: %s", r.GetErrorString(rc));
@@ -156,20 +179,43 @@ int c3_comm_destroy(c3_comm *c) {
 
 int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int64_t *counts, float *all_dev, int dst, void *stream) {
     if (!c || !counts) return fail("null argument");
-    if (c->aborted) dst = 0;  // (the caller's destination rank no longer exists: the gather of an aborted communicator is the local copy)
-    if (dst < 0 || dst >= c->world || row_floats <= 0) return fail("bad arguments (dst %d of %d ranks, %d floats per row)", dst, c->world, row_floats);
+    if (row_floats <= 0) return fail("bad arguments (%d floats per row)", row_floats);
+    hipStream_t s = (hipStream_t)stream;
+    if (c->aborted) {
+        // the communicator is gone: what is left of the gather is the local copy of THIS rank's rows.  counts[] is still the
+        // caller's array over the original ranks, so this rank's count sits at orig_rank (not at 0)
+        if (counts[c->orig_rank] < 0) return fail("negative row count for rank %d", c->orig_rank);
+        const size_t own = (size_t)counts[c->orig_rank] * row_floats;
+        if (own && !rows_dev) return fail("null rows");
+        if (!all_dev) return fail("communicator aborted: the gather is the local copy of rank %d's rows and needs a destination buffer", c->orig_rank);
+        HIP_TRY(hipSetDevice(c->device));
+        if (own && all_dev != rows_dev) HIP_TRY(hipMemcpyAsync(all_dev, rows_dev, own * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    if (dst < 0 || dst >= c->world) return fail("bad arguments (dst %d of %d ranks)", dst, c->world);
     for (int r = 0; r < c->world; ++r)
         if (counts[r] < 0) return fail("negative row count for rank %d", r);
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
     const size_t mine = (size_t)counts[c->rank] * row_floats;
     if (mine && !rows_dev) return fail("null rows");
     if (c->rank == dst && !all_dev) return fail("the destination rank needs the gathered buffer");
-    if (c->world == 1) {
+    if (c->world == 1 && !c->nccl) {
         if (mine && all_dev != rows_dev) HIP_TRY(hipMemcpyAsync(all_dev, rows_dev, mine * sizeof(float), hipMemcpyDeviceToDevice, s));
         return 0;
     }
     RcclApi &r = RcclApi::get();
+    if (c->world == 1) {  // C3HIP_FORCE_RCCL: the one rank sends its rows to itself through the grouped send / receive pair
+        if (!mine || all_dev == rows_dev) return 0;
+        ncclResult_t g = r.GroupStart();
+        if (g != ncclSuccess) return fail("ncclGroupStart failed: %s", r.GetErrorString(g));
+        const ncclResult_t a = r.Send(rows_dev, mine, ncclFloat32, 0, c->nccl, s);
+        const ncclResult_t b = r.Recv(all_dev, mine, ncclFloat32, 0, c->nccl, s);
+        g = r.GroupEnd();
+        if (a != ncclSuccess) return fail("ncclSend (to self) failed: %s", r.GetErrorString(a));
+        if (b != ncclSuccess) return fail("ncclRecv (from self) failed: %s", r.GetErrorString(b));
+        if (g != ncclSuccess) return fail("ncclGroupEnd failed: %s", r.GetErrorString(g));
+        return 0;
+    }
     int rc = (int)r.GroupStart();
     if (rc) return fail("ncclGroupStart failed: %s", r.GetErrorString((ncclResult_t)rc));
     if (c->rank == dst) {
@@ -219,7 +265,7 @@ int c3_comm_abort(c3_comm *c) {
         RcclApi &r = RcclApi::get();
         const ncclResult_t rc = r.CommAbort(c->nccl);
         c->nccl = nullptr;
-        c->world = 1, c->rank = 0, c->aborted = true;  // whatever is asked of this handle from now on is local: a world of one, whose only rank is 0
+        c->world = 1, c->rank = 0, c->aborted = true;  // whatever is asked of this handle from now on is local (orig_rank keeps its place in counts[])
         if (rc != ncclSuccess) return fail("ncclCommAbort failed: %s", r.GetErrorString(rc));
     }
     return 0;

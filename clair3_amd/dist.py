@@ -33,7 +33,8 @@ def init_from_env(backend=None):
             if backend is None:
                 # C3_DIST_BACKEND: the control plane of a job whose ranks cannot form an RCCL group of their own -- the two-ranks-on-one-GPU
                 # arrangement of tests/test_comm_gpu.py (real RCCL refuses two ranks on one device); the rows then still travel on
-                # c3_gather_rows (RowExchange), everything else on gloo
+                # c3_gather_rows (RowExchange._cuda_job reads the same variable; job.run_job leaves the rows on the device for it),
+                # everything else on gloo
                 backend = os.environ.get("C3_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
@@ -181,6 +182,8 @@ class RcclComm:
                 if not any(unique_id):
                     raise _lib.C3Error(f"rank 0 could not create an RCCL unique id{': ' + repr(id_error) if id_error else ''}")
             idbuf.raw = unique_id
+        elif unique_id is not None:  # a world of one normally needs no id; under C3HIP_FORCE_RCCL=1 c3_comm_create uses the caller's if given
+            idbuf.raw = unique_id
         import threading
         box, lock = {}, threading.Lock()
 
@@ -287,11 +290,15 @@ class RowExchange:
             self.fallback_reason = "rows are not on GPUs"
 
     def _cuda_job(self):
-        """rows live on GPUs (the direct path moves device memory): a GPU job under torch.distributed -- whatever carries the
-        control plane (the id broadcast and the agreement all-reduce use host tensors when the backend is not nccl)"""
+        """rows live on GPUs (the direct path moves device memory): a GPU job under torch.distributed whose control plane is
+        nccl -- or any other backend the launcher asked for BY NAME (C3_DIST_BACKEND: gloo as the control plane of a GPU job;
+        the id broadcast and the agreement all-reduce then use host tensors).  An ordinary gloo job on a host that happens to
+        have GPUs (the CPU tests) is not one: it never touches RCCL."""
         import torch
         import torch.distributed as dist
-        return torch.cuda.is_available() and dist.is_initialized()
+        if not (torch.cuda.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_backend() == "nccl" or bool(os.environ.get("C3_DIST_BACKEND"))
 
     def _all_ok(self, ok):
         """every rank learns whether EVERY rank succeeded (one 1-element all-reduce on the control plane)"""

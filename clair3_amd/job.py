@@ -154,15 +154,27 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
     on_gpu = False
     if world > 1 or comm is not None:
         import torch
+    device = comm.device if comm is not None else (exchange.device if exchange is not None else int(getattr(m0, "_device", 0) or 0))
     if world > 1:
         import torch.distributed as dist
-        on_gpu = dist.get_backend() == "nccl"  # then every tensor a collective touches lives on the rank's GPU
-    device = comm.device if comm is not None else (exchange.device if exchange is not None else int(getattr(m0, "_device", 0) or 0))
-    keep_on_device = (on_gpu or comm is not None) and consume is None and hasattr(m0, "submit_dev") and not isinstance(model, (list, tuple))
+        on_gpu = dist.get_backend() == "nccl"  # then every tensor a control-plane collective touches lives on the rank's GPU
+        # the exchange is made BEFORE the compute phase: whether the rows take the direct path (c3_gather_rows moves DEVICE
+        # memory) decides where the forward pass leaves them.  (EVERY rank makes it here: its constructor holds collectives.)
+        if comm is None and exchange is None:
+            exchange = c3dist.RowExchange(rank, world, device=device)
+    direct = comm is not None or (exchange is not None and exchange.mode == "rccl_direct")
+    rows_on_device = on_gpu or direct  # the gather wants CUDA tensors: RCCL directly, or torch.distributed on nccl
+    model_device = getattr(m0, "_device", None)
+    same_device = model_device is None or int(model_device) == int(device)  # the forward pass writes the send buffer itself
+    keep_on_device = (rows_on_device and consume is None and hasattr(m0, "submit_dev") and not isinstance(model, (list, tuple))
+                      and same_device)
     t0 = time.perf_counter()
     y_dev = None
     if keep_on_device:
         y_dev = torch.empty((per_rank[rank], int(m0.row_size)), dtype=torch.float32, device=f"cuda:{device}")
+        # the block comes from torch's caching allocator and libc3hip writes it on its OWN stream: whatever torch still had
+        # queued against a reused block must be done first
+        torch.cuda.current_stream(device).synchronize()
         n_done = _rows_to_device(m0, _segment_files(list_fn, names, mine), y_dev, positions)
     elif not mine:
         n_done = 0
@@ -197,15 +209,13 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
     if width <= 0:
         raise RuntimeError("no rank knows the row width (no windows anywhere and a model without row_size)")
     t1 = time.perf_counter()
-    if comm is None and exchange is None:
-        exchange = c3dist.RowExchange(rank, world, device=device)
     if y_dev is not None:
         y_t = y_dev
     else:
         if y_local is None:
             y_local = np.zeros((0, width), np.float32)
         y_t = torch.from_numpy(y_local)
-        if on_gpu or comm is not None:
+        if rows_on_device:
             y_t = y_t.cuda(device)
     got = comm.gather(y_t, per_rank, dst=0) if comm is not None else exchange.gather(y_t, per_rank, dst=0)
     if y_t.is_cuda:

@@ -175,7 +175,10 @@ int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *ro
  * over xGMI, librccl bound with dlopen) on the caller's HIP stream, ordered behind the forward pass on that stream.
  *   c3_comm_unique_id   rank 0 fills 128 bytes (ncclGetUniqueId); the caller hands them to every rank (any control
  *                       plane: a file, the launcher's store) -- rendezvous is not this library's business
- *   c3_comm_create      every rank, same id; world == 1 needs no id and no RCCL (the gather is a device copy)
+ *   c3_comm_create      every rank, same id; world == 1 needs no id and no RCCL (the gather is a device copy) -- unless the
+ *                       environment says C3HIP_FORCE_RCCL=1 (test knob): then a world of one makes its own id and a one-rank
+ *                       communicator (ncclCommInitRank, nranks = 1) and its gather is a grouped self ncclSend / ncclRecv, so
+ *                       the whole call sequence meets the real librccl on a one-GPU box (tests/test_comm_gpu.py)
  *   c3_gather_rows      rows_dev: this rank's counts[rank] rows of row_floats floats (device); counts: rows of every rank
  *                       (host, identical on all ranks -- they follow from the shard ranges); all_dev (rank dst only):
  *                       sum(counts) rows, rank-major = window order for contiguous shards.  Asynchronous on `stream`. */
@@ -187,8 +190,9 @@ int c3_gather_rows(c3_comm *c, const float *rows_dev, int row_floats, const int6
 /* what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): *ranks_out ranks, this one *rank_out
  * (may be NULL); world == 1 answers without RCCL.  bench.py prints it as rccl_ranks_seen. */
 int c3_comm_count(c3_comm *c, int *ranks_out, int *rank_out);
-/* give up on a collective that does not complete (ncclCommAbort); the handle then behaves like a world of one and the
- * caller routes its rows another way (clair3_amd/dist.py falls back to torch.distributed) */
+/* give up on a collective that does not complete (ncclCommAbort); from then on c3_gather_rows on this handle is the local
+ * copy of THIS rank's rows (counts[] stays the caller's array over the original ranks; all_dev is required) and the caller
+ * routes its rows another way (clair3_amd/dist.py falls back to torch.distributed) */
 int c3_comm_abort(c3_comm *c);
 /* watchdog for work queued on `stream` of `device` (hipStreamQuery polled every 50 us): 0 = finished, 1 = still running after
  * timeout_ms (c3_last_error() == "timeout"; timeout_ms < 0 waits for ever), other = error */

@@ -48,7 +48,7 @@ def test_the_committed_final_collection_is_consistent():
         assert line["cpu_baseline"]["kind"] == "reference" and line["gt_concordance"]["gt21_differ"] == 0
     line = json.loads(open(os.path.join(ROOT, "profiles", "r04_final_bench.json")).read())
     traffic = json.load(open(os.path.join(ROOT, "profiles", "r04_final_pmc_traffic.json")))
-    assert abs(line["roofline"]["traffic"] / traffic["hbm_bytes_per_launch"] - 1) < 1e-3
+    assert abs(line["roofline"]["traffic"] / traffic.get("fabric_bytes_per_launch", traffic.get("hbm_bytes_per_launch")) - 1) < 1e-3
     # the same fraction from the profiler's averages: algorithmic FLOP of the convolution family / its launches' durations
     stats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_final_kernel_stats_fa_one_in_flight.csv")))}
     conv = {k: v for k, v in stats.items() if "conv3x3_planes_kernel" in k or "conv3x3_s2_planes_kernel" in k}
@@ -57,3 +57,26 @@ def test_the_committed_final_collection_is_consistent():
     flop = 449_418_240 * line["config"]["windows_per_step"]  # algorithmic FLOP of the convolution family per window (C = 8)
     frac_csv = flop / (conv_us * 1e-6) / 2500e12
     assert abs(frac_csv / line["roofline"]["frac"] - 1) < 0.03, (frac_csv, line["roofline"]["frac"])
+
+
+def test_family_time_is_a_share_of_the_free_running_step():
+    """round 4's line carried kernel_us_per_step 341.96 > step 336.6 us (eight bracketed launches read longer than the whole free-running
+    step): the family's time is now its SHARE of the bracketed kernel time applied to the free-running step"""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_final_bench_full.json")))
+    r = full["roofline"]
+    ev_family, ev_all, step = r["kernel_us_per_step"], r["step_us_sum_of_kernels"], r["step_us_one_batch_in_flight"]
+    share, fam = bench.family_time(ev_family, ev_all, step)
+    assert 0.9 < share <= 1.0 and fam <= step and abs(fam - ev_family / ev_all * step) < 1e-9
+    assert bench.family_time(10.0, 5.0, 100.0) == (1.0, 100.0)  # a share is never above one
+    # and every line committed from round 5 on keeps the inequality
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if name.startswith("r05_") and name.endswith(("bench.json", "bench20.json")):
+            raw = open(os.path.join(ROOT, "profiles", name)).read().strip()
+            if len(raw.splitlines()) != 1:
+                continue
+            line = json.loads(raw)
+            roof = line["roofline"]
+            assert roof["kernel_us_per_step"] <= roof["step_us_one_batch_in_flight"] * (1 + 1e-9), name
+            assert "fabric_bytes_per_step" in roof and "hbm_frac" not in roof, name
+            assert abs(roof["whole_network_frac"] - line["value"] * 451538432 / 2500e12) < 2e-3, name

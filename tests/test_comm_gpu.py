@@ -100,17 +100,18 @@ def test_two_ranks_gather_rows_over_the_send_recv_path(tmp_path):
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):
-    """`bench.py --gpus 2` -- the command the driver's scaling run uses, launched the way it launches it -- executes end to end with
-    two ranks on the lease's ONE device: gloo as the control plane (C3_DIST_BACKEND), both ranks on device 0 (C3_BENCH_DEVICE), the
+    """`python bench.py --gpus 2 ...` typed PLAINLY (no torchrun around it: bench.py starts its own two ranks)
+    executes end to end with two ranks on the lease's ONE device: gloo as the control plane (C3_DIST_BACKEND), both ranks on device 0 (C3_BENCH_DEVICE), the
     rows of every 8 steps gathered to rank 0 on c3_gather_rows through the stand-in for librccl.  Not a measurement (two ranks
     share one GPU): what is checked is that the N > 1 path runs -- barriers, the MAX over ranks, the guarded first gather, the
     per-rank rates -- and prints the one parseable line with the gather on the direct path."""
     import json
     env = dict(os.environ, C3HIP_RCCL_LIB=_stub(), C3_DIST_BACKEND="gloo", C3_BENCH_DEVICE="0", OMP_NUM_THREADS="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0", C3_BENCH_FULL=str(tmp_path / "full.json"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "9", "--warmup", "2",
-           "--repeats", "2", "--workload", "full_alignment"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "9", "--warmup", "2", "--repeats", "2",
+           "--workload", "full_alignment"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -124,3 +125,78 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert mg["gather"] == "rccl_direct" and mg["rccl_ranks_seen"] == 2 and mg["ranks"] == 2, mg
     assert len(mg["per_rank_windows_per_s"]) == 2 and all(v > 0 for v in mg["per_rank_windows_per_s"])
     assert "roofline" in line and "cpu_baseline" not in line  # the CPU baseline is an N = 1 leg
+
+
+REAL_RCCL = textwrap.dedent("""
+    import ctypes as C, os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    WITH_TORCH = {with_torch!r}
+    if WITH_TORCH:
+        import torch
+    from clair3_amd import _lib, dist as c3dist
+    L = _lib.lib()
+    assert os.environ.get("C3HIP_FORCE_RCCL") == "1" and not os.environ.get("C3HIP_RCCL_LIB")
+    # 1. the 128-byte id of the REAL library
+    idbuf = (C.c_char * 128)()
+    _lib.check(L.c3_comm_unique_id(idbuf), "c3_comm_unique_id")
+    assert any(idbuf.raw)
+    mapped = sorted({{ln.split()[-1] for ln in open("/proc/self/maps") if "rccl" in ln}})
+    assert mapped and not any("fake_rccl" in m for m in mapped), mapped
+    # 2. a one-rank communicator on it: ncclCommInitRank(nranks = 1), ncclCommCount / ncclCommUserRank
+    comm = c3dist.RcclComm(0, 1, 0, unique_id=idbuf.raw)
+    assert comm.ranks_seen() == (1, 0)
+    rows = np.random.default_rng(5).random((777, 90), dtype=np.float32)
+    if WITH_TORCH:
+        # 3. the gather = a grouped self ncclSend / ncclRecv on torch's current stream
+        y = torch.from_numpy(rows).cuda(0)
+        out = comm.gather(y, [777], dst=0, timeout_s=120.0)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert out.data_ptr() != y.data_ptr()
+    else:
+        hip = C.CDLL("libamdhip64.so.7")  # already in the process (libc3hip brought it): device buffers without PyTorch
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        a, b = C.c_void_p(), C.c_void_p()
+        assert hip.hipMalloc(C.byref(a), rows.nbytes) == 0 and hip.hipMalloc(C.byref(b), rows.nbytes) == 0
+        assert hip.hipMemcpy(a, rows.ctypes.data, rows.nbytes, 1) == 0
+        cnt = (C.c_int64 * 1)(777)
+        _lib.check(L.c3_gather_rows(comm._h, a, 90, cnt, b, 0, None), "c3_gather_rows")
+        rc = L.c3_stream_wait(None, 0, 120000)
+        assert rc == 0, _lib.last_error()
+        got = np.empty_like(rows)
+        assert hip.hipMemcpy(got.ctypes.data, b, rows.nbytes, 2) == 0
+    assert np.array_equal(got, rows)  # bit for bit
+    # 4. an id made by c3_comm_create itself (no id from the caller), then destroy both
+    comm2 = c3dist.RcclComm(0, 1, 0)
+    assert comm2.ranks_seen() == (1, 0)
+    comm2.close()
+    comm.close()
+    print("REAL_RCCL_OK " + ";".join(mapped))
+""")
+
+
+def _real_rccl(tmp_path, with_torch):
+    script = tmp_path / ("real_rccl_%d.py" % with_torch)
+    script.write_text(REAL_RCCL.format(root=ROOT, with_torch=with_torch))
+    env = dict(os.environ, C3HIP_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.pop("C3HIP_RCCL_LIB", None)
+    return subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_one_rank_on_the_real_librccl(tmp_path):
+    """Every RCCL call c3_comm.h makes, executed ONCE against the REAL library on the lease's one GPU: dlopen +
+    symbol binding, RTLD_NOLOAD sharing of the copy PyTorch ships, ncclGetUniqueId, ncclCommInitRank(nranks = 1), ncclCommCount,
+    ncclCommUserRank, a grouped self ncclSend / ncclRecv in c3_gather_rows (C3HIP_FORCE_RCCL=1 makes a world of one take the
+    wire path), ncclCommDestroy.  The gathered rows are compared bit for bit."""
+    r = _real_rccl(tmp_path, True)
+    assert r.returncode == 0 and "REAL_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
+    libs = r.stdout.strip().splitlines()[-1].split(" ", 1)[1]
+    assert "torch" in libs, libs  # a process with PyTorch shares PyTorch's copy instead of loading a second librccl
+
+
+def test_one_rank_on_the_system_librccl_without_pytorch(tmp_path):
+    """The same sequence in a process that never imports torch: libc3hip then dlopens the SYSTEM librccl (/opt/rocm/lib)."""
+    r = _real_rccl(tmp_path, False)
+    assert r.returncode == 0 and "REAL_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]

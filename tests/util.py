@@ -11,8 +11,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # parity gate of BASELINE.json: probabilities within 1e-4 (fp32), genotype / zygosity labels identical
 PROB_TOL = 1e-4
-# arg-max labels may legitimately differ only when the reference's own top-2 are closer than this
-NEAR_TIE = 1e-5
+# arg-max labels may legitimately differ only when the reference's own top-2 are closer than this (the reference
+# moves its own probabilities by 1-2 ulp = 1.2e-7 with thread count or batch size, so "identical labels" is only meaningful outside ~1e-6)
+NEAR_TIE = 1e-6
 HEAD_SLICES = ((0, 21), (21, 24), (24, 57), (57, 90))
 
 

@@ -4,6 +4,7 @@
 #   bench     python bench.py (the driver's line)            bench20 the driver's own command (--steps 20 --warmup 5)
 #   prof_fa / prof_p     rocprofv3 --kernel-trace --stats over ONLY the one-batch-in-flight leg of one workload
 #   pmc_fa / pmc_p       HBM traffic of the same leg: separate FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py reads them)
+#   l2_fa / l2_p         L2 hit rate of the same leg (TCC_HIT_sum / TCC_MISS_sum; tools/pmc_traffic.py adds it to the traffic record)
 #   sq_fa / sq_p         SQ busy / MFMA busy / instruction mix of the same leg
 #   dprobe / cprobe / lprobe   tools/dense_probe.hip / conv_probe.hip / lstm_probe.hip (ablations and phase traces of the dense / convolution / recurrence kernels)
 #   info      rocminfo / lscpu / cgroup quota of the box
@@ -33,6 +34,8 @@ for s in ${1:-test bench}; do
     prof_p)  prof prof_p pileup ;;
     pmc_fa)  pmc pmc_fetch_fa full_alignment FETCH_SIZE; pmc pmc_write_fa full_alignment WRITE_SIZE ;;
     pmc_p)   pmc pmc_fetch_p pileup FETCH_SIZE; pmc pmc_write_p pileup WRITE_SIZE ;;
+    l2_fa)   pmc pmc_l2_fa full_alignment TCC_HIT_sum TCC_MISS_sum ;;
+    l2_p)    pmc pmc_l2_p pileup TCC_HIT_sum TCC_MISS_sum ;;
     sq_fa)   pmc pmc_sq_a_fa full_alignment SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
              pmc pmc_sq_b_fa full_alignment SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM ;;
     sq_p)    pmc pmc_sq_a_p pileup SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE

@@ -12,6 +12,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def l2_hit_rate(tag_dir):
+    """TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) over the c3 kernels of the pass tools/gpu_round.sh l2_fa / l2_p collected
+    (MI355X_MICROARCH.md, L2 section); None when the pass was not run"""
+    path = os.path.join(ROOT, "gpurun_out", tag_dir, "c3_counter_collection.csv")
+    if not os.path.exists(path):
+        return None
+    a = agg(path)
+    hit = sum(sum(v.get("TCC_HIT_sum", [])) for k, v in a.items() if k.startswith(("void c3::", "c3::")))
+    miss = sum(sum(v.get("TCC_MISS_sum", [])) for k, v in a.items() if k.startswith(("void c3::", "c3::")))
+    per = {k[:90]: round(sum(v["TCC_HIT_sum"]) / max(sum(v["TCC_HIT_sum"]) + sum(v["TCC_MISS_sum"]), 1.0), 4)
+           for k, v in a.items() if k.startswith(("void c3::", "c3::")) and "TCC_HIT_sum" in v and "TCC_MISS_sum" in v}
+    return {"all_c3_kernels": hit / (hit + miss) if hit + miss else None, "per_kernel": per}
+
+
 def agg(path):
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
@@ -56,12 +70,16 @@ def main(tag):
         "kernel_family": "the convolution launches of one full-alignment step (8 with conv1 computed inside res1a / res1b, else 9)",
         "launches_per_step": n / steps if steps else None,
         "launches": n,
-        "hbm_bytes_per_launch": (2 * tot_f + tot_w) * 1024 / n,
+        "fabric_bytes_per_launch": (2 * tot_f + tot_w) * 1024 / n,
         "fetch_bytes_per_launch_corrected": 2 * tot_f * 1024 / n,
         "write_bytes_per_launch": tot_w * 1024 / n,
         "unfused_layer_bytes_per_step": sum(B * (a + b + c) for a, b, c in shapes),  # every layer reading its inputs and writing its output once
         "steps": steps,
-        "hbm_bytes_per_step": (2 * all_f + all_w) * 1024 if steps else None,
+        "fabric_bytes_per_step": (2 * all_f + all_w) * 1024 if steps else None,
+        "what_the_counters_count": "FETCH_SIZE / WRITE_SIZE derive from the L2's memory-side request counters (TCC_EA0_RDREQ / _WRREQ): "
+                                   "Infinity-Cache hits are counted, not excluded -- fabric bytes, an upper bound of HBM bytes",
+        "l2_hit_rate": (l2_hit_rate("pmc_l2_fa") or {}).get("all_c3_kernels"),
+        "l2_hit_rate_per_kernel": (l2_hit_rate("pmc_l2_fa") or {}).get("per_kernel"),
         "per_kernel": per,
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as fh:
@@ -101,12 +119,16 @@ def main_pileup(tag):
         "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B",
         "kernel_family": "the two BiLSTM recurrence launches of one pileup step (lstm1_fused_kernel + lstm_recurrent_kernel_v2<160>)",
         "launches": n,
-        "hbm_bytes_per_launch": (2 * tot_f + tot_w) * 1024 / n,
+        "fabric_bytes_per_launch": (2 * tot_f + tot_w) * 1024 / n,
         "fetch_bytes_per_launch_corrected": 2 * tot_f * 1024 / n,
         "write_bytes_per_launch": tot_w * 1024 / n,
         "algorithmic_bytes_per_launch": algorithmic,
         "steps": steps,
-        "hbm_bytes_per_step": (2 * all_f + all_w) * 1024 if steps else None,
+        "fabric_bytes_per_step": (2 * all_f + all_w) * 1024 if steps else None,
+        "what_the_counters_count": "FETCH_SIZE / WRITE_SIZE derive from the L2's memory-side request counters (TCC_EA0_RDREQ / _WRREQ): "
+                                   "Infinity-Cache hits are counted, not excluded -- fabric bytes, an upper bound of HBM bytes",
+        "l2_hit_rate": (l2_hit_rate("pmc_l2_p") or {}).get("all_c3_kernels"),
+        "l2_hit_rate_per_kernel": (l2_hit_rate("pmc_l2_p") or {}).get("per_kernel"),
         "per_kernel": per,
     }
     with open(os.path.join(ROOT, "profiles", "pmc_traffic_pileup.json"), "w") as fh:
