@@ -20,9 +20,11 @@
 //     y[2j] = M0 + M1 + M2      y[2j+1] = M1 - M2 - M3
 //
 // Tile-pixels.  m' = (b * Hj + j) * W + w flattens (window, row pair, column); one workgroup (256 threads = 4 waves as 2 x 2) owns
-// 128 consecutive m' x 64 output channels = 256 output pixels, a wave 64 m' x 32 couts x 4 xi = eight 32 x 32 accumulators.  The
-// column taps of tile-pixel m' are m' - 1, m', m' + 1 (masked at the window's edge by a redirect to a zero row, as in c3_conv3.h).
-// LDS holds V of ONE 32-channel slab: 4 xi planes x 131 rows x 144 B (hi 64 B | lo 64 B | 16 B pad: the ds_read_b128 of the 16 rows
+// 126 consecutive m' x 64 output channels = 252 output pixels plus one halo tile-pixel on either side = 128 V rows (so that the
+// transform is exactly two items per thread); a wave computes 64 rows x 32 couts x 4 xi = eight 32 x 32 accumulators (rows 0 and 127
+// of a tile are computed on zeros and dropped).  The column taps of tile-pixel m' are m' - 1, m', m' + 1 (masked at the window's edge
+// by a redirect to a zero row, as in c3_conv3.h).
+// LDS holds V of ONE 32-channel slab: 4 xi planes x 129 rows x 144 B (hi 64 B | lo 64 B | 16 B pad: the ds_read_b128 of the 16 rows
 // of a lane group covers all 64 banks once) = 75 KB -- two workgroups per CU -- and the slab's transform (8 buffer loads, ~100
 // vector instructions, 8 ds_write_b128 per (row, 8-channel) item; two items per thread) runs between two barriers while the
 // OTHER workgroup of the CU is in its tap loop.  Per slab and wave: 144 matrix instructions (direct: 2 x 108 for the same outputs).
@@ -31,13 +33,13 @@
 
 namespace c3 {
 
-constexpr int kWTM = 128;                          // tile-pixels per workgroup tile
-constexpr int kWRows = kWTM + 2;                   // + the column-tap halo on either side
+constexpr int kWTM = 126;                          // output tile-pixels per workgroup tile
+constexpr int kWRows = 128;                        // V rows of a tile: its outputs and the column-tap halo row on either side
 constexpr int kWRowB = 144;                        // LDS row stride of one xi plane (32 channels x 2 pieces x 2 B + 16)
-constexpr int kWPlaneB = (kWRows + 1) * kWRowB;    // + the zero row (row kWRows)
-constexpr int kWLdsV = 4 * kWPlaneB;               // 75 456 B; the epilogue stages 256 output rows x 272 B = 69 632 B in it
-constexpr int kWItems = (4 * kWRows + kPlThreads - 1) / kPlThreads;  // (row, 8-channel group) transform items per thread: 3 (the third: 8 threads)
-static_assert(2 * kWTM * kPlRowB <= kWLdsV, "the staged output tile must fit the V planes");
+constexpr int kWPlaneB = (kWRows + 1) * kWRowB;    // + the zero row (row kWRows) a masked column tap reads: 18 576 B
+constexpr int kWLdsV = 4 * kWPlaneB;               // 74 304 B; the epilogue stages 256 output rows x 272 B = 69 632 B in it
+static_assert(4 * kWRows == 2 * kPlThreads, "two (row, 8-channel group) transform items per thread");
+static_assert(2 * kWRows * kPlRowB <= kWLdsV, "the staged output tile must fit the V planes");
 
 struct WinoConvParams {
     const void *x;        // plane activations [M][C/64][2][64] fp16 (c3_conv3.h)
@@ -50,24 +52,59 @@ struct WinoConvParams {
     int M;                // pixels = B * H * W
     int Mp;               // tile-pixels = B * Hj * W
     int H, W, Hj;         // Hj = ceil(H / 2) row pairs
-    int tiles;            // ceil(Mp / 128) * (C / 64)
+    int tiles;            // ceil(Mp / 126) * (C / 64)
     uint32_t mg_hjw = 0, mg_w = 0;  // fast_div magics of Hj * W and W
+    long long *trace = nullptr;     // ABL bit 32 (tools/wino_probe.hip): [2 workgroups][256] x {tag, shader clock}
 };
 
+// One mixed-precision instruction instead of two conversions and an add: (float)h16 + (float)l16 -- exact (the two fp16 pieces of an
+// fp32 value) -- and v - (float)h16, the remainder the low piece is rounded from.  HALF picks the 16-bit half of the register.
+template <int HALF> __device__ __forceinline__ float mix_add(uint32_t h, uint32_t l) {
+    float r;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    return r;
+}
+template <int HALF> __device__ __forceinline__ float mix_rem(float v, uint32_t h) {
+    float r;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+// split2_f16 (c3_gemm.h) with the remainder formed by mix_rem: the same pieces bit for bit
+__device__ __forceinline__ void split2_f16_mix(const f32x4 x, u32x2 (&piece)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x[i], x[i + 1]}, f16x2));
+        const f32x2 r = {mix_rem<0>(x[i], h), mix_rem<1>(x[i + 1], h)};
+        piece[0][i >> 1] = h;
+        piece[1][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+    }
+}
+
 // ABL (tools/wino_probe.hip only; 0 in the product): 1 no weight loads, 2 no transform after the first slab of the first tile,
-// 4 no epilogue, 8 no matrix instructions.
-template <int C, bool RES, int ABL = 0>
+// 4 no epilogue, 8 no matrix instructions, 32 shader-clock trace of workgroups 0 and 256 (wave 0) at phase boundaries, 16 the transform's loads NOT requested ahead (round-5 first cut: each item's loads issued
+// and waited for at the slab switch).  MIX = false: the transform on plain conversions (the probe checks the two forms agree bit for bit).
+//
+// Where the transform's memory latency goes.  A thread owns two items (row r = (tid + 256 it) >> 2 of the 128 V rows, 8-channel group
+// g = tid & 3) per slab.  The 16 buffer loads of BOTH items of the next slab go out right behind the slab's last matrix instruction,
+// into registers the pixel fragments no longer need (requesting item 0 from the middle of the tap loop does not fit: 128 accumulator
+// + 32 ring + 32 fragment + 32 item registers and the addresses spill): one memory latency per slab switch, under the other waves'
+// tails and the OTHER workgroup's tap loop.  The loads of the next TILE's first slab go out as soon as the accumulators are staged:
+// none at a tile switch -- the store loop of the epilogue runs in between.
+template <int C, bool RES, int ABL = 0, bool MIX = true>
 __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(WinoConvParams p) {
     constexpr int NS = C / 64;     // output column tiles
     constexpr int NS32 = C / 32;   // input slabs
     constexpr int PIXB = 4 * C;    // bytes per pixel
     constexpr int NCH = 12 * NS32; // 8 KB weight chunks per tile
-    constexpr int T = kWRows;      // index of the zero row
-    __shared__ __attribute__((aligned(16))) char smem[kWLdsV + 512 + kWRows * 8 + 16];
+    constexpr int T = kWRows;      // index of the zero row of every plane
+    constexpr bool AHEAD = !(ABL & 16);
+    __shared__ __attribute__((aligned(16))) char smem[kWLdsV + 512 + 2 * kWRows * 8];
     char *const vlds = smem;
     float *const bias_lds = reinterpret_cast<float *>(smem + kWLdsV);
     float *const post_lds = bias_lds + 64;
-    int2 *const rowinfo = reinterpret_cast<int2 *>(smem + kWLdsV + 512);
+    int2 *const rowinfo0 = reinterpret_cast<int2 *>(smem + kWLdsV + 512);  // two row tables: this tile's and the next one's
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,6 +113,13 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
     const int W = p.W, H = p.H;
     const int G = gridDim.x;
     const uint32_t rowB = (uint32_t)W * (uint32_t)PIXB;  // bytes between two image rows
+    // the zero rows of the four planes (the staged output tile of the epilogue runs over three of them: rewritten per tile)
+    auto zero_rows = [&]() __attribute__((always_inline)) {
+        uint32_t z = 0;
+        int t = tid;
+        asm volatile("" : "+v"(z), "+v"(t));  // (a plain constant or address is hoisted out of the tile loop and, with no register left for it, spilled)
+        if (t < 4 * 8) *reinterpret_cast<pl_u32x4 *>(vlds + (t >> 3) * kWPlaneB + T * kWRowB + (t & 7) * 16) = pl_u32x4{z, z, z, z};
+    };
 
     int v = blockIdx.x;
     int tile = xcd_tile_index(v, p.tiles);
@@ -104,95 +148,131 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
     };
 
-    // ---- per-tile row table: row r of the V tile is tile-pixel m0 - 1 + r = (b, j, w)
+    // ---- row table of a tile: V row r is tile-pixel mbase - 1 + r = (b, j, w); rows 1 .. 126 are the tile's outputs
     //   .x  byte offset of input pixel (b, 2j - 1, w)  (may lie in front of the tensor: only used together with its row bit)
-    //   .y  bits 0-3 input rows 2j-1 .. 2j+2 inside the window; bits 4-6 column taps kw = 0..2 inside the window; bit 7 output row
-    //       2j + 1 exists; bit 8 the tile-pixel exists
-    auto make_rowinfo = [&](int mbase) __attribute__((always_inline)) {
+    //   .y  bits 0-3 input rows 2j-1 .. 2j+2 inside the window; bits 4-6 column taps kw = 0..2 inside the window AND the tile; bit 7
+    //       output row 2j + 1 exists; bit 8 the tile-pixel exists and is an output of this tile
+    auto make_rowinfo = [&](int2 *tab, int mbase, bool on) __attribute__((always_inline)) {
         if (tid < kWRows) {
             const int mp = mbase - 1 + tid;
             int2 ri = make_int2(0, 0);
-            if ((unsigned)mp < (unsigned)p.Mp) {
+            if (on && (unsigned)mp < (unsigned)p.Mp) {
                 const int hjw = p.Hj * W;
                 const int b = fast_div(mp, p.mg_hjw), rem = mp - b * hjw;
                 const int j = fast_div(rem, p.mg_w), w = rem - j * W;
                 ri.x = (int)((uint32_t)((b * H + 2 * j - 1) * W + w) * (uint32_t)PIXB);
-                int bits = 0x100;
+                int bits = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) bits |= (unsigned)(2 * j - 1 + k) < (unsigned)H ? 1 << k : 0;
+                if (tid >= 1 && tid <= kWTM) {  // rows 0 and 127 are halo only: their own outputs belong to the neighbouring tiles
+                    bits |= 0x100;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) bits |= (unsigned)(w + kw - 1) < (unsigned)W ? 16 << kw : 0;
-                bits |= 2 * j + 1 < H ? 0x80 : 0;
+                    for (int kw = 0; kw < 3; ++kw) bits |= (unsigned)(w + kw - 1) < (unsigned)W ? 16 << kw : 0;
+                    bits |= 2 * j + 1 < H ? 0x80 : 0;
+                }
                 ri.y = bits;
             }
-            rowinfo[tid] = ri;
+            tab[tid] = ri;
         }
     };
 
-    // ---- input transform of one 32-channel slab: item (row r, 8-channel group g) -> V0..V3 as fp16 pieces in the four planes
-    auto transform = [&](int s32) __attribute__((always_inline)) {
+    // ---- input transform of one 32-channel slab, in two halves: the loads of item `it` of slab s32 of the tile whose row table is
+    // `tab`; and (later) V0..V3 of that item as fp16 pieces into the four planes
+    auto titem_issue = [&](const int2 *tab, int s32, int it, pl_u32x4 (&rh)[4], pl_u32x4 (&rl)[4]) __attribute__((always_inline)) {
         const uint32_t soff = (uint32_t)((s32 >> 1) * 256 + (s32 & 1) * 64);
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        const int idx = tid_ + kPlThreads * it;
+        const int r = idx >> 2, g = idx & 3;
+        const int2 ri = tab[r];
 #pragma unroll
-        for (int it = 0; it < kWItems; ++it) {
-            int tid_ = tid;
-            asm volatile("" : "+v"(tid_));
-            const int idx = tid_ + kPlThreads * it;
-            if (idx >= 4 * kWRows) continue;
-            const int r = idx >> 2, g = idx & 3;
-            const int2 ri = rowinfo[r];
-            pl_u32x4 rh[4], rl[4];
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t off = ((ri.y >> k) & 1) ? (uint32_t)ri.x + (uint32_t)k * rowB + soff + (uint32_t)(g * 16) : kPlOob;
+            rh[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
+            rl[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 128, 0));
+        }
+    };
+    auto titem_finish = [&](int it, const pl_u32x4 (&rh)[4], const pl_u32x4 (&rl)[4]) __attribute__((always_inline)) {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        const int idx = tid_ + kPlThreads * it;
+        const int r = idx >> 2, g = idx & 3;
+        char *dst = vlds + r * kWRowB + g * 16;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // four channels at a time (registers)
+            f32x4 d[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t off = ((ri.y >> k) & 1) ? (uint32_t)ri.x + (uint32_t)k * rowB + soff + (uint32_t)(g * 16) : kPlOob;
-                rh[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
-                rl[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 128, 0));
-            }
-            char *dst = vlds + r * kWRowB + g * 16;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {  // four channels at a time (registers)
-                f32x4 d[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                if constexpr (MIX) {
+                    d[k][0] = mix_add<0>(rh[k][2 * half], rl[k][2 * half]), d[k][1] = mix_add<1>(rh[k][2 * half], rl[k][2 * half]);
+                    d[k][2] = mix_add<0>(rh[k][2 * half + 1], rl[k][2 * half + 1]), d[k][3] = mix_add<1>(rh[k][2 * half + 1], rl[k][2 * half + 1]);
+                } else {
                     const f16x8 h8 = __builtin_bit_cast(f16x8, rh[k]), l8 = __builtin_bit_cast(f16x8, rl[k]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[k][e] = (float)h8[4 * half + e] + (float)l8[4 * half + e];
                 }
-                const f32x4 vv[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+            }
+            const f32x4 vv[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
 #pragma unroll
-                for (int xi = 0; xi < 4; ++xi) {
-                    u32x2 pc[2];
-                    split2_f16(vv[xi], pc);
-                    *reinterpret_cast<u32x2 *>(dst + xi * kWPlaneB + half * 8) = pc[0];
-                    *reinterpret_cast<u32x2 *>(dst + xi * kWPlaneB + 64 + half * 8) = pc[1];
-                }
+            for (int xi = 0; xi < 4; ++xi) {
+                u32x2 pc[2];
+                if constexpr (MIX) split2_f16_mix(vv[xi], pc);
+                else split2_f16(vv[xi], pc);
+                *reinterpret_cast<u32x2 *>(dst + xi * kWPlaneB + half * 8) = pc[0];
+                *reinterpret_cast<u32x2 *>(dst + xi * kWPlaneB + 64 + half * 8) = pc[1];
             }
         }
     };
 
-    const int lrow[2] = {wm * 64 + frow, wm * 64 + 32 + frow};  // this lane's tile-pixels of the tile (V row = lrow + kw)
+    int tr_n = 0;
+    auto trace = [&](int tag) __attribute__((always_inline)) {
+        if constexpr (ABL & 32) {
+            if ((blockIdx.x == 0 || blockIdx.x == 256) && tid == 0 && tr_n < 250) {
+                long long *tb = p.trace + ((blockIdx.x ? 1 : 0) * 256 + tr_n) * 2;
+                tb[0] = tag, tb[1] = (long long)__builtin_readcyclecounter();
+                ++tr_n;
+            }
+        }
+    };
+    trace(1);
+    const int lrow[2] = {wm * 64 + frow, wm * 64 + 32 + frow};  // this lane's V rows (tile-pixel m0 - 1 + lrow; its column taps: lrow + kw - 1)
     const int cb0 = wn * 32 + 4 * kh;                            // first of this lane's output channels inside the column tile
     float omax = 0.f;
+    pl_u32x4 ta_h[4], ta_l[4], tb_h[4], tb_l[4];                 // the two transform items in flight
 
     // ---- prologue
-    make_rowinfo(m0);
+    int cur = 0;
+    make_rowinfo(rowinfo0, m0, true);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) w_issue(0, ks, 0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) w_issue(1, ks, 1);
     if (tid < 64) bias_lds[tid] = p.bias[tn * 64 + tid], post_lds[tid] = p.post[tn * 64 + tid];
-    // the zero rows of the four planes
-    if (tid < 4 * 8) *reinterpret_cast<pl_u32x4 *>(vlds + (tid >> 3) * kWPlaneB + T * kWRowB + (tid & 7) * 16) = pl_u32x4{0u, 0u, 0u, 0u};
+    zero_rows();
     lds_barrier();  // the row table is there
-    transform(0);
+    titem_issue(rowinfo0, 0, 0, ta_h, ta_l);
+    titem_issue(rowinfo0, 0, 1, tb_h, tb_l);
+    titem_finish(0, ta_h, ta_l);
+    titem_finish(1, tb_h, tb_l);
+    trace(2);
     lds_barrier();
+    trace(3);
 
     for (;;) {
-        uint32_t mask[2];
+        int2 *const rinfo = rowinfo0 + cur * kWRows, *const rnext = rowinfo0 + (cur ^ 1) * kWRows;
+        // where this lane's two tile-pixels read their three column taps: V row lrow + kw - 1, or the zero row where the tap falls off
+        // the window or the tile (plane and k-step are immediate offsets of the reads)
+        const char *asrc[2][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) mask[i] = ((uint32_t)rowinfo[lrow[i] + 1].y >> 4) & 7u;
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t mk = (uint32_t)rinfo[lrow[i]].y >> 4;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) asrc[i][kw] = vlds + (((mk >> kw) & 1u) ? lrow[i] + kw - 1 : T) * kWRowB + kh * 16;
+        }
         const int vn = v + G;
         const bool more = vn < p.tiles;
         const int m0n = more ? (xcd_tile_index(vn, p.tiles) / NS) * kWTM : 0;
+        make_rowinfo(rnext, m0n, more);  // (read from the first slab switch on; a tile has at least two slabs)
 
         f32x16 acc[4][2];
 #pragma unroll
@@ -208,8 +288,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
             const int xi = tap / 3, kw = tap % 3;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int r = ((mask[i] >> kw) & 1u) ? lrow[i] + kw : T;
-                const char *src = vlds + xi * kWPlaneB + r * kWRowB + kh * 16 + ks * 32;
+                const char *src = asrc[i][kw] + xi * kWPlaneB + ks * 32;
                 xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(src);
                 xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(src + 64);
             }
@@ -217,6 +296,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
 
 #pragma unroll 1
         for (int s32 = 0; s32 < NS32; ++s32) {
+            const bool last_slab = s32 + 1 == NS32;
             frags(0, 0, 0);
 #pragma unroll
             for (int tap = 0; tap < 12; ++tap) {
@@ -243,22 +323,71 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
                     w_issue(slot, ks, ccn);
                 }
             }
-            if (s32 + 1 < NS32) {  // slab switch inside the tile
-                lds_barrier();     // every wave has finished reading the old slab
-                if constexpr (!(ABL & 2)) transform(s32 + 1);
+            // both items of the next slab's transform go out right behind the slab's last matrix instruction, into registers the pixel
+            // fragments no longer need (the next TILE's: as soon as the accumulators are staged, below)
+            trace(10 + s32);
+            if (!last_slab) {  // slab switch inside the tile
+                if constexpr (AHEAD && !(ABL & 2)) {
+                    titem_issue(rinfo, s32 + 1, 0, ta_h, ta_l);
+                    titem_issue(rinfo, s32 + 1, 1, tb_h, tb_l);
+                }
+                if constexpr (!(ABL & 2)) {
+                    if constexpr (!AHEAD) {
+                        lds_barrier();
+                        titem_issue(rinfo, s32 + 1, 0, ta_h, ta_l);
+                        titem_finish(0, ta_h, ta_l);
+                        titem_issue(rinfo, s32 + 1, 1, tb_h, tb_l);
+                        titem_finish(1, tb_h, tb_l);
+                    } else {
+                        trace(20);
+                        lds_barrier();  // every wave has finished reading the old slab
+                        trace(21);
+                        titem_finish(0, ta_h, ta_l);
+                        titem_finish(1, tb_h, tb_l);
+                        trace(22);
+                    }
+                } else {
+                    lds_barrier();
+                }
                 lds_barrier();
+                trace(23);
             }
         }
 
         // ---- epilogue: output transform in registers, bias, the two output rows of every tile-pixel through LDS, then
         // (output pixel, 8-channel) items: residual, ReLU, split, two 16-byte stores
         lds_barrier();  // all waves are done with the V planes
+        trace(30);
         if constexpr (ABL & 4) {
             float sacc = 0.f;
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) sacc += acc[xi][0][0] + acc[xi][1][3];
             if (sacc == 12345.f) p.range_flag[1] = 1u;
+            if constexpr (AHEAD && !(ABL & 2)) {
+                titem_issue(rnext, 0, 0, ta_h, ta_l);
+                titem_issue(rnext, 0, 1, tb_h, tb_l);
+            }
         } else {
+            // (output pixel, 8-channel) items of the store loop: idx = tid + 256 k, k = 0..7 -> staged row pr = idx >> 3 (output row of the
+            // pair = pr >> 7, V row = pr & 127), channel group g = idx & 7.  Their residual pixels are requested EARLY -- the first four
+            // items' before the accumulators are staged, the last four's right behind -- so that the store loop waits for nothing
+            int tid_e = tid;
+            asm volatile("" : "+v"(tid_e));  // (addresses of the eight items are recomputed per tile instead of living through the tap loop)
+            uint32_t ioff[8];
+            pl_u32x4 rh[8], rl[8];
+            auto item_request = [&](int k) __attribute__((always_inline)) {
+                const int idx = tid_e + kPlThreads * k;
+                const int pr = idx >> 3, g = idx & 7;
+                const int2 ri = rinfo[pr & (kWRows - 1)];
+                const bool ok = (ri.y >> ((pr >> 7) ? 7 : 8)) & 1;
+                ioff[k] = ok ? (uint32_t)ri.x + (uint32_t)(1 + (pr >> 7)) * rowB + (uint32_t)(tn * 256 + g * 16) : kPlOob;
+                if constexpr (RES) {
+                    rh[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[k], 0, 0));
+                    rl[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[k], 128, 0));
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) item_request(k);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -272,65 +401,69 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
                         y0[e] = __builtin_fmaf((a0 + a1) + a2, sv[e], bv[e]);
                         y1[e] = __builtin_fmaf((a1 - a2) - a3, sv[e], bv[e]);
                     }
-                    *reinterpret_cast<f32x4 *>(vlds + (2 * lrow[i]) * kPlRowB + (cb0 + 8 * q) * 4) = y0;
-                    *reinterpret_cast<f32x4 *>(vlds + (2 * lrow[i] + 1) * kPlRowB + (cb0 + 8 * q) * 4) = y1;
+                    // (staged row = 128 * output row of the pair + V row: consecutive lanes 272 B apart, conflict-free 16-byte writes)
+                    *reinterpret_cast<f32x4 *>(vlds + lrow[i] * kPlRowB + (cb0 + 8 * q) * 4) = y0;
+                    *reinterpret_cast<f32x4 *>(vlds + (kWRows + lrow[i]) * kPlRowB + (cb0 + 8 * q) * 4) = y1;
                 }
+#pragma unroll
+            for (int k = 4; k < 8; ++k) item_request(k);
+            // the accumulators are staged: the transform loads of the next tile's first slab go out under the store loop
+            if constexpr (AHEAD && !(ABL & 2)) {
+                titem_issue(rnext, 0, 0, ta_h, ta_l);
+                titem_issue(rnext, 0, 1, tb_h, tb_l);
+            }
+            trace(31);
             lds_barrier();
+            trace(32);
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {  // 2048 items = 8 per thread, four at a time (residual registers)
-                uint32_t ioff[4];
-                pl_u32x4 rh[4], rl[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int idx = tid + kPlThreads * (4 * jb + jj);
-                    const int pr = idx >> 3, g = idx & 7;  // staged row = 2 * tile-pixel + output row of the pair
-                    const int2 ri = rowinfo[(pr >> 1) + 1];
-                    const bool ok = (ri.y >> ((pr & 1) ? 7 : 8)) & 1;
-                    ioff[jj] = ok ? (uint32_t)ri.x + (uint32_t)(1 + (pr & 1)) * rowB + (uint32_t)(tn * 256 + g * 16) : kPlOob;
-                    if constexpr (RES) {
-                        rh[jj] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[jj], 0, 0));
-                        rl[jj] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[jj], 128, 0));
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int idx = tid + kPlThreads * (4 * jb + jj);
-                    const int pr = idx >> 3, g = idx & 7;
-                    f32x4 a = *reinterpret_cast<const f32x4 *>(vlds + pr * kPlRowB + g * 32);
-                    f32x4 b = *reinterpret_cast<const f32x4 *>(vlds + pr * kPlRowB + g * 32 + 16);
-                    if constexpr (RES) {
-                        const f16x8 h8 = __builtin_bit_cast(f16x8, rh[jj]), l8 = __builtin_bit_cast(f16x8, rl[jj]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a[e] += (float)h8[e] + (float)l8[e];
-                            b[e] += (float)h8[4 + e] + (float)l8[4 + e];
-                        }
-                    }
+            for (int k = 0; k < 8; ++k) {
+                const int idx = tid_e + kPlThreads * k;
+                const int pr = idx >> 3, g = idx & 7;
+                f32x4 a = *reinterpret_cast<const f32x4 *>(vlds + pr * kPlRowB + g * 32);
+                f32x4 b = *reinterpret_cast<const f32x4 *>(vlds + pr * kPlRowB + g * 32 + 16);
+                if constexpr (RES) {
+                    const f16x8 h8 = __builtin_bit_cast(f16x8, rh[k]), l8 = __builtin_bit_cast(f16x8, rl[k]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        a[e] = __int_as_float(max(__float_as_int(a[e]), 0));
-                        b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
+                        a[e] += (float)h8[e] + (float)l8[e];
+                        b[e] += (float)h8[4 + e] + (float)l8[4 + e];
                     }
-                    omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-                    u32x2 pa[2], pb[2];
-                    split2_f16(a, pa);
-                    split2_f16(b, pb);
-                    const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(hi, orsrc, ioff[jj], 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(lo, orsrc, ioff[jj], 128, 0);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = __int_as_float(max(__float_as_int(a[e]), 0));
+                    b[e] = __int_as_float(max(__float_as_int(b[e]), 0));
+                }
+                if (ioff[k] != kPlOob)  // (rows 0 and 127 of the tile and rows beyond the tensor carry no output)
+                    omax = fmaxf(omax, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+                u32x2 pa[2], pb[2];
+                split2_f16(a, pa);
+                split2_f16(b, pb);
+                const pl_u32x4 hi = {pa[0][0], pa[0][1], pb[0][0], pb[0][1]}, lo = {pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+                __builtin_amdgcn_raw_buffer_store_b128(hi, orsrc, ioff[k], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(lo, orsrc, ioff[k], 128, 0);
             }
         }
+        trace(33);
         if (!more) break;
-        lds_barrier();  // the staged tile has been read back, the row table is free
-        make_rowinfo(m0n);
-        // the staging rows overwrote the zero rows' neighbourhood?  No: staging uses rows 0..255 x 272 B = bytes [0, 69 632) of the V
-        // region, and the zero row of plane 0 sits at byte 130 * 144 = 18 720 -- inside it.  Rewrite the four zero rows.
-        if (tid < 4 * 8) *reinterpret_cast<pl_u32x4 *>(vlds + (tid >> 3) * kWPlaneB + T * kWRowB + (tid & 7) * 16) = pl_u32x4{0u, 0u, 0u, 0u};
+        lds_barrier();  // the staged tile has been read back
+        trace(34);
+        zero_rows();
+        if constexpr (!(ABL & 2)) {
+            if constexpr (!AHEAD) {
+                titem_issue(rnext, 0, 0, ta_h, ta_l);
+                titem_finish(0, ta_h, ta_l);
+                titem_issue(rnext, 0, 1, tb_h, tb_l);
+                titem_finish(1, tb_h, tb_l);
+            } else {
+                titem_finish(0, ta_h, ta_l);
+                titem_finish(1, tb_h, tb_l);
+            }
+        }
+        trace(35);
         lds_barrier();
-        if constexpr (!(ABL & 2)) transform(0);
-        lds_barrier();
-        v = vn, m0 = m0n;
+        trace(36);
+        v = vn, m0 = m0n, cur ^= 1;
     }
     if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);
 }

@@ -256,7 +256,7 @@ struct DenseWresParams {
 };
 
 // ABL (tools/dense_probe.hip only; 0 in the product): 1 no activation loads, 2 no LDS staging writes, 4 no matrix instructions,
-// 8 no fragment reads, 16 no result stores, 32 no barriers.
+// 8 no fragment reads, 16 no result stores, 32 no barriers; 64 (product A/B knob C3HIP_GX2_NT): non-temporal result stores.
 template <int ABL = 0>
 __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_wres_kernel(DenseWresParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * kWrStage + 8192];
@@ -329,6 +329,8 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_wres_kernel(DenseW
         for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
         if constexpr (ABL & 16) {
             if (val[0] == 1234.5f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+        } else if constexpr (ABL & 64) {  // A/B knob (C3HIP_GX2_NT=1): the 173 MB of pre-activations leave with the non-temporal hint
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 2);
         } else {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
         }

@@ -182,6 +182,42 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             const double tiles_x = sppf ? (double)((n + wpt - 1) / wpt) : (double)tiles_m;  // pixel tiles the launch really runs
             const int c1_rows = l == 1 ? (kPlBM + 2 * ww[l] + 2 + 31) / 32 * 32 : kPlBM;
             ps.mfma(2.0 * tiles_x * kPlBM * (double)Cout * 9.0 * cin * 3 + (src8 ? 2.0 * tiles_m * c1_rows * 64.0 * (m->C == 8 ? 80.0 : 96.0) * 2 : 0.0), true);
+            m->choice_s1[(l / 3) * 2 + (l % 3 - 1)] = 'd';
+            // F(2,3) along H (c3_conv3w.h) for the plain plane-to-plane layers: 12 instead of 18 groups of piece products per output
+            // pair.  Not where conv1 is computed inside the kernel (res1a / res1b) or the pyramid pooling is its epilogue (res3b):
+            // those stay on the direct kernel.  C3HIP_WINO: 0 none, 1 the 64- / 128-channel ones, 2 (default) every plain one -- same-box
+            // A/B of the whole step (profiles/r05_e_ab_wino_step*.txt): B = 256 707 k -> 729 k windows/s (res2a / res2b 48.3 / 50.3 -> 41.7 /
+            // 43.8 us; res3a unchanged: 244 tiles = one workgroup per CU), B = 1000 774 k -> 804 k (res3a 172 -> 148.5 us as well).
+            const bool wino_layer = m->wino >= 2 || (m->wino == 1 && (Cout == 64 || Cout == 128));
+            if (wino_layer && !src8 && !sppf && m->wconv_w[l]) {
+                WinoConvParams wp;
+                wp.x = m->act[l - 1], wp.wf = m->wconv_w[l], wp.bias = m->conv_b[l], wp.post = m->wconv_post[l];
+                wp.res = res ? m->act[l - 2] : nullptr, wp.out = m->act[l], wp.range_flag = m->range_flag;
+                wp.M = M, wp.H = hh[l], wp.W = ww[l], wp.Hj = (hh[l] + 1) / 2, wp.Mp = (int)(n * wp.Hj * ww[l]);
+                TRY(div_magic(wp.Hj * ww[l], (int64_t)wp.Mp + 2 * kWTM, &wp.mg_hjw));
+                TRY(div_magic(ww[l], wp.Hj * ww[l], &wp.mg_w));
+                const int tiles_w = (wp.Mp + kWTM - 1) / kWTM;
+                wp.tiles = tiles_w * (Cout / 64);
+                ps.mfma(2.0 * tiles_w * kWRows * (double)Cout * 12.0 * cin * 3, true);
+                int gw = wp.tiles;
+                const int wslots = m->wg_slots, wunit = 8 * (Cout / 64);
+                if (gw > wslots) gw = std::max(wunit, wslots / wunit * wunit);
+                const dim3 wgrid(gw), wblock(kPlThreads);
+                if (Cout == 64) {
+                    if (res) hipLaunchKernelGGL((conv3x3_wino_planes_kernel<64, true>), wgrid, wblock, 0, s, wp);
+                    else hipLaunchKernelGGL((conv3x3_wino_planes_kernel<64, false>), wgrid, wblock, 0, s, wp);
+                } else if (Cout == 128) {
+                    if (res) hipLaunchKernelGGL((conv3x3_wino_planes_kernel<128, true>), wgrid, wblock, 0, s, wp);
+                    else hipLaunchKernelGGL((conv3x3_wino_planes_kernel<128, false>), wgrid, wblock, 0, s, wp);
+                } else {
+                    if (res) hipLaunchKernelGGL((conv3x3_wino_planes_kernel<256, true>), wgrid, wblock, 0, s, wp);
+                    else hipLaunchKernelGGL((conv3x3_wino_planes_kernel<256, false>), wgrid, wblock, 0, s, wp);
+                }
+                HIP_TRY(hipGetLastError());
+                m->choice_s1[(l / 3) * 2 + (l % 3 - 1)] = 'w';
+                cin = Cout;
+                continue;
+            }
             // persistent: one workgroup per tile when they all fit (two 256-thread workgroups, <= 70 KB of LDS each, per CU), else as
             // many as fit, rounded down so that a workgroup's tiles share their column tile (c3_conv3.h)
             int g = cp.tiles;
@@ -340,7 +376,9 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             // LSTM launch (three batches in flight 5.46 M -> 5.59 M windows/s; alone 4.9 M -> 4.3 M, hence the caller's hint)
             if (m->sharing > 1) wp.lanes_per_xcd = std::max(1, wp.lanes_per_xcd / 2);
             m->choice_proj2 = m->sharing > 1 ? "weights-resident-half-grid" : "weights-resident";
-            hipLaunchKernelGGL(dense_planes_wres_kernel<0>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
+            static const bool gx2_nt = getenv("C3HIP_GX2_NT") && atoi(getenv("C3HIP_GX2_NT")) != 0;  // A/B knob (profiles/r05_*_ab_gx2_nt.txt)
+            if (gx2_nt) hipLaunchKernelGGL(dense_planes_wres_kernel<64>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
+            else hipLaunchKernelGGL(dense_planes_wres_kernel<0>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
             HIP_TRY(hipGetLastError());
         } else if (h1_planes) {  // batches below ~190 windows: fewer than two row tiles per lane
             DensePlanesParams dp;

@@ -37,6 +37,7 @@
 #include "c3_host.h"
 #include "c3_conv3.h"
 #include "c3_conv3s2.h"
+#include "c3_conv3w.h"
 #include "c3_l4.h"
 #include "c3_dense.h"
 
@@ -141,6 +142,9 @@ struct c3_model {
     float *pconv_w[9] = {};  // stride-1 convs: conv3x3_planes_kernel chunks in fragment order [Cout/64][Cin/64][9][2][4][2][64 lanes x 16 B];
                              // stride-2 convs: conv3x3_s2_planes_kernel chunks, the same fragment order [Cout/64][9 Cin/64][2][4][2][64 lanes x 16 B]
     float *pconv_pre[9] = {}, *pconv_post[9] = {};  // [Cout] the output channels' powers of two 2^k / 2^-k (c3_pack.h row_scales)
+    float *wconv_w[9] = {};     // stride-1 convs: the F(2,3)-along-H weights U of conv3x3_wino_planes_kernel (c3_conv3w.h) in fragment
+                                // order [Cout/64][Cin/32][12 taps][2][2][2][64 lanes x 16 B]
+    float *wconv_post[9] = {};  // [Cout] 2^-k of U's rows
     // shared FC tail
     float *l4_w = nullptr, *l4_b = nullptr;  // [FC][K4] native layout (fp32 form)
     float *l4_wf = nullptr;                  // the same as two fp16 pieces in fragment order (c3_l4.h), every feature row times its power of two
@@ -158,6 +162,9 @@ struct c3_model {
 
     // ---- switches (README) ----
     bool spp_fused = true;    // PyramidPolling as the epilogue of res3b (c3_conv3.h SPPF; 12 x 5 windows); env C3HIP_SPP_FUSED
+    int wino = 2;             // stride-1 convolutions on F(2,3) along H (c3_conv3w.h: 12 instead of 18 piece-product groups per output pair)
+                              // where the layer is a plain plane-to-plane one (res2a, res2b, res3a); env C3HIP_WINO: 0 = the direct kernels
+                              // everywhere, 1 = only the 64- / 128-channel layers
     bool conv1_fused = true;  // conv1 computed inside res1a / res1b (c3_conv3.h SRC8): no conv1 launch, no conv1 planes; env C3HIP_CONV1_FUSED
     bool half_tiles = true;   // LSTM recurrences on 8-window tiles while 16-window tiles would leave CUs without a workgroup; env C3HIP_HALF_TILES
     int sharing = 1;          // handles the CALLER says feed this GPU side by side (c3_model_set_sharing): beside other batches the chip is
@@ -186,6 +193,7 @@ struct c3_model {
     // which kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
     const char *choice_lstm1 = "-", *choice_proj2 = "-", *choice_lstm2 = "-", *choice_fa = "-";
     const char *choice_s2[2] = {"-", "-"};  // conv3, conv5: one or two workgroups per CU (c3_conv3s2.h PAIR)
+    char choice_s1[8] = "------";           // the six stride-1 convolutions res1a .. res3b: d = direct, w = F(2,3) along H
 
     bool prof = false;
     std::vector<ProfRec> recs;

@@ -82,6 +82,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
     if (const char *e = getenv("C3HIP_FP32")) m->f16_ok = atoi(e) == 0;  // start on the fp32-MFMA forms (what the range guard falls back to)
     if (const char *e = getenv("C3HIP_CONV1_FUSED")) m->conv1_fused = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_WINO")) m->wino = atoi(e);
     if (const char *e = getenv("C3HIP_SPP_FUSED")) m->spp_fused = atoi(e) != 0;
     m->tail_fused = kind == C3_KIND_PILEUP;
     if (const char *e = getenv("C3HIP_TAIL_FUSED")) m->tail_fused = atoi(e) != 0;
@@ -237,7 +238,8 @@ int c3_model_describe(c3_model *m, char *buf, int n) {
     if (m->kind == C3_KIND_PILEUP)
         snprintf(buf, (size_t)n, "sharing=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d", m->sharing, m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok);
     else
-        snprintf(buf, (size_t)n, "sharing=%d conv_stack=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->choice_fa, m->choice_s2[0], m->choice_s2[1], (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d conv_stack=%s stride1=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->choice_fa, m->choice_s1, m->choice_s2[0],
+                 m->choice_s2[1], (int)!m->f16_ok);
     return 0;
 }
 
@@ -267,6 +269,8 @@ int c3_model_destroy(c3_model *m) {
         if (m->pconv_w[l]) (void)hipFree(m->pconv_w[l]);
         if (m->pconv_pre[l]) (void)hipFree(m->pconv_pre[l]);
         if (m->pconv_post[l]) (void)hipFree(m->pconv_post[l]);
+        if (m->wconv_w[l]) (void)hipFree(m->wconv_w[l]);
+        if (m->wconv_post[l]) (void)hipFree(m->wconv_post[l]);
     }
     for (auto &sl : m->slot) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);

@@ -522,6 +522,43 @@ static int pack_conv(c3_model *m, const TensorMap &tm, int l, int Cin, const FaC
                                     memcpy(&q16[dst + 64 * 8], &h1, 2);
                                 }
         TRY(upload(m, &m->pconv_w[l], pk));
+        // conv3x3_wino_planes_kernel (c3_conv3w.h): F(2,3) along the rows.  Per column tap kw the three row taps g0, g1, g2 of a
+        // (cout, cin) pair become U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 -- formed in double from the
+        // folded fp32 weights, rounded to fp32 once, then every output row times its own power of two and split into the two fp16
+        // pieces.  Chunk (column tile tn, 32-channel slab, tap = xi * 3 + kw) = 8 KB in fragment order [cout half wn][k-step][hi | lo][lane]
+        // x 16 B: lane (n = lane & 31, kh = lane >> 5) holds channels 32 slab + 8 (2 ks + kh) .. + 7 of cout 64 tn + 32 wn + n.
+        {
+            const int NS32 = Cin / 32;
+            std::vector<float> u((size_t)Cout * 12 * Cin);
+            for (int co = 0; co < Cout; ++co)
+                for (int kw = 0; kw < 3; ++kw)
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const double g0 = pw[(size_t)co * ldb + (size_t)(0 + kw) * Cin + ci], g1 = pw[(size_t)co * ldb + (size_t)(3 + kw) * Cin + ci],
+                                     g2 = pw[(size_t)co * ldb + (size_t)(6 + kw) * Cin + ci];
+                        const double uu[4] = {g0, 0.5 * (g0 + g1 + g2), 0.5 * (g0 - g1 + g2), g2};
+                        for (int xi = 0; xi < 4; ++xi) u[((size_t)co * 12 + xi * 3 + kw) * Cin + ci] = (float)uu[xi];
+                    }
+            std::vector<float> scw, postw;
+            row_scales(u.data(), Cout, (size_t)12 * Cin, scw, postw);
+            TRY(upload(m, &m->wconv_post[l], postw));
+            std::vector<float> pu((size_t)NS * NS32 * 12 * 2048);  // 8 KB per chunk
+            uint16_t *u16 = reinterpret_cast<uint16_t *>(pu.data());
+            for (int tn = 0; tn < NS; ++tn)
+                for (int s32 = 0; s32 < NS32; ++s32)
+                    for (int tap = 0; tap < 12; ++tap)
+                        for (int wn = 0; wn < 2; ++wn)
+                            for (int ks = 0; ks < 2; ++ks)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int j = 0; j < 8; ++j) {
+                                        const int co = tn * 64 + 32 * wn + (lane & 31), ci = s32 * 32 + 8 * (2 * ks + (lane >> 5)) + j;
+                                        const float v = u[((size_t)co * 12 + tap) * Cin + ci] * scw[co];  // exact
+                                        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+                                        const size_t dst = (((((((size_t)tn * NS32 + s32) * 12 + tap) * 2 + wn) * 2 + ks) * 2) * 64 + lane) * 8 + j;
+                                        memcpy(&u16[dst], &h0, 2);
+                                        memcpy(&u16[dst + 64 * 8], &h1, 2);
+                                    }
+            TRY(upload(m, &m->wconv_w[l], pu));
+        }
     }
     if (kConvStride[l] == 2 && l > 0 && Cin % 64 == 0 && Cout % kS2BN == 0) {
         // conv3x3_s2_planes_kernel (c3_conv3s2.h): column tiles of 64 couts, chunk kc = tap * Cin/64 + slab = 16 KB in the FRAGMENT order of

@@ -761,3 +761,45 @@ def test_two_handles_side_by_side_give_the_same_rows(oracle_mod):
             assert np.array_equal(y, y_alone)
     d = m1.describe()
     assert "sharing=2" in d and "lstm1=fused-f16x3-full-tiles" in d and "proj2=weights-resident-half-grid" in d and "lstm2=f16x3-full-tiles" in d
+
+
+def test_rows_winograd_convolutions_against_the_direct_ones(monkeypatch, oracle_mod):
+    """F(2,3) along the image rows (c3_conv3w.h): 12 instead of 18 groups of piece products per output pair for the plain
+    plane-to-plane stride-1 convolutions.  C3HIP_WINO=0: the direct kernels everywhere; 1: the 64- and 128-channel layers
+    that are plain (res2a / res2b; res1a / res1b too when conv1 is its own launch); 2 (default): every plain stride-1 layer (res3a as
+    well).  With conv1 and the pooling as launches of their own all six layers take the form ("wwwwww").  Every selection stays within the parity gate against
+    the oracle, within 1e-5 of the direct form with identical labels, and a window's row does not depend on the batch it travels
+    in (tiles of 126 row pairs x columns: 1, 5, 37 and 330 windows cover one partial tile, ragged last tiles and several tiles per
+    workgroup on every stage)."""
+    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=131)
+    sdt = syn.make_state_dict(syn.FULL_ALIGNMENT, 9, True, seed=132, trained_like=True)
+    seen = set()
+    for n in (1, 5, 37, 330):
+        x = syn.make_fa_windows(n, seed=133 + n)
+        sel = np.unique(np.r_[0:min(n, 8), max(0, n - 8):n])
+        y_ref = oracle_mod.fa_forward(sd, x[sel], True)
+        rows = {}
+        for name, env in (("direct", {"C3HIP_WINO": "0"}), ("narrow", {"C3HIP_WINO": "1"}), ("default", {}),
+                          ("all-six", {"C3HIP_WINO": "2", "C3HIP_CONV1_FUSED": "0", "C3HIP_SPP_FUSED": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m = make_model(syn.FULL_ALIGNMENT, 8, True, sd)
+            rows[name] = m.predict_numpy(x)
+            form = [t for t in m.describe().split() if t.startswith("stride1=")][0]
+            seen.add((name, form))
+            util.assert_rows_match(rows[name][sel], y_ref, what=f"{name} ({form}), {n} windows")
+            if n > 3 and name != "direct":  # the same windows in another batch composition: bit-identical rows
+                k = n // 3
+                assert np.array_equal(np.concatenate([m.predict_numpy(x[:k]), m.predict_numpy(x[k:])]), rows[name]), (name, n)
+            for k in env:
+                monkeypatch.delenv(k)
+        for name in ("narrow", "default", "all-six"):
+            assert np.abs(rows[name] - rows["direct"]).max() < 1e-5, (name, n)
+            for lo, hi in util.HEAD_SLICES:
+                assert (rows[name][:, lo:hi].argmax(1) == rows["direct"][:, lo:hi].argmax(1)).all(), (name, n, lo)
+    assert ("direct", "stride1=dddddd") in seen and ("narrow", "stride1=ddwwdd") in seen, seen
+    assert ("default", "stride1=ddwwwd") in seen and ("all-six", "stride1=wwwwww") in seen, seen
+    # trained-like weights, 9-channel (dwell) windows, every layer on the form
+    monkeypatch.setenv("C3HIP_WINO", "2"), monkeypatch.setenv("C3HIP_CONV1_FUSED", "0"), monkeypatch.setenv("C3HIP_SPP_FUSED", "0")
+    xt = syn.make_fa_windows(41, seed=139, channels=9)
+    util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, 9, True, sdt).predict_numpy(xt), oracle_mod.fa_forward(sdt, xt, True), what="trained-like, all six")

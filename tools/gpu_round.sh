@@ -6,6 +6,7 @@
 #   pmc_fa / pmc_p       HBM traffic of the same leg: separate FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py reads them)
 #   l2_fa / l2_p         L2 hit rate of the same leg (TCC_HIT_sum / TCC_MISS_sum; tools/pmc_traffic.py adds it to the traffic record)
 #   sq_fa / sq_p         SQ busy / MFMA busy / instruction mix of the same leg
+#   wprobe    tools/wino_probe.hip: the F(2,3)-along-H convolution against the direct one (agreement, times, ablations)
 #   dprobe / cprobe / lprobe   tools/dense_probe.hip / conv_probe.hip / lstm_probe.hip (ablations and phase traces of the dense / convolution / recurrence kernels)
 #   info      rocminfo / lscpu / cgroup quota of the box
 set -u
@@ -44,6 +45,7 @@ for s in ${1:-test bench}; do
     cprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/conv_probe.hip -o /tmp/conv_probe && timeout 300 /tmp/conv_probe > gpurun_out/conv_probe.txt 2>&1; echo "cprobe rc=$?"; cat gpurun_out/conv_probe.txt ;;
     l4probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/l4_probe.hip -o /tmp/l4_probe && timeout 300 /tmp/l4_probe > gpurun_out/l4_probe.txt 2>&1; echo "l4probe rc=$?"; cat gpurun_out/l4_probe.txt ;;
     lprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/lstm_probe.hip -o /tmp/lstm_probe && timeout 300 /tmp/lstm_probe > gpurun_out/lstm_probe.txt 2>&1; echo "lprobe rc=$?"; cat gpurun_out/lstm_probe.txt ;;
+    wprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/wino_probe.hip -o /tmp/wino_probe && timeout 300 /tmp/wino_probe ${WPROBE_ARGS:-} > gpurun_out/wino_probe.txt 2>&1; echo "wprobe rc=$?"; cat gpurun_out/wino_probe.txt ;;
     info)    (rocminfo | grep -E "Name|Compute Unit|Max Clock|Wavefront" | head -40; lscpu | head -20; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null) > gpurun_out/info.txt 2>&1 ;;
     *)       echo "unknown stage $s" ;;
   esac
