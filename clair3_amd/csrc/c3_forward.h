@@ -426,17 +426,57 @@ static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype
         return fail("pileup windows must be int8 or int32 (got dtype %d)", x_dtype);
     TRY(ensure_workspace(m, batch));
     const int64_t wbytes = c3_model_window_bytes(m, x_dtype);
+    auto run = [&](hipStream_t st, const char *xp, const int32_t *sp, int64_t n, float *yp) -> int {
+        if (m->kind == C3_KIND_FULL_ALIGNMENT) return run_fa(m, st, (const int8_t *)xp, n, yp);
+        if (x_dtype == C3_DTYPE_I8) return run_pileup_t<int8_t>(m, st, (const int8_t *)xp, n, yp, sp);
+        return run_pileup_t<int32_t>(m, st, (const int32_t *)xp, n, yp, sp);
+    };
     for (int64_t off = 0; off < batch; off += m->cap) {
         const int64_t n = std::min<int64_t>(m->cap, batch - off);
         const char *xp = starts ? (const char *)x : (const char *)x + off * wbytes;  // region matrix is shared
         const int32_t *sp = starts ? starts + off : nullptr;
         float *yp = y + off * m->row;
-        if (m->kind == C3_KIND_FULL_ALIGNMENT)
-            TRY(run_fa(m, s, (const int8_t *)xp, n, yp));
-        else if (x_dtype == C3_DTYPE_I8)
-            TRY(run_pileup_t<int8_t>(m, s, (const int8_t *)xp, n, yp, sp));
-        else
-            TRY(run_pileup_t<int32_t>(m, s, (const int32_t *)xp, n, yp, sp));
+        // DUO (C3HIP_DUO=1): the micro-batch as two halves on two streams.  Every layer is its own launch and every workgroup of a
+        // launch is in the same phase, so ~10 us of head and tail per launch overlap nothing when one batch is alone on the chip
+        // (DESIGN.md 3.8); windows are independent, so the second half's launches -- enqueued behind the first half's, i.e. half a
+        // step out of phase -- fill them.  Each half works in its own part of the workspace (the buffers are sized for the whole
+        // micro-batch); a window's row does not depend on the batch it travels in, so the rows are the undivided call's bit for bit.
+        const int64_t duo_min = m->kind == C3_KIND_FULL_ALIGNMENT ? 192 : 768;
+        if (m->duo > 0 && !m->keep && m->sharing <= 1 && n >= duo_min) {
+            if (!m->duo_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&m->duo_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&m->duo_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&m->duo_join, hipEventDisableTiming));
+            }
+            const int64_t n0 = ((n / 2 + 15) / 16) * 16, n1 = n - n0;  // whole 16-window tiles in the first half
+            HIP_TRY(hipEventRecord(m->duo_fork, s));
+            HIP_TRY(hipStreamWaitEvent(m->duo_stream, m->duo_fork, 0));
+            TRY(run(s, xp, sp, n0, yp));
+            // the second half: the same buffers, behind the first half's share of each
+            float *const act0[9] = {m->act[0], m->act[1], m->act[2], m->act[3], m->act[4], m->act[5], m->act[6], m->act[7], m->act[8]};
+            float *const spp0 = m->spp, *const part0 = m->part, *const dbg0 = m->l4dbg, *const h10 = m->h1, *const gx20 = m->gx2, *const h20 = m->h2;
+            if (m->kind == C3_KIND_FULL_ALIGNMENT) {
+                int hh[10], ww[10];
+                fa_geometry(m, hh, ww);
+                size_t biggest = 0;
+                for (int l = 0; l < 9; ++l) biggest = std::max(biggest, (size_t)hh[l + 1] * ww[l + 1] * kConvCout[l]);
+                for (int l = 0; l < 9; ++l) m->act[l] = act0[l] + biggest * (size_t)n0;
+                m->spp = spp0 + (size_t)n0 * m->K4;
+            } else {
+                const size_t T = (size_t)m->positions;
+                m->h1 = h10 + (size_t)n0 * T * 256, m->gx2 = gx20 + (size_t)n0 * T * 1280, m->h2 = h20 + (size_t)n0 * T * 320;
+            }
+            m->part = part0 + (size_t)l4_splits(m) * n0 * m->FC, m->l4dbg = dbg0 + (size_t)n0 * m->FC;
+            const int rc = run(m->duo_stream, starts ? xp : xp + n0 * wbytes, sp ? sp + n0 : nullptr, n1, yp + n0 * m->row);
+            for (int l = 0; l < 9; ++l) m->act[l] = act0[l];
+            m->spp = spp0, m->part = part0, m->l4dbg = dbg0, m->h1 = h10, m->gx2 = gx20, m->h2 = h20;
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(m->duo_join, m->duo_stream));
+            HIP_TRY(hipStreamWaitEvent(s, m->duo_join, 0));
+            m->last_n = n0;
+            continue;
+        }
+        TRY(run(s, xp, sp, n, yp));
         m->last_n = n;
     }
     return 0;

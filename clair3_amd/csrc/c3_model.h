@@ -119,6 +119,8 @@ struct c3_model {
     int row = 24;  // floats per output row: nout, + kDecodeCols when c3_model_set_decode_columns is on
     bool loaded = false;
     hipStream_t stream = nullptr, h2d_stream = nullptr;  // kernels (and the rows on their way out); staged windows on their way in
+    hipStream_t duo_stream = nullptr;                    // the second half of a micro-batch (c3_forward.h forward_device, C3HIP_DUO)
+    hipEvent_t duo_fork = nullptr, duo_join = nullptr;
 
     // ---- packed weights (device) ----
     // pileup
@@ -173,6 +175,7 @@ struct c3_model {
     bool lock_sources = false;  // c3_model_set_lock_sources: c3_predict may page-lock the caller's windows for the duration of a call
     bool tail_fused = false;  // the split-K sum of L4 inside fc_tail_mfma_kernel (c3_tail.h) instead of its own launch: on for the pileup network (+0.7 %:
                               // 15 partials of 128 features), off for full alignment (-1 %: four branch workgroups re-read 28 partials of 256); env C3HIP_TAIL_FUSED
+    int duo = 0;              // a micro-batch as two halves on two streams inside one call (c3_forward.h forward_device); env C3HIP_DUO
     int wg_slots = 512;       // co-resident 256-thread / 64 KiB-LDS workgroups on the device (2 per CU)
 
     void *decode_dev = nullptr;  // scratch of c3_outcome_maxima

@@ -83,6 +83,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_FP32")) m->f16_ok = atoi(e) == 0;  // start on the fp32-MFMA forms (what the range guard falls back to)
     if (const char *e = getenv("C3HIP_CONV1_FUSED")) m->conv1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_WINO")) m->wino = atoi(e);
+    if (const char *e = getenv("C3HIP_DUO")) m->duo = atoi(e);
     if (const char *e = getenv("C3HIP_SPP_FUSED")) m->spp_fused = atoi(e) != 0;
     m->tail_fused = kind == C3_KIND_PILEUP;
     if (const char *e = getenv("C3HIP_TAIL_FUSED")) m->tail_fused = atoi(e) != 0;
@@ -236,10 +237,11 @@ int c3_model_set_lock_sources(c3_model *m, int on) {
 int c3_model_describe(c3_model *m, char *buf, int n) {
     if (!m || !buf || n <= 0) return fail("null argument");
     if (m->kind == C3_KIND_PILEUP)
-        snprintf(buf, (size_t)n, "sharing=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d", m->sharing, m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d duo=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d", m->sharing, m->duo, m->choice_lstm1, m->choice_proj2, m->choice_lstm2,
+                 (int)!m->f16_ok);
     else
-        snprintf(buf, (size_t)n, "sharing=%d conv_stack=%s stride1=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->choice_fa, m->choice_s1, m->choice_s2[0],
-                 m->choice_s2[1], (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d duo=%d conv_stack=%s stride1=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->duo, m->choice_fa, m->choice_s1,
+                 m->choice_s2[0], m->choice_s2[1], (int)!m->f16_ok);
     return 0;
 }
 
@@ -287,6 +289,9 @@ int c3_model_destroy(c3_model *m) {
     }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     if (m->h2d_stream) (void)hipStreamDestroy(m->h2d_stream);
+    if (m->duo_stream) (void)hipStreamDestroy(m->duo_stream);
+    if (m->duo_fork) (void)hipEventDestroy(m->duo_fork);
+    if (m->duo_join) (void)hipEventDestroy(m->duo_join);
     delete m;
     return 0;
 }

@@ -803,3 +803,35 @@ def test_rows_winograd_convolutions_against_the_direct_ones(monkeypatch, oracle_
     monkeypatch.setenv("C3HIP_WINO", "2"), monkeypatch.setenv("C3HIP_CONV1_FUSED", "0"), monkeypatch.setenv("C3HIP_SPP_FUSED", "0")
     xt = syn.make_fa_windows(41, seed=139, channels=9)
     util.assert_rows_match(make_model(syn.FULL_ALIGNMENT, 9, True, sdt).predict_numpy(xt), oracle_mod.fa_forward(sdt, xt, True), what="trained-like, all six")
+
+
+def test_a_micro_batch_as_two_halves_on_two_streams(monkeypatch, oracle_mod):
+    """C3HIP_DUO=1 (c3_forward.h forward_device): from 192 full-alignment / 768 pileup windows on, a micro-batch runs as two halves on
+    two streams inside the call, each half in its own part of the workspace.  A window's row does not depend on the batch it travels
+    in, so the rows must be the undivided call's bit for bit: at the thresholds, at sizes whose halves are ragged, across several
+    micro-batches (2100 full-alignment windows = 2048 + 52), for int32 pileup windows, through the blocking call, the ring and the
+    device-resident entry; and against the oracle."""
+    import torch
+    for kind, ch, indel, sizes in ((syn.FULL_ALIGNMENT, 8, True, (191, 192, 333, 2100)), (syn.PILEUP, 18, False, (767, 768, 1024, 1501))):
+        sd = syn.make_state_dict(kind, ch, indel, seed=141)
+        for n in sizes:
+            x = syn.make_windows(kind, n, seed=142 + n, channels=ch)
+            monkeypatch.setenv("C3HIP_DUO", "0")
+            m0 = make_model(kind, ch, indel, sd)
+            y0 = m0.predict_numpy(x)
+            assert "duo=0" in m0.describe()
+            monkeypatch.setenv("C3HIP_DUO", "1")
+            m1 = make_model(kind, ch, indel, sd)
+            y1 = m1.predict_numpy(x)
+            assert "duo=1" in m1.describe()
+            assert np.array_equal(y0, y1), (kind, n)
+            t = m1.wait(m1.submit(x, slot=0))
+            assert np.array_equal(t, y0), (kind, n, "ring")
+            yd = m1(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+            assert np.array_equal(yd, y0), (kind, n, "device-resident")
+            if kind == syn.PILEUP and n == 1024:
+                assert np.array_equal(m1.predict_numpy(x.astype(np.int32)), m0.predict_numpy(x.astype(np.int32)))
+            monkeypatch.delenv("C3HIP_DUO")
+        sel = np.r_[0:8, n // 2 - 8:n // 2 + 8, n - 8:n]
+        ref = oracle_mod.fa_forward(sd, x[sel], True) if kind == syn.FULL_ALIGNMENT else oracle_mod.pileup_forward(sd, x[sel], False)
+        util.assert_rows_match(y1[sel], ref, what=f"{kind}, two halves")
