@@ -36,7 +36,7 @@ def agg(path):
 def main(tag):
     f = agg(os.path.join(ROOT, "gpurun_out/pmc_fetch_fa/c3_counter_collection.csv"))
     w = agg(os.path.join(ROOT, "gpurun_out/pmc_write_fa/c3_counter_collection.csv"))
-    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("conv1_i8" in k) or ("conv3x3_planes_kernel" in k) or ("conv3x3_s2_planes_kernel" in k)
+    conv = lambda k: ("gemm_mfma_kernel<c3::Conv" in k) or ("conv1_i8" in k) or ("conv3x3_planes_kernel" in k) or ("conv3x3_wino_planes_kernel" in k) or ("conv3x3_s2_planes_kernel" in k)
     tot_f = tot_w = n = 0
     per = {}
     all_f = all_w = 0.0

@@ -21,7 +21,7 @@ def main():
     roof = line["roofline"]
     step_ms = line.get("one_batch_in_flight", {}).get("ms_per_step", line["ms_per_step"])  # the short line: value / ms_per_step ARE the one-in-flight leg
     batch = line["config"].get("batch_per_gpu") or line["config"].get("batch") or 256
-    conv = {k: v for k, v in fa.items() if "conv3x3_planes_kernel" in k or "conv3x3_s2_planes_kernel" in k or "conv1_i8" in k}
+    conv = {k: v for k, v in fa.items() if "conv3x3_planes_kernel" in k or "conv3x3_wino_planes_kernel" in k or "conv3x3_s2_planes_kernel" in k or "conv1_i8" in k}
     steps = min(c for k, (c, _) in conv.items() if "conv3x3" in k)
     print(f"| kernel (full alignment, B = {batch}, one batch in flight) | launches per step | average us (rocprofv3) |\n|---|---:|---:|")
     total = 0.0

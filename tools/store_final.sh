@@ -3,7 +3,7 @@
 # the two worker_throughput runs) left in gpurun_out/ into profiles/<tag>_*, with the PMC passes reduced to the JSON files bench.py reads.
 set -e
 cd "$(dirname "$0")/.."
-tag=${1:-r04_final}
+tag=${1:-r05_final}
 python tools/pmc_traffic.py $tag > /dev/null; python tools/pmc_traffic.py pileup $tag > /dev/null
 python tools/pmc_sq_summary.py fa > profiles/${tag}_pmc_sq_fa.md; python tools/pmc_sq_summary.py p > profiles/${tag}_pmc_sq_pileup.md
 cp profiles/pmc_traffic.json profiles/${tag}_pmc_traffic.json; cp profiles/pmc_traffic_pileup.json profiles/${tag}_pmc_traffic_pileup.json
