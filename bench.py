@@ -656,7 +656,7 @@ def cpu_baseline(name, budget_s, batch, gpu_rows):
                 top2 = np.sort(y_cpu[:, lo:hi], axis=1)[:, -2:]
                 diff = a != b
                 conc[k] = {"identical": int((~diff).sum()), "differ": int(diff.sum()),
-                           "differ_outside_near_ties_1e-5": int((diff & ((top2[:, 1] - top2[:, 0]) > 1e-5)).sum())}
+                           "differ_outside_near_ties_1e-6": int((diff & ((top2[:, 1] - top2[:, 0]) > 1e-6)).sum())}
     return out, conc
 
 
@@ -716,7 +716,7 @@ def short_line(full, names, full_path):
             return None
         return {"windows": g["windows"], "max_abs_dy": _r(g["max_abs_dy"]), "gt21_differ": g["gt21"]["differ"],
                 "zygosity_differ": g["zygosity"]["differ"],
-                "differ_outside_near_ties": g["gt21"]["differ_outside_near_ties_1e-5"] + g["zygosity"]["differ_outside_near_ties_1e-5"]}
+                "differ_outside_near_ties": sum(g[h].get("differ_outside_near_ties_1e-6", g[h].get("differ_outside_near_ties_1e-5", 0)) for h in ("gt21", "zygosity"))}
 
     def sub(r, S):
         o = {"value": _r(r["one_batch_in_flight"]["value"]), "ms_per_step": _r(r["one_batch_in_flight"]["ms_per_step"]),
