@@ -126,7 +126,7 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     bool alone = true;
     for (int k = 0; k < kHostSlots; ++k) alone &= !m->slot[k].busy;
     if (batch > 0 && m->host_copy_kernel && alone && xb <= kcopy_max && yb <= kcopy_max && !src_locked && !is_registered(x_host, xb)) {
-        TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, (yb + 255) & ~(size_t)255));
+        TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, y_dev_out ? 0 : (yb + 255) & ~(size_t)255));  // (rows that stay on the device need no slot buffers)
         StagePool::get().copy(sl.pin_x, x_host, xb);  // (plain memcpy below 1 MB, split over the helpers above)
         hipLaunchKernelGGL(host_copy_kernel, dim3(128), dim3(256), 0, m->stream, (const uint4 *)sl.pin_x, (uint4 *)sl.dev_x, (xb + 15) / 16,
                            (const uint32_t *)nullptr, (uint32_t *)nullptr);
@@ -143,7 +143,7 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     } else
     if (batch > 0) {
         // the slot becomes busy only once everything has been queued: a failure on the way leaves it free
-        TRY(ensure_slot(m, sl, xb, yb));
+        TRY(ensure_slot(m, sl, xb, y_dev_out ? 0 : yb));  // (rows that stay on the device need no slot buffers)
         TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream, src_locked));
         HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
