@@ -392,8 +392,13 @@ class RowPrinter:
             values = class_lists_of_rows(batch_Y[idx, :self.width], indel)[:, _CHAIN[indel]]
             homo = cols[idx, 9 + bi[idx]]
             above = values > homo[:, None]
+            # every row's walk order in ONE stable sort: entries above the homo-reference probability by falling probability (ties in
+            # chain order), the others -- keyed +inf -- behind them; row j walks order[j, :count[j]].  (Rows that reject their first
+            # candidate have most of their entries above it: sorting only those with one lexsort over the batch was twice as slow.)
+            order = np.argsort(np.where(above, -values, np.float32(np.inf)), axis=1, kind="stable")
+            count = above.sum(axis=1).tolist()
             for j, (i, c, ref, look, chromosome, position, depth, d, acgt) in enumerate(walks):
-                found = self._next_candidate(values[j], above[j], c, pos[i], ref, look)
+                found = self._next_candidate(values[j], order[j, :count[j]], c, pos[i], ref, look)
                 if found is FALLBACK:
                     continue
                 self.retried += 1
@@ -459,21 +464,18 @@ class RowPrinter:
         hit = self._dead_cache[key] = (dead, dead[_CHAIN[True]])
         return hit
 
-    def _next_candidate(self, values, above, cls0, pos0, ref, look):
+    def _next_candidate(self, values, keep, cls0, pos0, ref, look):
         """The passes of output_from's loop after its first candidate (class cls0, entry pos0) was rejected: -> (class,
         alleles, maximum probability) of the first candidate the reads offer, None when the loop ends on the homo-reference
         probability, FALLBACK when the accepted maximum is shared by two classes.
-        ``values``: the row's nine lists laid end to end IN CHAIN ORDER (_CHAIN), ``above``: values > the homo-reference probability.
+        ``values``: the row's nine lists laid end to end IN CHAIN ORDER (_CHAIN), ``keep``: the entries above the homo-reference
+        probability in walk order (stable sort by falling probability; formed for the whole batch at once in ``rows``).
         Each pass of the loop takes the maximum over homo_Ref and the nine lists, returns the reference call when that is
         homo_Ref (:735), else looks up the first class of the chain that holds it at its first index and zeroes that entry
         on rejection -- i.e. it walks the entries above homo_Ref by (probability falling, chain rank, index): a stable sort of
         the chain-ordered entries by falling probability."""
         indel = self.cfg.add_indel_length
-        keep = np.flatnonzero(above)
         v = values[keep]
-        order = np.argsort(-v, kind="stable")
-        keep = keep[order]
-        v = v[order]
         klass, index = _KLASS_C[indel][keep], _INDEX_C[indel][keep]
         if len(keep) == 0 or klass[0] != cls0 or index[0] != pos0:
             return FALLBACK  # the device's first decision is not the head of the walk: leave the row to the reference
