@@ -82,29 +82,30 @@ def test_family_time_is_a_share_of_the_free_running_step():
             assert abs(roof["whole_network_frac"] - line["value"] * 451538432 / 2500e12) < 2e-3, name
 
 
-def test_the_round_5_collection_is_consistent():
-    """profiles/r05_g_*: one parseable line under 4 KB, value / ms_per_step / roofline on the same leg, the family's time inside the step,
-    fabric-byte names, and the roofline fraction recomputed from the rocprofv3 kernel statistics of the same box within 3 % (eight convolution
-    launches per step: five direct / stride-2 kernels and three on the F(2,3) form)"""
+def test_the_round_5_collections_are_consistent():
+    """profiles/r05_g_* and r05_final_* (the round's tree on two boxes): one parseable line under 4 KB, value / ms_per_step / roofline on the
+    same leg, the family's time inside the step, fabric-byte names, and the roofline fraction recomputed from the rocprofv3 kernel statistics
+    of the same box within 3 % (eight convolution launches per step: five direct / stride-2 kernels and three on the F(2,3) form)"""
     import csv
-    for name in ("r05_g_bench.json", "r05_g_bench20.json"):
-        raw = open(os.path.join(ROOT, "profiles", name)).read().strip()
-        assert len(raw.splitlines()) == 1 and len(raw) <= 4096, (name, len(raw))
-        line = json.loads(raw)
-        assert line["n_gpus"] == 1 and line["config"]["batches_in_flight"] == 1 and line["higher_is_better"] is True
-        assert abs(line["value"] * line["ms_per_step"] / 1e3 / line["config"]["windows_per_step"] - 1) < 1e-3
-        roof = line["roofline"]
-        assert roof["bound"] == "mfma" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-        assert abs(roof["step_us_one_batch_in_flight"] / (1e3 * line["ms_per_step"]) - 1) < 1e-3
-        assert roof["kernel_us_per_step"] <= roof["step_us_one_batch_in_flight"]
-        assert abs(roof["whole_network_frac"] - line["value"] * 451538432 / 2500e12) < 1e-3
-        assert line["cpu_baseline"]["kind"] == "reference" and line["gt_concordance"]["gt21_differ"] == 0
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_g_bench.json")).read())
-    traffic = json.load(open(os.path.join(ROOT, "profiles", "r05_g_pmc_traffic.json")))
-    assert 0.5 < traffic["l2_hit_rate"] < 1.0 and traffic["fabric_bytes_per_step"] > 0
-    stats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_g_kernel_stats_fa_one_in_flight.csv")))}
-    conv = {k: v for k, v in stats.items() if "conv3x3_planes_kernel" in k or "conv3x3_wino_planes_kernel" in k or "conv3x3_s2_planes_kernel" in k}
-    assert len(conv) == 8 and len({c for c, _ in conv.values()}) == 1 and sum("wino" in k for k in conv) == 3
-    conv_us = sum(avg for _, avg in conv.values()) / 1e3
-    frac_csv = 449_418_240 * line["config"]["windows_per_step"] / (conv_us * 1e-6) / 2500e12
-    assert abs(frac_csv / line["roofline"]["frac"] - 1) < 0.03, (frac_csv, line["roofline"]["frac"])
+    for tag in ("r05_g", "r05_final"):
+        for name in (f"{tag}_bench.json", f"{tag}_bench20.json"):
+            raw = open(os.path.join(ROOT, "profiles", name)).read().strip()
+            assert len(raw.splitlines()) == 1 and len(raw) <= 4096, (name, len(raw))
+            line = json.loads(raw)
+            assert line["n_gpus"] == 1 and line["config"]["batches_in_flight"] == 1 and line["higher_is_better"] is True
+            assert abs(line["value"] * line["ms_per_step"] / 1e3 / line["config"]["windows_per_step"] - 1) < 1e-3
+            roof = line["roofline"]
+            assert roof["bound"] == "mfma" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+            assert abs(roof["step_us_one_batch_in_flight"] / (1e3 * line["ms_per_step"]) - 1) < 1e-3
+            assert roof["kernel_us_per_step"] <= roof["step_us_one_batch_in_flight"]
+            assert abs(roof["whole_network_frac"] - line["value"] * 451538432 / 2500e12) < 1e-3
+            assert line["cpu_baseline"]["kind"] == "reference" and line["gt_concordance"]["gt21_differ"] == 0
+        line = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench.json")).read())
+        traffic = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
+        assert 0.5 < traffic["l2_hit_rate"] < 1.0 and traffic["fabric_bytes_per_step"] > 0
+        stats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_fa_one_in_flight.csv")))}
+        conv = {k: v for k, v in stats.items() if "conv3x3_planes_kernel" in k or "conv3x3_wino_planes_kernel" in k or "conv3x3_s2_planes_kernel" in k}
+        assert len(conv) == 8 and len({c for c, _ in conv.values()}) == 1 and sum("wino" in k for k in conv) == 3
+        conv_us = sum(avg for _, avg in conv.values()) / 1e3
+        frac_csv = 449_418_240 * line["config"]["windows_per_step"] / (conv_us * 1e-6) / 2500e12
+        assert abs(frac_csv / line["roofline"]["frac"] - 1) < 0.03, (tag, frac_csv, line["roofline"]["frac"])
