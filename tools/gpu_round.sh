@@ -45,7 +45,7 @@ for s in ${1:-test bench}; do
     cprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/conv_probe.hip -o /tmp/conv_probe && timeout 300 /tmp/conv_probe > gpurun_out/conv_probe.txt 2>&1; echo "cprobe rc=$?"; cat gpurun_out/conv_probe.txt ;;
     l4probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/l4_probe.hip -o /tmp/l4_probe && timeout 300 /tmp/l4_probe > gpurun_out/l4_probe.txt 2>&1; echo "l4probe rc=$?"; cat gpurun_out/l4_probe.txt ;;
     lprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/lstm_probe.hip -o /tmp/lstm_probe && timeout 300 /tmp/lstm_probe > gpurun_out/lstm_probe.txt 2>&1; echo "lprobe rc=$?"; cat gpurun_out/lstm_probe.txt ;;
-    wprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/wino_probe.hip -o /tmp/wino_probe && timeout 300 /tmp/wino_probe ${WPROBE_ARGS:-} > gpurun_out/wino_probe.txt 2>&1; echo "wprobe rc=$?"; cat gpurun_out/wino_probe.txt ;;
+    wprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc -I tools tools/wino_probe.hip -o /tmp/wino_probe && timeout 300 /tmp/wino_probe ${WPROBE_ARGS:-} > gpurun_out/wino_probe.txt 2>&1; echo "wprobe rc=$?"; cat gpurun_out/wino_probe.txt ;;
     info)    (rocminfo | grep -E "Name|Compute Unit|Max Clock|Wavefront" | head -40; lscpu | head -20; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null) > gpurun_out/info.txt 2>&1 ;;
     *)       echo "unknown stage $s" ;;
   esac

@@ -11,7 +11,7 @@
 #include <cstring>
 #include <random>
 #include <vector>
-#include "../clair3_amd/csrc/c3_conv3w.h"
+#include "c3_conv3w16.h"
 using namespace c3;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -42,6 +42,10 @@ static void put16(uint16_t *q, size_t dst, float v) {
 
 template <int C, bool RES, int ABL> static void launch_w(const WinoConvParams &wp, int grid) {
     hipLaunchKernelGGL((conv3x3_wino_planes_kernel<C, RES, ABL>), dim3(grid), dim3(kPlThreads), 0, 0, wp);
+}
+
+template <int C, bool RES, int ABL> static void launch_w16(const WinoConvParams &wp, int grid) {
+    hipLaunchKernelGGL((conv3x3_wino16_planes_kernel<C, RES, ABL>), dim3(grid), dim3(kPlThreads), 0, 0, wp);
 }
 
 template <int C> static int shape(const char *name, int B, int H, int W, int cus, bool timing) {
@@ -94,6 +98,15 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
             put16(w16, (((((((size_t)tn * NS32 + s32) * 12 + tap) * 2 + wn) * 2 + ks) * 2) * 64 + lane) * 8 + j, u[((size_t)co * 12 + tap) * C + ci] * scw[co]);
         }
 
+    constexpr int NS16 = C / 16;
+    std::vector<float> pw16v((size_t)NS * NS16 * 12 * 1024);  // 4 KB per chunk: [tn][s16][tap][wn][piece][lane] x 16 B
+    uint16_t *w16b = reinterpret_cast<uint16_t *>(pw16v.data());
+    for (int tn = 0; tn < NS; ++tn) for (int s16 = 0; s16 < NS16; ++s16) for (int tap = 0; tap < 12; ++tap) for (int wn = 0; wn < 2; ++wn)
+        for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+            const int co = tn * 64 + 32 * wn + (lane & 31), ci = s16 * 16 + 8 * (lane >> 5) + j;
+            put16(w16b, ((((((size_t)tn * NS16 + s16) * 12 + tap) * 2 + wn) * 2) * 64 + lane) * 8 + j, u[((size_t)co * 12 + tap) * C + ci] * scw[co]);
+        }
+    void *wfw16; CK(hipMalloc(&wfw16, pw16v.size() * 4)); CK(hipMemcpy(wfw16, pw16v.data(), pw16v.size() * 4, hipMemcpyHostToDevice));
     void *x, *yd, *yw, *r, *wfd, *wfw; float *dbias, *dpost, *dpostw, *fd, *fw; uint32_t *flag;
     CK(hipMalloc(&x, bytes)); CK(hipMalloc(&yd, bytes)); CK(hipMalloc(&yw, bytes)); CK(hipMalloc(&r, bytes));
     CK(hipMalloc(&wfd, pk.size() * 4)); CK(hipMalloc(&wfw, pw.size() * 4));
@@ -165,10 +178,28 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
         for (size_t i = 0; i < a.size(); ++i) mixdiff += a[i] != b2[i];
         hipFree(yw2);
     }
+    size_t w16diff = 0; double w16max = 0;
+    {   // the LDS-DMA / 16-channel-slab form: the same V values, the same products per accumulator in the same channel order
+        void *yw3; CK(hipMalloc(&yw3, bytes)); CK(hipMemset(yw3, 0xff, bytes));
+        WinoConvParams w3 = wp; w3.out = yw3; w3.wf = wfw16;
+        launch_w16<C, true, 0>(w3, gw);
+        CK(hipGetLastError()); CK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)(((size_t)M * C + 255) / 256)), dim3(256), 0, 0, yw3, fd, (int64_t)M, C);
+        CK(hipDeviceSynchronize());
+        std::vector<float> h3((size_t)M * C);
+        CK(hipMemcpy(h3.data(), fd, bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h3.size(); ++i) {
+            if (!(h3[i] == h3[i])) { ++w16diff; continue; }
+            if (h3[i] != hw[i]) ++w16diff;
+            w16max = std::max(w16max, (double)std::fabs(h3[i] - hw[i]));
+        }
+        hipFree(yw3);
+    }
     printf("== %s C=%d B=%d %dx%d: M=%d Mp=%d; direct %d tiles grid %d, wino %d tiles grid %d\n", name, C, B, H, W, M, Mp, cp.tiles, gd, wp.tiles, gw);
     printf("  max|y| %.3f  max|wino - direct| %.3e (at pixel %zu ch %zu: direct %.6f wino %.6f)  NaN/unwritten in wino %zu\n", ymax, dmax, worst / C, worst % C,
            hd[worst], hw[worst], nan_w);
     printf("  vs fp64 host on %d sampled outputs: direct %.3e  wino %.3e;  words differing between the two transform forms: %zu\n", samples + 4, ed, ew, mixdiff);
+    printf("  wino16 (LDS-DMA, 16-channel slabs) against wino: %zu values differ, max |difference| %.3e\n", w16diff, w16max);
     if (timing) {
         const double mfd = 2.0 * tiles_m * kPlBM * (double)C * 9.0 * C * 3, mfw = 2.0 * tiles_w * kWRows * (double)C * 12.0 * C * 3;
         printf("  executed matrix work: direct %.1f GFLOP (%.1f us at 2500 TF), wino %.1f GFLOP (%.1f us)\n", mfd / 1e9, mfd / 2500e6, mfw / 1e9, mfw / 2500e6);
@@ -180,6 +211,25 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
         printf("  wino no loads/transform/epi  %6.1f us\n", time_it([&] { launch_w<C, true, 7>(wp, gw); }));
         printf("  wino no MFMA                 %6.1f us\n", time_it([&] { launch_w<C, true, 8>(wp, gw); }));
         printf("  wino loads not ahead         %6.1f us\n", time_it([&] { launch_w<C, true, 16>(wp, gw); }));
+        WinoConvParams w6 = wp; w6.wf = wfw16;
+        printf("  wino16 full                  %6.1f us\n", time_it([&] { launch_w16<C, true, 0>(w6, gw); }));
+        printf("  wino16 no weight loads       %6.1f us\n", time_it([&] { launch_w16<C, true, 1>(w6, gw); }));
+        printf("  wino16 no DMA / transform    %6.1f us\n", time_it([&] { launch_w16<C, true, 2>(w6, gw); }));
+        printf("  wino16 no epilogue           %6.1f us\n", time_it([&] { launch_w16<C, true, 4>(w6, gw); }));
+        printf("  wino16 matrix + LDS only     %6.1f us\n", time_it([&] { launch_w16<C, true, 7>(w6, gw); }));
+        printf("  wino16 full again            %6.1f us\n", time_it([&] { launch_w16<C, true, 0>(w6, gw); }));
+        {   // phase trace of the wino16 form
+            long long *tb; CK(hipMalloc(&tb, 2 * 256 * 16)); CK(hipMemset(tb, 0, 2 * 256 * 16));
+            WinoConvParams wt = w6; wt.trace = tb;
+            launch_w16<C, true, 32>(wt, gw); launch_w16<C, true, 32>(wt, gw);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> ht(2 * 256 * 2);
+            CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+            printf("  wino16 trace workgroup 0 (10+s taps of slab s done, 21 DMA landed + barrier, 22 transformed, 23 barrier; 30 epilogue 31 half staged 32 barrier 33 half stored 35 next tile transformed 36 barrier):\n   ");
+            for (int i = 1; i < 250 && ht[i * 2] != 0; ++i) printf(" %lld:+%lld", ht[i * 2], ht[i * 2 + 1] - ht[(i - 1) * 2 + 1]);
+            printf("\n");
+            hipFree(tb);
+        }
         const int g1 = grid_for(wp.tiles, cus);
         printf("  wino full, one wg per CU     %6.1f us (grid %d)\n", time_it([&] { launch_w<C, true, 0>(wp, g1); }), g1);
         {   // shader-clock trace of workgroups 0 and 256, wave 0
@@ -200,7 +250,7 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
         printf("  direct full again            %6.1f us\n", time_it([&] { hipLaunchKernelGGL((conv3x3_planes_kernel<C, true>), dim3(gd), dim3(kPlThreads), 0, 0, cp); }));
         printf("  wino full again              %6.1f us\n", time_it([&] { launch_w<C, true, 0>(wp, gw); }));
     }
-    hipFree(x); hipFree(yd); hipFree(yw); hipFree(r); hipFree(wfd); hipFree(wfw); hipFree(dbias); hipFree(dpost); hipFree(dpostw); hipFree(flag); hipFree(fd); hipFree(fw);
+    hipFree(wfw16); hipFree(x); hipFree(yd); hipFree(yw); hipFree(r); hipFree(wfd); hipFree(wfw); hipFree(dbias); hipFree(dpost); hipFree(dpostw); hipFree(flag); hipFree(fd); hipFree(fw);
     return 0;
 }
 int main(int argc, char **argv) {
