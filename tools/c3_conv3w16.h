@@ -23,22 +23,34 @@
 
 namespace c3 {
 
-constexpr int kW16RowB = 80;                           // LDS row stride of one xi plane: 16 channels x 2 pieces x 2 B + 16
-constexpr int kW16PlaneB = (kWRows + 1) * kW16RowB;    // 10 320 B (row kWRows: the zero row)
-constexpr int kW16LdsV = 4 * kW16PlaneB;               // 41 280 B; the epilogue stages 128 output rows x 272 B = 34 816 B in it, twice
-constexpr int kW16Raw = kWRows * 256;                  // 32 768 B: 128 V rows x 16 units of 16 B (4 input rows x hi | lo x 2 halves)
-static_assert(kWRows * kPlRowB <= kW16LdsV, "half of the staged output tile must fit the V planes");
+constexpr int kW16RowB = 80;  // LDS row stride of one xi plane: 16 channels x 2 pieces x 2 B + 16
+// RT = row tiles (32 V rows) per wave: 2 -> 128-row tiles (126 output pairs), 128 accumulator registers, two workgroups per CU;
+// 1 -> 64-row tiles (62 output pairs), 64 accumulator registers, <= 128 registers a lane and 40 KB of LDS: FOUR workgroups per CU, so
+// that one workgroup's slab switches and epilogue run under three others' tap loops (a weight fragment then feeds three matrix
+// instructions instead of six: twice the vector-memory traffic per matrix instruction)
+template <int RT> struct W16Geom {
+    static constexpr int Rows = 64 * RT, TM = Rows - 2;
+    static constexpr int PlaneB = (Rows + 1) * kW16RowB;  // (row Rows: the zero row)
+    static constexpr int LdsV = 4 * PlaneB;                // RT 2: 41 280 B, RT 1: 20 800 B; the epilogue stages Rows x 272 B in it, twice
+    static constexpr int Raw = Rows * 256;                 // Rows V rows x 16 units of 16 B (4 input rows x hi | lo x 2 halves)
+    static constexpr int Smem = Raw + LdsV + 512 + 2 * Rows * 8 + 2 * Rows * 16;
+    static_assert(Rows * kPlRowB <= LdsV, "half of the staged output tile must fit the V planes");
+};
 
 // ABL (tools/wino_probe.hip only; 0 in the product): 1 no weight loads, 2 no DMA / transform after the first slab of the first tile,
 // 4 no epilogue, 8 no matrix instructions, 32 shader-clock trace (as c3_conv3w.h).
-template <int C, bool RES, int ABL = 0>
-__global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(WinoConvParams p) {
+template <int C, bool RES, int ABL = 0, int RT = 2, int WD = 4>
+__global__ __launch_bounds__(kPlThreads, RT == 1 ? 4 : 2) void conv3x3_wino16_planes_kernel(WinoConvParams p) {
+    using Geo = W16Geom<RT>;
+    constexpr int kWRows = Geo::Rows, kWTM = Geo::TM, kW16PlaneB = Geo::PlaneB, kW16LdsV = Geo::LdsV, kW16Raw = Geo::Raw;  // (shadow c3_conv3w.h's)
+    constexpr int QW = 4 * RT;  // DMA requests per wave and slab
+    static_assert(12 % WD == 0 && WD >= 2, "ring slots are named statically");
     constexpr int NS = C / 64;      // output column tiles
     constexpr int NS16 = C / 16;    // input slabs
     constexpr int PIXB = 4 * C;     // bytes per pixel
     constexpr int NCH = 12 * NS16;  // 4 KB weight chunks per tile
     constexpr int T = kWRows;       // index of the zero row of every plane
-    __shared__ __attribute__((aligned(1024))) char smem[kW16Raw + kW16LdsV + 512 + 2 * kWRows * 8 + 2 * kWRows * 16];
+    __shared__ __attribute__((aligned(1024))) char smem[Geo::Smem];
     char *const raw = smem;                         // the DMA landing buffer (1 KB per instruction: 4 rows)
     char *const vlds = smem + kW16Raw;
     float *const bias_lds = reinterpret_cast<float *>(smem + kW16Raw + kW16LdsV);
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
 
     // ---- the weight ring: chunk cc (= slab * 12 + tap) sits in slot tap & 3 as (hi, lo); refilled with chunk cc + 4 right behind the
     // matrix instructions that read it
-    pl_u32x4 wq[4][2];
+    pl_u32x4 wq[WD][2];
     auto w_issue = [&](int slot, int cc) __attribute__((always_inline)) {
         if constexpr (ABL & 1) return;
         const uint32_t so = (uint32_t)(cc * 4096);
@@ -117,11 +129,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
     auto dma = [&](const int2 *tab, int s16, int q) __attribute__((always_inline)) {
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));  // (per-request lane arithmetic is recomputed instead of living through the tap loop)
-        const int r = 4 * (8 * wave + q) + (lane_ >> 4);
-        const int u = (lane_ & 15) ^ ((4 * q + (lane_ >> 4)) & 15);  // (row & 15: 32 wave is a multiple of 16)
+        const int r = 4 * (QW * wave + q) + (lane_ >> 4);
+        const int u = (lane_ & 15) ^ ((4 * q + (lane_ >> 4)) & 15);  // (row & 15: 4 QW wave is a multiple of 16)
         const uint32_t base = rowoff0[(tab - rowinfo0) * 4 + r * 4 + (u >> 2)];  // bit 31 set: outside (stays out of range under the adds below)
         const uint32_t off = base + (uint32_t)((s16 >> 2) * 256 + (s16 & 3) * 32) + (uint32_t)(((u >> 1) & 1) * 128 + (u & 1) * 16);
-        char *dst = raw + (8 * wave + q) * 1024;
+        char *dst = raw + (QW * wave + q) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)dst, 16, off, 0, 0, 0);
     };
 
@@ -129,30 +141,55 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
     auto transform = [&]() __attribute__((always_inline)) {
         int tid_ = tid;
         asm volatile("" : "+v"(tid_));
-        const int r = (tid_ & 15) + 16 * (tid_ >> 5), g = (tid_ >> 4) & 1;  // a lane group of 16 = 16 consecutive rows, one half: its 16 slots differ
-        const char *src = raw + r * 256;
-        const int x = r & 15;
-        f32x4 d[2][4];  // [4-channel half][input row]
+        if constexpr (RT == 2) {
+            const int r = (tid_ & 15) + 16 * (tid_ >> 5), g = (tid_ >> 4) & 1;  // a lane group of 16 = 16 consecutive rows, one half: its 16 slots differ
+            const char *src = raw + r * 256;
+            const int x = r & 15;
+            f32x4 d[2][4];  // [4-channel half][input row]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const pl_u32x4 h = *reinterpret_cast<const pl_u32x4 *>(src + (((4 * k + g) ^ x) << 4));
-            const pl_u32x4 l = *reinterpret_cast<const pl_u32x4 *>(src + (((4 * k + 2 + g) ^ x) << 4));
+            for (int k = 0; k < 4; ++k) {
+                const pl_u32x4 h = *reinterpret_cast<const pl_u32x4 *>(src + (((4 * k + g) ^ x) << 4));
+                const pl_u32x4 l = *reinterpret_cast<const pl_u32x4 *>(src + (((4 * k + 2 + g) ^ x) << 4));
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    d[half][k][0] = mix_add<0>(h[2 * half], l[2 * half]), d[half][k][1] = mix_add<1>(h[2 * half], l[2 * half]);
+                    d[half][k][2] = mix_add<0>(h[2 * half + 1], l[2 * half + 1]), d[half][k][3] = mix_add<1>(h[2 * half + 1], l[2 * half + 1]);
+                }
+            }
+            char *dst = vlds + r * kW16RowB + g * 16;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                d[half][k][0] = mix_add<0>(h[2 * half], l[2 * half]), d[half][k][1] = mix_add<1>(h[2 * half], l[2 * half]);
-                d[half][k][2] = mix_add<0>(h[2 * half + 1], l[2 * half + 1]), d[half][k][3] = mix_add<1>(h[2 * half + 1], l[2 * half + 1]);
-            }
-        }
-        char *dst = vlds + r * kW16RowB + g * 16;
+                const f32x4 vv[4] = {d[half][0] - d[half][2], d[half][1] + d[half][2], d[half][2] - d[half][1], d[half][1] - d[half][3]};
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const f32x4 vv[4] = {d[half][0] - d[half][2], d[half][1] + d[half][2], d[half][2] - d[half][1], d[half][1] - d[half][3]};
+                for (int xi = 0; xi < 4; ++xi) {
+                    u32x2 pc[2];
+                    split2_f16_mix(vv[xi], pc);
+                    *reinterpret_cast<u32x2 *>(dst + xi * kW16PlaneB + half * 8) = pc[0];
+                    *reinterpret_cast<u32x2 *>(dst + xi * kW16PlaneB + 32 + half * 8) = pc[1];
+                }
+            }
+        } else {
+            // 64 rows: thread = (row, 8-channel half g, 4-channel half): 8-byte reads; lanes 0..15 = 16 consecutive rows (16 distinct slots),
+            // lanes 16..31 the other eight bytes of the same slots: a half wave covers every bank once
+            const int r = (tid_ & 15) + 16 * (tid_ >> 6), half = (tid_ >> 4) & 1, g = (tid_ >> 5) & 1;
+            const char *src = raw + r * 256 + half * 8;
+            const int x = r & 15;
+            f32x4 d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x2 h = *reinterpret_cast<const u32x2 *>(src + (((4 * k + g) ^ x) << 4));
+                const u32x2 l = *reinterpret_cast<const u32x2 *>(src + (((4 * k + 2 + g) ^ x) << 4));
+                d[k][0] = mix_add<0>(h[0], l[0]), d[k][1] = mix_add<1>(h[0], l[0]);
+                d[k][2] = mix_add<0>(h[1], l[1]), d[k][3] = mix_add<1>(h[1], l[1]);
+            }
+            char *dst = vlds + r * kW16RowB + g * 16 + half * 8;
+            const f32x4 vv[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) {
                 u32x2 pc[2];
                 split2_f16_mix(vv[xi], pc);
-                *reinterpret_cast<u32x2 *>(dst + xi * kW16PlaneB + half * 8) = pc[0];
-                *reinterpret_cast<u32x2 *>(dst + xi * kW16PlaneB + 32 + half * 8) = pc[1];
+                *reinterpret_cast<u32x2 *>(dst + xi * kW16PlaneB) = pc[0];
+                *reinterpret_cast<u32x2 *>(dst + xi * kW16PlaneB + 32) = pc[1];
             }
         }
     };
@@ -174,7 +211,9 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
         }
     };
     trace(1);
-    const int lrow[2] = {wm * 64 + frow, wm * 64 + 32 + frow};  // this lane's V rows
+    int lrow[RT];  // this lane's V rows
+#pragma unroll
+    for (int i = 0; i < RT; ++i) lrow[i] = wm * 32 * RT + 32 * i + frow;
     const int cb0 = wn * 32 + 4 * kh;                            // first of this lane's output channels inside the column tile
     float omax = 0.f;
 
@@ -182,12 +221,12 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
     int cur = 0;
     make_rowinfo(rowinfo0, m0, true);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) w_issue(t, t);
+    for (int t = 0; t < WD; ++t) w_issue(t, t);
     if (tid < 64) bias_lds[tid] = p.bias[tn * 64 + tid], post_lds[tid] = p.post[tn * 64 + tid];
     zero_rows();
     lds_barrier();  // the row table is there
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dma(rowinfo0, 0, q);
+    for (int q = 0; q < QW; ++q) dma(rowinfo0, 0, q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     transform();
@@ -197,9 +236,9 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
 
     for (;;) {
         int2 *const rinfo = rowinfo0 + cur * kWRows, *const rnext = rowinfo0 + (cur ^ 1) * kWRows;
-        const char *asrc[2][3];
+        const char *asrc[RT][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
             const uint32_t mk = (uint32_t)rinfo[lrow[i]].y >> 4;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) asrc[i][kw] = vlds + (((mk >> kw) & 1u) ? lrow[i] + kw - 1 : T) * kW16RowB + kh * 16;
@@ -209,19 +248,19 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
         const int m0n = more ? (xcd_tile_index(vn, p.tiles) / NS) * kWTM : 0;
         make_rowinfo(rnext, m0n, more);  // (read from the first slab switch on; a tile has at least four slabs)
 
-        f32x16 acc[4][2];
+        f32x16 acc[4][RT];
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[xi][i][e] = 0.f;
 
-        pl_u32x4 xh[2][2], xl[2][2];  // operand registers of the tile-pixels: two stages (even / odd taps)
+        pl_u32x4 xh[2][RT], xl[2][RT];  // operand registers of the tile-pixels: two stages (even / odd taps)
         auto frags = [&](int tap, int st) __attribute__((always_inline)) {
             const int xi = tap / 3, kw = tap % 3;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RT; ++i) {
                 const char *src = asrc[i][kw] + xi * kW16PlaneB;
                 xh[st][i] = *reinterpret_cast<const pl_u32x4 *>(src);
                 xl[st][i] = *reinterpret_cast<const pl_u32x4 *>(src + 32);
@@ -236,9 +275,9 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
             frags(0, 0);
 #pragma unroll
             for (int tap = 0; tap < 12; ++tap) {
-                const int xi = tap / 3, slot = tap & 3, st = tap & 1;
+                const int xi = tap / 3, slot = tap % WD, st = tap & 1;
                 const int cc = s16 * 12 + tap;
-                int ccn = cc + 4;  // the ring refills with the chunk four ahead of this workgroup's cyclic stream
+                int ccn = cc + WD;  // the ring refills with the chunk WD ahead of this workgroup's cyclic stream
                 if (ccn >= NCH) ccn -= NCH;
                 if (tap != 11) frags(tap + 1, st ^ 1);
                 // the next slab's input rows: the eight DMA requests at the HEAD of the slab (four in front of tap 0, four in front of tap 1).
@@ -246,23 +285,24 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
                 // request too, so spread one per tap (round 5's first cut) every tap from the fifth on stood behind one; at the head only tap
                 // 4 / 5's fragments do, four taps after the requests left
                 if constexpr (!(ABL & 2))
-                    if (tap < 2) {
+                    if (tap < RT) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dma(ntab, ns16, 4 * tap + q);
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 8)) {
-                    acc[xi][0] = mma(acc[xi][0], wq[slot][0], xl[st][0]);
-                    acc[xi][1] = mma(acc[xi][1], wq[slot][0], xl[st][1]);
-                    acc[xi][0] = mma(acc[xi][0], wq[slot][1], xh[st][0]);
-                    acc[xi][1] = mma(acc[xi][1], wq[slot][1], xh[st][1]);
-                    acc[xi][0] = mma(acc[xi][0], wq[slot][0], xh[st][0]);
-                    acc[xi][1] = mma(acc[xi][1], wq[slot][0], xh[st][1]);
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[xi][i] = mma(acc[xi][i], wq[slot][0], xl[st][i]);
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[xi][i] = mma(acc[xi][i], wq[slot][1], xh[st][i]);
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[xi][i] = mma(acc[xi][i], wq[slot][0], xh[st][i]);
                 } else {
-                    acc[xi][0][tap & 3] += __uint_as_float(wq[slot][0][0] ^ xl[st][0][1] ^ xh[st][1][2] ^ wq[slot][1][3]);
+                    acc[xi][0][tap & 3] += __uint_as_float(wq[slot][0][0] ^ xl[st][0][1] ^ xh[st][RT - 1][2] ^ wq[slot][1][3]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                w_issue(slot, ccn);
+                // 64-row tiles: the ring does not run ahead into the next tile (its registers are the epilogue's: residual pixels)
+                if (RT == 2 || tap + WD < 12 || !last_slab) w_issue(slot, ccn);
             }
             trace(10 + (s16 & 7));
             // the DMA requests are older than the weight loads of taps 2 .. 11: with the eight of taps 8 .. 11 still in flight they have landed
@@ -285,30 +325,31 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
         if constexpr (ABL & 4) {
             float sacc = 0.f;
 #pragma unroll
-            for (int xi = 0; xi < 4; ++xi) sacc += acc[xi][0][0] + acc[xi][1][3];
+            for (int xi = 0; xi < 4; ++xi) sacc += acc[xi][0][0] + acc[xi][RT - 1][3];
             if (sacc == 12345.f) p.range_flag[1] = 1u;
         } else {
             int tid_e = tid;
             asm volatile("" : "+v"(tid_e));
-            uint32_t ioff[8];
-            pl_u32x4 rh[8], rl[8];
-            auto item_request = [&](int k) __attribute__((always_inline)) {  // item k: half k >> 2, staged row (tid + 256 (k & 3)) >> 3
-                const int idx = tid_e + kPlThreads * (k & 3);
+            constexpr int IP = 2 * RT;  // items per thread and half
+            uint32_t ioff[2 * IP];
+            pl_u32x4 rh[2 * IP], rl[2 * IP];
+            auto item_request = [&](int k) __attribute__((always_inline)) {  // item k: half k / IP, staged row (tid + 256 (k % IP)) >> 3
+                const int idx = tid_e + kPlThreads * (k % IP);
                 const int pr = idx >> 3, g = idx & 7;
                 const int2 ri = rinfo[pr];
-                const bool ok = (ri.y >> ((k >> 2) ? 7 : 8)) & 1;
-                ioff[k] = ok ? (uint32_t)ri.x + (uint32_t)(1 + (k >> 2)) * rowB + (uint32_t)(tn * 256 + g * 16) : kPlOob;
+                const bool ok = (ri.y >> ((k / IP) ? 7 : 8)) & 1;
+                ioff[k] = ok ? (uint32_t)ri.x + (uint32_t)(1 + k / IP) * rowB + (uint32_t)(tn * 256 + g * 16) : kPlOob;
                 if constexpr (RES) {
                     rh[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[k], 0, 0));
                     rl[k] = __builtin_bit_cast(pl_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ioff[k], 128, 0));
                 }
             };
 #pragma unroll
-            for (int k = 0; k < 4; ++k) item_request(k);
+            for (int k = 0; k < IP; ++k) item_request(k);
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + cb0 + 8 * q);
@@ -323,14 +364,14 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
                     }
                 if (ph == 0) {
 #pragma unroll
-                    for (int k = 4; k < 8; ++k) item_request(k);
+                    for (int k = IP; k < 2 * IP; ++k) item_request(k);
                 }
                 trace(31);
                 lds_barrier();
                 trace(32);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 4 * ph + kk;
+                for (int kk = 0; kk < IP; ++kk) {
+                    const int k = IP * ph + kk;
                     const int idx = tid_e + kPlThreads * kk;
                     const int pr = idx >> 3, g = idx & 7;
                     f32x4 a = *reinterpret_cast<const f32x4 *>(vlds + pr * kPlRowB + g * 32);
@@ -362,6 +403,10 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino16_planes_kernel(Wi
             }
         }
         if (!more) break;
+        if constexpr (RT == 1) {
+#pragma unroll
+            for (int t = 0; t < WD; ++t) w_issue(t, t);
+        }
         if constexpr (ABL & 4) lds_barrier();
         zero_rows();
         if constexpr (!(ABL & 2)) transform();  // the next tile's first slab landed during this tile's last tap loop

@@ -11,6 +11,7 @@ static std::string g_err;
 static int fail(const char *, ...) { return -1; }
 #include "c3_dense.h"
 #include "c3_conv3s2.h"
+#include "c3_conv3s2q.h"
 using namespace c3;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -133,6 +134,38 @@ int main(int argc, char **argv) {
                 RUNS(13, false, g1, "  weight loads + barriers only");
                 RUNS(31, false, g1, "  barriers only (prologue + launch)");
 #undef RUNS
+                // the four-wave form (a wave = 128 x 32 outputs): bit-identical output, times, ablations
+                {
+                    void *cc2;
+                    CK(hipMalloc(&cc2, cbytes));
+                    CK(hipMemset(cc, 0xff, cbytes));
+                    CK(hipMemset(cc2, 0xff, cbytes));
+                    hipLaunchKernelGGL((conv3x3_s2_planes_kernel<0, false>), dim3(g1), dim3(kS2Threads), 0, 0, sp);
+                    S2ConvParams sq = sp;
+                    sq.c = cc2;
+                    hipLaunchKernelGGL((conv3x3_s2q_planes_kernel<0>), dim3(g2), dim3(kS2QThreads), 0, 0, sq);
+                    CK(hipGetLastError());
+                    CK(hipDeviceSynchronize());
+                    std::vector<uint32_t> h1(cbytes / 4), h2(cbytes / 4);
+                    CK(hipMemcpy(h1.data(), cc, cbytes, hipMemcpyDeviceToHost));
+                    CK(hipMemcpy(h2.data(), cc2, cbytes, hipMemcpyDeviceToHost));
+                    size_t nd = 0, unw = 0;
+                    for (size_t i = 0; i < h1.size(); ++i) nd += h1[i] != h2[i], unw += h2[i] == 0xffffffffu;
+                    printf(" four waves of 128 x 32 (conv3x3_s2q_planes_kernel): %zu of %zu words differ from the eight-wave form, %zu unwritten\n", nd, h1.size(), unw);
+                    const int g3 = sp.tiles > 768 ? 768 / unit * unit : sp.tiles;
+#define RUNQ(abl, gs, name) rep(name, time_us([&] { hipLaunchKernelGGL((conv3x3_s2q_planes_kernel<abl>), dim3(gs), dim3(kS2QThreads), 0, 0, sq); }, 20))
+                    RUNQ(0, g2, "four waves, two workgroups per CU");
+                    RUNQ(0, g1, "four waves, one workgroup per CU");
+                    RUNQ(1, g2, "  - the pixel requests in the loop");
+                    RUNQ(2, g2, "  - the weight loads");
+                    RUNQ(16, g2, "  - epilogue");
+                    RUNQ(8, g2, "  - fragment reads");
+                    RUNQ(11, g2, "  matrix instructions + barriers only");
+                    RUNQ(0, g2, "four waves, two workgroups per CU (again)");
+                    (void)g3;
+#undef RUNQ
+                    (void)hipFree(cc2);
+                }
             }
             (void)hipFree(ca), (void)hipFree(cw), (void)hipFree(cc);
         }

@@ -41,7 +41,7 @@ for s in ${1:-test bench}; do
              pmc pmc_sq_b_fa full_alignment SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM ;;
     sq_p)    pmc pmc_sq_a_p pileup SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
              pmc pmc_sq_b_p pileup SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM ;;
-    dprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/dense_probe.hip -o /tmp/dense_probe && timeout 300 /tmp/dense_probe > gpurun_out/dense_probe.txt 2>&1; echo "dprobe rc=$?"; cat gpurun_out/dense_probe.txt ;;
+    dprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc -I tools tools/dense_probe.hip -o /tmp/dense_probe && timeout 300 /tmp/dense_probe > gpurun_out/dense_probe.txt 2>&1; echo "dprobe rc=$?"; cat gpurun_out/dense_probe.txt ;;
     cprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/conv_probe.hip -o /tmp/conv_probe && timeout 300 /tmp/conv_probe > gpurun_out/conv_probe.txt 2>&1; echo "cprobe rc=$?"; cat gpurun_out/conv_probe.txt ;;
     l4probe) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/l4_probe.hip -o /tmp/l4_probe && timeout 300 /tmp/l4_probe > gpurun_out/l4_probe.txt 2>&1; echo "l4probe rc=$?"; cat gpurun_out/l4_probe.txt ;;
     lprobe)  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/lstm_probe.hip -o /tmp/lstm_probe && timeout 300 /tmp/lstm_probe > gpurun_out/lstm_probe.txt 2>&1; echo "lprobe rc=$?"; cat gpurun_out/lstm_probe.txt ;;

@@ -44,8 +44,8 @@ template <int C, bool RES, int ABL> static void launch_w(const WinoConvParams &w
     hipLaunchKernelGGL((conv3x3_wino_planes_kernel<C, RES, ABL>), dim3(grid), dim3(kPlThreads), 0, 0, wp);
 }
 
-template <int C, bool RES, int ABL> static void launch_w16(const WinoConvParams &wp, int grid) {
-    hipLaunchKernelGGL((conv3x3_wino16_planes_kernel<C, RES, ABL>), dim3(grid), dim3(kPlThreads), 0, 0, wp);
+template <int C, bool RES, int ABL, int RT = 2, int WD = 4> static void launch_w16(const WinoConvParams &wp, int grid) {
+    hipLaunchKernelGGL((conv3x3_wino16_planes_kernel<C, RES, ABL, RT, WD>), dim3(grid), dim3(kPlThreads), 0, 0, wp);
 }
 
 template <int C> static int shape(const char *name, int B, int H, int W, int cus, bool timing) {
@@ -178,7 +178,7 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
         for (size_t i = 0; i < a.size(); ++i) mixdiff += a[i] != b2[i];
         hipFree(yw2);
     }
-    size_t w16diff = 0; double w16max = 0;
+    size_t w16diff = 0, s16diff = 0; double w16max = 0, s16max = 0;
     {   // the LDS-DMA / 16-channel-slab form: the same V values, the same products per accumulator in the same channel order
         void *yw3; CK(hipMalloc(&yw3, bytes)); CK(hipMemset(yw3, 0xff, bytes));
         WinoConvParams w3 = wp; w3.out = yw3; w3.wf = wfw16;
@@ -193,6 +193,20 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
             if (h3[i] != hw[i]) ++w16diff;
             w16max = std::max(w16max, (double)std::fabs(h3[i] - hw[i]));
         }
+        // ... and its 64-row tiles (four workgroups per CU)
+        CK(hipMemset(yw3, 0xff, bytes));
+        WinoConvParams w4 = w3;
+        w4.tiles = (Mp + W16Geom<1>::TM - 1) / W16Geom<1>::TM * NS;
+        launch_w16<C, true, 0, 1, 3>(w4, grid_for(w4.tiles, 4 * cus));
+        CK(hipGetLastError()); CK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)(((size_t)M * C + 255) / 256)), dim3(256), 0, 0, yw3, fd, (int64_t)M, C);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h3.data(), fd, bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h3.size(); ++i) {
+            if (!(h3[i] == h3[i])) { ++s16diff; continue; }
+            if (h3[i] != hw[i]) ++s16diff;
+            s16max = std::max(s16max, (double)std::fabs(h3[i] - hw[i]));
+        }
         hipFree(yw3);
     }
     printf("== %s C=%d B=%d %dx%d: M=%d Mp=%d; direct %d tiles grid %d, wino %d tiles grid %d\n", name, C, B, H, W, M, Mp, cp.tiles, gd, wp.tiles, gw);
@@ -200,6 +214,7 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
            hd[worst], hw[worst], nan_w);
     printf("  vs fp64 host on %d sampled outputs: direct %.3e  wino %.3e;  words differing between the two transform forms: %zu\n", samples + 4, ed, ew, mixdiff);
     printf("  wino16 (LDS-DMA, 16-channel slabs) against wino: %zu values differ, max |difference| %.3e\n", w16diff, w16max);
+    printf("  wino16 with 64-row tiles against wino: %zu values differ, max |difference| %.3e\n", s16diff, s16max);
     if (timing) {
         const double mfd = 2.0 * tiles_m * kPlBM * (double)C * 9.0 * C * 3, mfw = 2.0 * tiles_w * kWRows * (double)C * 12.0 * C * 3;
         printf("  executed matrix work: direct %.1f GFLOP (%.1f us at 2500 TF), wino %.1f GFLOP (%.1f us)\n", mfd / 1e9, mfd / 2500e6, mfw / 1e9, mfw / 2500e6);
@@ -218,6 +233,32 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
         printf("  wino16 no epilogue           %6.1f us\n", time_it([&] { launch_w16<C, true, 4>(w6, gw); }));
         printf("  wino16 matrix + LDS only     %6.1f us\n", time_it([&] { launch_w16<C, true, 7>(w6, gw); }));
         printf("  wino16 full again            %6.1f us\n", time_it([&] { launch_w16<C, true, 0>(w6, gw); }));
+        {
+            WinoConvParams w7 = w6;
+            w7.tiles = (Mp + W16Geom<1>::TM - 1) / W16Geom<1>::TM * NS;
+            const int g4 = grid_for(w7.tiles, 4 * cus), g3 = grid_for(w7.tiles, 3 * cus), g2 = grid_for(w7.tiles, 2 * cus);
+            printf("  wino16 64-row tiles: %d tiles, grid %d\n", w7.tiles, g4);
+            printf("  wino16/64 full (ring 4, scratch) %6.1f us\n", time_it([&] { launch_w16<C, true, 0, 1, 4>(w7, g4); }));
+            printf("  wino16/64 full (ring 3)      %6.1f us\n", time_it([&] { launch_w16<C, true, 0, 1, 3>(w7, g4); }));
+            printf("  wino16/64 full (ring 2)      %6.1f us\n", time_it([&] { launch_w16<C, true, 0, 1, 2>(w7, g4); }));
+            printf("  wino16/64 grid 3 per CU      %6.1f us (grid %d)\n", time_it([&] { launch_w16<C, true, 0, 1, 3>(w7, g3); }), g3);
+            printf("  wino16/64 grid 2 per CU      %6.1f us (grid %d)\n", time_it([&] { launch_w16<C, true, 0, 1, 3>(w7, g2); }), g2);
+            printf("  wino16/64 no weight loads    %6.1f us\n", time_it([&] { launch_w16<C, true, 1, 1, 3>(w7, g4); }));
+            printf("  wino16/64 no DMA / transform %6.1f us\n", time_it([&] { launch_w16<C, true, 2, 1, 3>(w7, g4); }));
+            printf("  wino16/64 no epilogue        %6.1f us\n", time_it([&] { launch_w16<C, true, 4, 1, 3>(w7, g4); }));
+            printf("  wino16/64 matrix + LDS only  %6.1f us\n", time_it([&] { launch_w16<C, true, 7, 1, 3>(w7, g4); }));
+            printf("  wino16/64 full again (ring 3)%6.1f us\n", time_it([&] { launch_w16<C, true, 0, 1, 3>(w7, g4); }));
+            long long *tb; CK(hipMalloc(&tb, 2 * 256 * 16)); CK(hipMemset(tb, 0, 2 * 256 * 16));
+            WinoConvParams wt = w7; wt.trace = tb;
+            launch_w16<C, true, 32, 1, 3>(wt, g4); launch_w16<C, true, 32, 1, 3>(wt, g4);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> ht(2 * 256 * 2);
+            CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+            printf("  wino16/64 trace workgroup 0:\n   ");
+            for (int i = 1; i < 250 && ht[i * 2] != 0; ++i) printf(" %lld:+%lld", ht[i * 2], ht[i * 2 + 1] - ht[(i - 1) * 2 + 1]);
+            printf("\n");
+            hipFree(tb);
+        }
         {   // phase trace of the wino16 form
             long long *tb; CK(hipMalloc(&tb, 2 * 256 * 16)); CK(hipMemset(tb, 0, 2 * 256 * 16));
             WinoConvParams wt = w6; wt.trace = tb;
