@@ -3,6 +3,8 @@
 // batches in flight: staging copy, H2D, kernels, D2H, range guard), the region form of the pileup call, zero-copy sources, and
 // the decoder entry points that take host rows.
 #pragma once
+#include <sys/mman.h>
+
 #include "c3_forward.h"
 
 // ------------------------------------------------------------------------------------------ host staging
@@ -64,6 +66,15 @@ static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStr
 
 extern "C" {
 
+// Pinned staging memory stays out of forked children.  The reference's loop forks its decode processes (ProcessPoolExecutor, clair3/
+// CallVariantsFromCffi.py:302) AFTER the model is in use: fork write-protects the parent's pages for copy-on-write, and every first
+// write to a page the device has mapped then costs a fault plus an invalidation of that mapping -- measured (tests/diag/feed_rate.py):
+// the first 40 groups after eight forks took 9.3 ms each instead of 2.6.  A range marked MADV_DONTFORK is not shared with the child,
+// so the parent's pages are left alone (what ibv_fork_init does for RDMA buffers).  A child could not use the handle anyway.
+static void keep_out_of_children(void *p, size_t bytes) {
+    if (p && bytes) (void)madvise(p, (bytes + 4095) & ~(size_t)4095, MADV_DONTFORK);
+}
+
 static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     // host_copy_kernel moves whole 16-byte pieces ((bytes + 15) / 16 of them): every buffer it touches is sized to a multiple of
     // 256 bytes here, for every path (90-column rows of an odd batch, 121-float decoder rows: yb % 16 != 0)
@@ -72,12 +83,16 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
     }
-    if (!sl.pin_flag) HIP_TRY(hipHostMalloc((void **)&sl.pin_flag, 64, hipHostMallocDefault));
+    if (!sl.pin_flag) {
+        HIP_TRY(hipHostMalloc((void **)&sl.pin_flag, 64, hipHostMallocDefault));
+        keep_out_of_children(sl.pin_flag, 64);
+    }
     if (xb > sl.cap_x) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);
         if (sl.dev_x) (void)hipFree(sl.dev_x);
         sl.pin_x = sl.dev_x = nullptr, sl.cap_x = 0;
         HIP_TRY(hipHostMalloc(&sl.pin_x, xb, hipHostMallocDefault));
+        keep_out_of_children(sl.pin_x, xb);
         HIP_TRY(hipMalloc(&sl.dev_x, xb));
         sl.cap_x = xb;
     }
@@ -86,6 +101,7 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
         if (sl.dev_y) (void)hipFree(sl.dev_y);
         sl.pin_y = nullptr, sl.dev_y = nullptr, sl.cap_y = 0;
         HIP_TRY(hipHostMalloc((void **)&sl.pin_y, yb, hipHostMallocDefault));
+        keep_out_of_children(sl.pin_y, yb);
         HIP_TRY(hipMalloc((void **)&sl.dev_y, yb));
         sl.cap_y = yb;
     }
@@ -95,13 +111,16 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
 
 static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked,
                           float *y_dev_out = nullptr);
+static int feeder_owns_ring(c3_model *m);  // c3_feed.h: != 0 (and an error) while another thread's feeder has batches in this ring
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
+    if (m) TRY(feeder_owns_ring(m));
     return predict_submit(m, x_host, x_dtype, batch, y_host, slot, false);
 }
 // the ring with the rows LEFT ON THE DEVICE (a rank of a sharded job: its rows go to the RCCL gather, not to this host): the
 // forward pass writes them straight into the caller's device buffer, only the range flag crosses PCIe
 int c3_predict_submit_dev(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_dev, int slot) {
     if (batch > 0 && !y_dev) return fail("null device buffer");
+    if (m) TRY(feeder_owns_ring(m));
     return predict_submit(m, x_host, x_dtype, batch, nullptr, slot, false, y_dev);
 }
 // src_locked: the caller (c3_predict) has page-locked x_host for the duration of ITS call -- a private fact of that call, not
@@ -217,6 +236,7 @@ static int64_t predict_chunk(const c3_model *m) {
 
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host) {
     if (!m) return fail("null model");
+    TRY(feeder_owns_ring(m));
     const int64_t chunk = predict_chunk(m);
     if (chunk <= 0 || batch < 2 * chunk) {
         TRY(c3_predict_submit(m, x_host, x_dtype, batch, y_host, 0));
@@ -277,6 +297,7 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
                              int64_t batch, float *y_host) {
     if (!m) return fail("null model");
     if (m->kind != C3_KIND_PILEUP) return fail("c3_predict_pileup_region needs a pileup model");
+    TRY(feeder_owns_ring(m));
     if (batch < 0 || n_cols < 0) return fail("negative size");
     if (batch == 0) return 0;
     if (!region_host || !starts_host || !y_host) return fail("null buffer");
