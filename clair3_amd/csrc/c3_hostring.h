@@ -68,8 +68,8 @@ extern "C" {
 
 // Pinned staging memory stays out of forked children.  The reference's loop forks its decode processes (ProcessPoolExecutor, clair3/
 // CallVariantsFromCffi.py:302) AFTER the model is in use: fork write-protects the parent's pages for copy-on-write, and every first
-// write to a page the device has mapped then costs a fault plus an invalidation of that mapping -- measured (tests/diag/feed_rate.py):
-// the first 40 groups after eight forks took 9.3 ms each instead of 2.6.  A range marked MADV_DONTFORK is not shared with the child,
+// write to a page the device has mapped then costs a fault plus an invalidation of that mapping -- measured (profiles/
+// r05_k_host_loop_feeder_not_kept.txt): the staging copies of the 40 groups after eight forks 155 -> 97 ms with this.  A range marked MADV_DONTFORK is not shared with the child,
 // so the parent's pages are left alone (what ibv_fork_init does for RDMA buffers).  A child could not use the handle anyway.
 static void keep_out_of_children(void *p, size_t bytes) {
     if (p && bytes) (void)madvise(p, (bytes + 4095) & ~(size_t)4095, MADV_DONTFORK);
@@ -111,16 +111,13 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
 
 static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked,
                           float *y_dev_out = nullptr);
-static int feeder_owns_ring(c3_model *m);  // c3_feed.h: != 0 (and an error) while another thread's feeder has batches in this ring
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
-    if (m) TRY(feeder_owns_ring(m));
     return predict_submit(m, x_host, x_dtype, batch, y_host, slot, false);
 }
 // the ring with the rows LEFT ON THE DEVICE (a rank of a sharded job: its rows go to the RCCL gather, not to this host): the
 // forward pass writes them straight into the caller's device buffer, only the range flag crosses PCIe
 int c3_predict_submit_dev(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_dev, int slot) {
     if (batch > 0 && !y_dev) return fail("null device buffer");
-    if (m) TRY(feeder_owns_ring(m));
     return predict_submit(m, x_host, x_dtype, batch, nullptr, slot, false, y_dev);
 }
 // src_locked: the caller (c3_predict) has page-locked x_host for the duration of ITS call -- a private fact of that call, not
@@ -236,7 +233,6 @@ static int64_t predict_chunk(const c3_model *m) {
 
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host) {
     if (!m) return fail("null model");
-    TRY(feeder_owns_ring(m));
     const int64_t chunk = predict_chunk(m);
     if (chunk <= 0 || batch < 2 * chunk) {
         TRY(c3_predict_submit(m, x_host, x_dtype, batch, y_host, 0));
@@ -297,7 +293,6 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
                              int64_t batch, float *y_host) {
     if (!m) return fail("null model");
     if (m->kind != C3_KIND_PILEUP) return fail("c3_predict_pileup_region needs a pileup model");
-    TRY(feeder_owns_ring(m));
     if (batch < 0 || n_cols < 0) return fail("negative size");
     if (batch == 0) return 0;
     if (!region_host || !starts_host || !y_host) return fail("null buffer");

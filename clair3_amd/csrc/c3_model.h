@@ -110,7 +110,6 @@ struct HostSlot {
     bool used_f16 = false;  // the batch in flight was computed by the fp16x3 kernels (c3_predict_wait then checks its range)
 };
 
-struct c3_feeder;  // c3_feed.h: the thread that drives the ring for c3_feed_push / c3_feed_wait
 constexpr int kHostSlots = 4;  // batches in flight per handle through c3_predict_submit / _wait (C3_HOST_SLOTS)
 
 struct c3_model {
@@ -193,7 +192,6 @@ struct c3_model {
     int64_t last_n = 0;  // windows of the last micro-batch (for debug fetch)
 
     HostSlot slot[kHostSlots];
-    c3_feeder *feeder = nullptr;  // created by the first c3_feed_push; owns the ring while it has batches outstanding
 
     // which kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
     const char *choice_lstm1 = "-", *choice_proj2 = "-", *choice_lstm2 = "-", *choice_fa = "-";

@@ -4,7 +4,6 @@
 #include "c3_pack.h"
 #include "c3_forward.h"
 #include "c3_hostring.h"
-#include "c3_feed.h"
 #include "c3_comm.h"
 #include "c3_debug.h"
 
@@ -243,11 +242,6 @@ int c3_model_describe(c3_model *m, char *buf, int n) {
     else
         snprintf(buf, (size_t)n, "sharing=%d duo=%d conv_stack=%s stride1=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->duo, m->choice_fa, m->choice_s1,
                  m->choice_s2[0], m->choice_s2[1], (int)!m->f16_ok);
-    if (m->feeder) {  // (read without the feeder's lock: a progress report, not a synchronisation point)
-        const size_t len = strlen(buf);
-        snprintf(buf + len, (size_t)n - len, " feed=%lld:%.0f:%.0f:%.0f", (long long)m->feeder->done_upto, m->feeder->ms_submit, m->feeder->ms_wait,
-                 m->feeder->ms_idle);
-    }
     return 0;
 }
 
@@ -259,7 +253,6 @@ int c3_model_synchronize(c3_model *m) {
 
 int c3_model_destroy(c3_model *m) {
     if (!m) return 0;
-    feeder_destroy(m);  // batches in flight are waited for, batches never started are dropped
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
     free_workspace(m);

@@ -235,29 +235,6 @@ class _HipModel:
         _lib.check(_lib.lib().c3_predict_wait(self._handle, slot), "c3_predict_wait")
         return y
 
-    def feed(self, x):
-        """Queue ``x`` on the handle's feeder thread (c3_feed_push: the library drives the submit / wait ring itself, batches in
-        push order, three in flight) and return at once; ``feed_wait(ticket)`` returns the rows.  ``x`` must stay unchanged until
-        then (the ticket keeps it alive).  While anything is outstanding the other predict calls of this handle fail."""
-        x = np.ascontiguousarray(x)
-        dt = _NP_DTYPE.get(x.dtype)
-        if dt is None:
-            raise _lib.C3Error(f"unsupported window dtype {x.dtype} (int8 / int32 expected)")
-        self._check_shape(x.shape, dt)
-        y = np.empty((x.shape[0], self.row_size), dtype=np.float32)
-        t = C.c_int64(-1)
-        _lib.check(_lib.lib().c3_feed_push(self._handle, x.ctypes.data, dt, x.shape[0], y.ctypes.data, C.byref(t)), "c3_feed_push")
-        return t.value, y, x
-
-    def feed_wait(self, ticket):
-        _lib.check(_lib.lib().c3_feed_wait(self._handle, ticket[0]), "c3_feed_wait")
-        return ticket[1]
-
-    def feed_drain(self):
-        """Block until everything fed has been computed (errors nobody waited for are raised here)."""
-        if self._handle is not None:
-            _lib.check(_lib.lib().c3_feed_drain(self._handle), "c3_feed_drain")
-
     def sharing(self, handles=1):
         """Tell the handle how many handles feed its GPU side by side (c3_model_set_sharing; a speed hint only)."""
         _lib.check(_lib.lib().c3_model_set_sharing(self._handle, int(handles)), "c3_model_set_sharing")

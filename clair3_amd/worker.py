@@ -115,13 +115,7 @@ def group_windows_for(model):
     return 4000 if getattr(model, "KIND", None) == 0 else 2000
 
 
-def _queue_groups():
-    """Groups whose rows may sit finished ahead of the loop (C3HIP_PREFETCH_QUEUE; 0 = no feeder thread: the loop's own calls of
-    the generator drive the ring, as until round 4)."""
-    return max(0, int(os.environ.get("C3HIP_PREFETCH_QUEUE", "8")))
-
-
-def lookahead_batches(model, files, batch_size, pending, depth=2, group_windows=0, queue_groups=None):
+def lookahead_batches(model, files, batch_size, pending, depth=2, group_windows=0):
     """The transport behind the reference's OWN loop.  ``call_variants_from_cffi`` pulls one batch from its generator and
     makes one blocking ``_torch_predict`` call on it (clair3/CallVariantsFromCffi.py:302-317); this generator keeps the
     loop's shape -- the same batches (never across files, the last batch of a file short), the same order -- and runs ahead
@@ -130,22 +124,12 @@ def lookahead_batches(model, files, batch_size, pending, depth=2, group_windows=
     loop is reading are in flight, and ``pending[id(X)] = (model, group, X, lo, hi)`` tells the rebound ``_torch_predict``
     (predict._hip_predict) that the rows of batch ``X`` only need to be waited for and sliced.  Same rows as the blocking
     calls: a window's row does not depend on the batch it travels in.
-    ``files``: an iterator of (tensor, positions, alt_infos) per tensor file (iter_tensor_files).
-
-    ``queue_groups`` > 0 (default: C3HIP_PREFETCH_QUEUE, 8) and a handle with ``feed`` (the library's feeder thread,
-    csrc/c3_feed.h): the ring is driven by that NATIVE thread instead of by the loop's calls -- up to ``queue_groups`` groups are
-    pushed ahead (descriptors only), so the staging copies leave the loop thread and the GPU keeps working while the loop sits in
-    ``as_completed`` waiting for a decode process (clair3/CallVariantsFromCffi.py:337-341; measured on the reference's own loop,
-    tests/diag/loop_timeline.py: the loop thread spent 0.23 s per 240 k windows in this generator and 0.21 s waiting for rows, next
-    to 0.32 s waiting for decode processes -- one after the other; a Python feeder thread made it worse, it waits for the
-    interpreter lock).  ``depth`` then plays no part (the feeder keeps three groups in flight).  Same batches, same order, same rows."""
+    ``files``: an iterator of (tensor, positions, alt_infos) per tensor file (iter_tensor_files)."""
     from collections import deque
     slots = depth + 1
     if not 1 <= slots <= HOST_SLOTS:
         raise ValueError(f"depth must be in [0, {HOST_SLOTS - 1}], got {depth}")
     per_group = max(1, int(group_windows) // int(batch_size)) * int(batch_size)
-    if queue_groups is None:
-        queue_groups = _queue_groups()
 
     def groups():  # (tensor slice of the group, [(lo, hi, positions, alt_infos) per batch, offsets inside the group])
         for tensor, positions, alt_infos in files:
@@ -156,9 +140,6 @@ def lookahead_batches(model, files, batch_size, pending, depth=2, group_windows=
                          for lo in range(g0, g1, batch_size)]
                 yield tensor[g0:g1], parts
 
-    if queue_groups > 0 and hasattr(model, "feed") and getattr(model, "_handle", None) is not None:  # (a handle of the library)
-        yield from _fed_batches(model, groups(), pending, int(queue_groups))
-        return
     queue = deque()  # (group, Xg, parts), oldest first
     it = groups()
     n_submitted, exhausted = 0, False
@@ -194,64 +175,6 @@ def lookahead_batches(model, files, batch_size, pending, depth=2, group_windows=
         for X in handed:
             pending.pop(id(X), None)
         for group, _, _ in queue:  # abandoned or failed half way: nothing may stay in flight on the handle
-            group.drain()
-
-
-class _FedGroup:
-    """A group computed by the handle's feeder thread (model.feed): its rows are waited for once, by the first batch that asks."""
-    __slots__ = ("model", "ticket", "rows")
-
-    def __init__(self, model, ticket):
-        self.model, self.ticket, self.rows = model, ticket, None
-
-    def take(self, lo, hi):
-        if self.rows is None:
-            self.rows = self.model.feed_wait(self.ticket)
-        return self.rows[lo:hi]
-
-    def drain(self):
-        if self.rows is None:
-            try:
-                self.rows = self.model.feed_wait(self.ticket)
-            except Exception:
-                self.rows = ()
-
-
-def _fed_batches(model, groups, pending, queue_groups):
-    """lookahead_batches on the library's feeder thread (include/c3hip.h c3_feed_push): up to ``queue_groups`` groups are pushed
-    ahead of the one the loop is reading -- descriptors only; the staging copy, the transfers and the kernels of every group run
-    on the library's thread, in order, whatever this thread is doing."""
-    from collections import deque
-    ahead = deque()  # (group, Xg, parts) pushed, oldest first
-    exhausted = False
-    handed = []
-    try:
-        while True:
-            while not exhausted and len(ahead) <= queue_groups:
-                try:
-                    Xg, parts = next(groups)
-                except StopIteration:
-                    exhausted = True
-                    break
-                Xg = np.ascontiguousarray(Xg)
-                ahead.append((_FedGroup(model, model.feed(Xg)), Xg, parts))
-            if not ahead:
-                return
-            group, Xg, parts = ahead[0]
-            for lo, hi, positions, alt_infos in parts:
-                X = Xg[lo:hi]
-                pending[id(X)] = (model, group, X, lo, hi)
-                handed.append(X)
-                yield X, positions, alt_infos
-            for X in handed:
-                pending.pop(id(X), None)
-            handed = []
-            group.drain()
-            ahead.popleft()
-    finally:
-        for X in handed:
-            pending.pop(id(X), None)
-        for group, _, _ in ahead:  # abandoned or failed half way: nothing may stay outstanding on the handle
             group.drain()
 
 

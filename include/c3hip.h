@@ -115,16 +115,6 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
  * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);
 int c3_predict_wait(c3_model *m, int slot);
-/* The ring driven by a thread of the library instead of by the caller's calls (csrc/c3_feed.h) -- for a caller whose own loop cannot
- * come back in time to keep it full: the reference's stage-B loop (clair3/CallVariantsFromCffi.py:302-353) is one Python thread that
- * also feeds and waits for its decode processes.  c3_feed_push queues one batch (descriptors only: x_host must stay valid and y_host
- * untouched until c3_feed_wait(ticket) has returned) and returns at once; batches run in push order, three in flight; c3_feed_wait
- * blocks until the rows of that batch are in its y_host and returns what c3_predict would have returned for it (range guard
- * included); c3_feed_drain waits for everything pushed.  Between the first push and a drain that leaves nothing outstanding the
- * ring belongs to the feeder: c3_predict / c3_predict_submit / _wait from another thread fail.  Tickets are consecutive from 0. */
-int c3_feed_push(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int64_t *ticket);
-int c3_feed_wait(c3_model *m, int64_t ticket);
-int c3_feed_drain(c3_model *m);
 /* The same ring with the rows LEFT ON THE DEVICE: y_dev is a device pointer on the model's device (batch x c3_model_row_size()
  * floats) that the forward pass writes directly; nothing but the range flag crosses PCIe on the way out.  For a rank of a
  * sharded job whose rows go to c3_gather_rows, not to its own host -- the reference's per-GPU workers each write their rows to

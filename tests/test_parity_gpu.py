@@ -171,66 +171,6 @@ def test_async_submit_wait_and_device_paths_agree():
     assert yd.is_cuda and np.array_equal(yd.cpu().numpy(), ya)
 
 
-def test_the_feeder_thread_returns_the_rows_of_the_blocking_call(tmp_path):
-    """c3_feed_push / c3_feed_wait (csrc/c3_feed.h): batches pushed at once -- ragged sizes, an empty one, both networks, with the
-    decoder columns -- come back bit for bit as c3_predict's rows, whatever the order they are waited for in; while anything is
-    outstanding the handle's own calls refuse; the transport of the drop-in loop (worker.lookahead_batches) rides on it and
-    yields the rows of the blocking calls."""
-    from clair3_amd import worker
-    for kind, ch, indel, n0 in ((syn.FULL_ALIGNMENT, 8, True, 300), (syn.PILEUP, 18, False, 1500)):
-        sd = syn.make_state_dict(kind, ch, indel, seed=71)
-        m = make_model(kind, ch, indel, sd)
-        m.decode_columns(True)
-        sizes = [n0, 1, 0, 257, n0 // 3, 64, n0, 33]
-        xs = [syn.make_windows(kind, n, seed=80 + i, channels=ch) for i, n in enumerate(sizes)]
-        want = [m.predict_numpy(x) if len(x) else np.empty((0, m.row_size), np.float32) for x in xs]
-        tickets = [m.feed(x) for x in xs]
-        with pytest.raises(_lib.C3Error, match="feeder has batches in flight"):
-            m.wait(m.submit(xs[1], slot=3))
-        for i in (3, 0, 7, 1, 2, 6, 5, 4):
-            assert np.array_equal(m.feed_wait(tickets[i]), want[i]), (kind, i)
-        m.feed_drain()
-        assert np.array_equal(m.predict_numpy(xs[3]), want[3])  # the ring is the caller's again
-        # a second round on the same handle, drained without waiting for anything
-        tickets = [m.feed(x) for x in xs[:4]]
-        m.feed_drain()
-        assert all(np.array_equal(t[1], w) for t, w in zip(tickets, want))
-        # the transport: files of ragged length, batches of 100, groups of 300
-        d = tmp_path / f"job{kind}"
-        d.mkdir()
-        names = []
-        for i, n in enumerate((250, 100, 7, 301)):
-            x = syn.make_windows(kind, n, seed=90 + i, channels=ch)
-            np.save(d / f"t{i}.npy", x)
-            (d / f"t{i}.info").write_text("".join(f"chr1:{1000 * i + j}:{'ACGT' * 8}A\t10-A 5\n" for j in range(n)))
-            names.append(f"t{i}")
-        (d / "list").write_text("\n".join(names) + "\n")
-        pending, got, ref = {}, [], []
-        for X, pos, alt in worker.lookahead_batches(m, worker.iter_tensor_files(str(d / "list")), 100, pending, depth=2, group_windows=300,
-                                                    queue_groups=4):
-            assert id(X) in pending and isinstance(pending[id(X)][1], worker._FedGroup)
-            got.append(_hip_predict(m, None, X))
-            ref.append(np.array(X))
-        assert not pending
-        m.feed_drain()
-        for g, x in zip(got, ref):
-            assert np.array_equal(g, m.predict_numpy(x))
-        assert sum(len(g) for g in got) == 658
-        del m  # destroying a handle whose feeder exists joins its thread
-
-
-def test_a_handle_is_destroyed_with_batches_still_queued_on_its_feeder():
-    sd = syn.make_state_dict(syn.FULL_ALIGNMENT, 8, True, seed=72)
-    m = make_model(syn.FULL_ALIGNMENT, 8, True, sd)
-    xs = [syn.make_fa_windows(200, seed=73 + i) for i in range(8)]
-    tickets = [m.feed(x) for x in xs]
-    y0 = m.feed_wait(tickets[0])
-    assert np.isfinite(y0).all()
-    m._destroy()  # batches in flight are waited for, batches never started are dropped; the thread is joined
-    assert m._handle is None
-    del tickets
-
-
 def test_strict_state_dict_loading():
     sd = syn.make_state_dict(syn.PILEUP, seed=61)
     m = Clair3_P(predict=True).to("cuda:0")
