@@ -59,13 +59,13 @@ int c3_debug_fetch(c3_model *m, const char *name, float *host_out, int64_t n_flo
         float *tmp = nullptr;
         HIP_TRY(hipMalloc((void **)&tmp, (size_t)n * sizeof(float)));
         hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const void *)src, tmp, n / C, C);
-        hipError_t e = hipMemcpy(host_out, tmp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+        const int rc = d2h_staged(host_out, tmp, (size_t)n * sizeof(float));
         (void)hipFree(tmp);
-        if (e != hipSuccess) return fail("debug fetch copy failed: %s", hipGetErrorString(e));
+        if (rc != 0) return rc;
         unscale();
         return 0;
     }
-    HIP_TRY(hipMemcpy(host_out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    TRY(d2h_staged(host_out, src, (size_t)n * sizeof(float)));
     unscale();
     return 0;
 }

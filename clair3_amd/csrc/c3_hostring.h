@@ -3,8 +3,6 @@
 // batches in flight: staging copy, H2D, kernels, D2H, range guard), the region form of the pileup call, zero-copy sources, and
 // the decoder entry points that take host rows.
 #pragma once
-#include <sys/mman.h>
-
 #include "c3_forward.h"
 
 // ------------------------------------------------------------------------------------------ host staging
@@ -66,15 +64,8 @@ static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStr
 
 extern "C" {
 
-// Pinned staging memory stays out of forked children.  The reference's loop forks its decode processes (ProcessPoolExecutor, clair3/
-// CallVariantsFromCffi.py:302) AFTER the model is in use: fork write-protects the parent's pages for copy-on-write, and every first
-// write to a page the device has mapped then costs a fault plus an invalidation of that mapping -- measured (profiles/
-// r05_k_host_loop_feeder_not_kept.txt): the staging copies of the 40 groups after eight forks 155 -> 97 ms with this.  A range marked MADV_DONTFORK is not shared with the child,
-// so the parent's pages are left alone (what ibv_fork_init does for RDMA buffers).  A child could not use the handle anyway.
-static void keep_out_of_children(void *p, size_t bytes) {
-    if (p && bytes) (void)madvise(p, (bytes + 4095) & ~(size_t)4095, MADV_DONTFORK);
-}
-
+// Pinned staging memory stays out of forked children (keep_out_of_children, c3_model.h: the staging copies of the 40 groups after
+// eight forks 155 -> 97 ms, profiles/r05_k_host_loop_feeder_not_kept.txt).
 static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     // host_copy_kernel moves whole 16-byte pieces ((bytes + 15) / 16 of them): every buffer it touches is sized to a multiple of
     // 256 bytes here, for every path (90-column rows of an odd batch, 121-float decoder rows: yb % 16 != 0)
@@ -355,15 +346,14 @@ int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uin
     float *maxp = (float *)(base + yb + rb);
     int32_t *arg = (int32_t *)(base + yb + rb + mb);
     uint8_t *early = (uint8_t *)(base + yb + rb + 2 * mb);
-    HIP_TRY(hipMemcpyAsync(y, y_host, yb, hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(ref, ref21_host, (size_t)batch, hipMemcpyHostToDevice, m->stream));
+    TRY(h2d_staged(y, y_host, yb, m->stream));  // (pageable rows: through the bounce buffer, c3_model.h)
+    TRY(h2d_staged(ref, ref21_host, (size_t)batch, m->stream));
     DecodeParams dp{y, m->nout, ref, maxp, arg, early, nullptr, (int)batch, m->nout == 90 ? 1 : 0};
     hipLaunchKernelGGL(outcome_maxima_kernel<false>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(maxp_host, maxp, mb, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(argmax_host, arg, mb, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(early_host, early, (size_t)batch, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    TRY(d2h_staged(maxp_host, maxp, mb, m->stream));
+    TRY(d2h_staged(argmax_host, arg, mb, m->stream));
+    TRY(d2h_staged(early_host, early, (size_t)batch, m->stream));
     return 0;
 }
 
@@ -382,13 +372,23 @@ int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *ro
         m->decode_bytes = total;
     }
     float *rows = (float *)m->decode_dev;
-    HIP_TRY(hipMemcpy2DAsync(rows, (size_t)wide * sizeof(float), y_host, (size_t)m->nout * sizeof(float),
-                             (size_t)m->nout * sizeof(float), (size_t)batch, hipMemcpyHostToDevice, m->stream));
+    {   // the rows widen on their way through the bounce buffer (the kernel fills the decoder columns behind each)
+        BounceBuf &b = bounce_buf();
+        std::lock_guard<std::mutex> lk(b.mu);
+        TRY(bounce_ready(b));
+        const int64_t per = (int64_t)(BounceBuf::kBytes / ((size_t)wide * sizeof(float)));
+        for (int64_t r0 = 0; r0 < batch; r0 += per) {
+            const int64_t nr = std::min(per, batch - r0);
+            for (int64_t r = 0; r < nr; ++r)
+                memcpy((float *)b.pin + r * wide, y_host + (r0 + r) * m->nout, (size_t)m->nout * sizeof(float));
+            HIP_TRY(hipMemcpyAsync(rows + r0 * wide, b.pin, (size_t)nr * wide * sizeof(float), hipMemcpyHostToDevice, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+    }
     DecodeParams dp{rows, wide, nullptr, nullptr, nullptr, nullptr, rows + m->nout, (int)batch, m->nout == 90 ? 1 : 0};
     hipLaunchKernelGGL(outcome_maxima_kernel<true>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(rows_host, rows, total, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    TRY(d2h_staged(rows_host, rows, total, m->stream));
     return 0;
 }
 

@@ -13,6 +13,7 @@
 // one fp32-MFMA form that the range guard falls back to (and that C3HIP_FP32=1 selects from the start).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -272,10 +273,64 @@ static int dev_alloc(c3_model *m, void **p, size_t bytes) {
     *p = b.p;
     return 0;
 }
+// ---- PAGEABLE host memory never meets the device directly.  A hipMemcpy from (or to) pageable memory makes the runtime pin the
+// caller's pages, and it keeps them registered with the device for as long as the range stays mapped (measured, tools/
+// fork_stall_probe.hip: after a 256 MB pageable upload the first kernel behind a fork() completes 3.3 s late -- fork write-protects
+// the registered pages, the driver evicts the process's queues and revalidates every registered page; with the source freed, or with
+// no pageable copy at all, nothing happens).  The reference's stage-B loop forks its decode pool right after its first model call
+// (clair3/CallVariantsFromCffi.py:302): with the weights uploaded from the state dict's pageable arrays that fork cost ~0.3 s of
+// every run of the loop (tests/diag/fork_stall.py: first call after the forks 320 ms, then 2.8 ms).  So every such copy goes through
+// ONE pinned bounce buffer that forked children do not inherit.
+static void keep_out_of_children(void *p, size_t bytes) {  // (what ibv_fork_init does for RDMA buffers; a child could not use the handle anyway)
+    if (p && bytes) (void)madvise(p, (bytes + 4095) & ~(size_t)4095, MADV_DONTFORK);
+}
+struct BounceBuf {
+    static constexpr size_t kBytes = (size_t)8 << 20;
+    std::mutex mu;
+    void *pin = nullptr;
+};
+static BounceBuf &bounce_buf() {
+    static BounceBuf *b = new BounceBuf;  // never destroyed (handles may outlive static destruction at exit)
+    return *b;
+}
+static int bounce_ready(BounceBuf &b) {
+    if (!b.pin) {
+        HIP_TRY(hipHostMalloc(&b.pin, BounceBuf::kBytes, hipHostMallocDefault));
+        keep_out_of_children(b.pin, BounceBuf::kBytes);
+    }
+    return 0;
+}
+// dev[0, bytes) = src[0, bytes): synchronous (src may be reused on return); s orders the copy behind the stream's work
+static int h2d_staged(void *dev, const void *src, size_t bytes, hipStream_t s = nullptr) {
+    BounceBuf &b = bounce_buf();
+    std::lock_guard<std::mutex> lk(b.mu);
+    TRY(bounce_ready(b));
+    for (size_t off = 0; off < bytes; off += BounceBuf::kBytes) {
+        const size_t n = std::min(BounceBuf::kBytes, bytes - off);
+        memcpy(b.pin, (const char *)src + off, n);
+        HIP_TRY(hipMemcpyAsync((char *)dev + off, b.pin, n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+// dst[0, bytes) = dev[0, bytes) behind the stream's work: synchronous
+static int d2h_staged(void *dst, const void *dev, size_t bytes, hipStream_t s = nullptr) {
+    BounceBuf &b = bounce_buf();
+    std::lock_guard<std::mutex> lk(b.mu);
+    TRY(bounce_ready(b));
+    for (size_t off = 0; off < bytes; off += BounceBuf::kBytes) {
+        const size_t n = std::min(BounceBuf::kBytes, bytes - off);
+        HIP_TRY(hipMemcpyAsync(b.pin, (const char *)dev + off, n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy((char *)dst + off, b.pin, n);
+    }
+    return 0;
+}
+
 static int upload(c3_model *m, float **dst, const std::vector<float> &src) {
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, std::max<size_t>(src.size() * sizeof(float), 256)));
-    HIP_TRY(hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    TRY(h2d_staged(p, src.data(), src.size() * sizeof(float)));
     if (*dst) (void)hipFree(*dst);
     *dst = (float *)p;
     (void)m;

@@ -195,7 +195,10 @@ int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64
     const bool f16 = m->f16_ok;
     TRY(forward_device(m, s, x_dev, x_dtype, batch, y_dev));
     if (!f16 || batch == 0) return 0;
-    if (!m->pin_flag) HIP_TRY(hipHostMalloc((void **)&m->pin_flag, 64, hipHostMallocDefault));
+    if (!m->pin_flag) {
+        HIP_TRY(hipHostMalloc((void **)&m->pin_flag, 64, hipHostMallocDefault));
+        keep_out_of_children(m->pin_flag, 64);
+    }
     const int64_t nf = batch * m->row;
     hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, y_dev, nf, m->range_flag);
     HIP_TRY(hipGetLastError());
@@ -215,7 +218,7 @@ int c3_model_range_status(c3_model *m, int *flag_out, int *on_fp32_out) {
     HIP_TRY(hipSetDevice(m->device));
     uint32_t f = 0;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&f, m->range_flag, 4, hipMemcpyDeviceToHost));
+    TRY(d2h_staged(&f, m->range_flag, 4));
     if (flag_out) *flag_out = (int)f;
     if (on_fp32_out) *on_fp32_out = m->f16_ok ? 0 : 1;
     return 0;
