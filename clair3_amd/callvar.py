@@ -35,6 +35,88 @@ def _select_device_for_worker(use_gpu):
     return torch.device("cpu")
 
 
+# ---- the decode pool of the stage-B loop, forked BEFORE the device is in use.
+# call_variants_from_cffi creates its ProcessPoolExecutor after the model is loaded, and the pool forks its processes on the loop's
+# first submits -- right behind the first model call.  A fork of the interpreter's process with the device at work costs the loop
+# ~0.3 s: the device does not answer for a quarter of a second and the loop thread and the fresh children crawl through
+# copy-on-write faults (profiles/r05_l_fork_stall.txt; tests/diag/loop_timeline.py: 240 k full-alignment windows in 0.95 - 1.03 s,
+# in 0.66 s = 365 k windows/s with the pool forked before the model load).  The loop's first call into rebound code on the GPU
+# branch is _select_device(True) (clair3/CallVariantsFromCffi.py:217), before any HIP call of this process: the pool is created
+# there -- the same concurrent.futures.ProcessPoolExecutor, the size the command line asks for, every process forked (one short
+# task each) -- and the module's name ProcessPoolExecutor hands it to the loop's `with ProcessPoolExecutor(max_workers=
+# args.cpu_threads)` (:302).  Any other request (another size, other arguments, a second pool) gets an ordinary executor.
+# C3HIP_PREFORK_POOL=0 leaves the loop's pool alone.
+_PREFORKED = None  # (executor, max_workers) waiting for the loop to ask for it
+
+
+def _cpu_threads_from_argv(default=4):
+    """--cpu_threads of the worker command line (clair3/CallVariantsFromCffi.py:569, default 4)"""
+    argv = sys.argv
+    for i, a in enumerate(argv):
+        try:
+            if a == "--cpu_threads" and i + 1 < len(argv):
+                return int(argv[i + 1])
+            if a.startswith("--cpu_threads="):
+                return int(a.split("=", 1)[1])
+        except ValueError:
+            return default
+    return default
+
+
+def _prefork_decode_pool(n):
+    """A ProcessPoolExecutor of n processes, all of them forked and idle; None if that is not possible."""
+    global _PREFORKED
+    import atexit
+    import concurrent.futures as cf
+    import time
+    if n < 1:
+        return None
+    # the loop's first SharedMemory(create=True) starts multiprocessing's resource tracker BEFORE its first fork, so its decode
+    # processes talk to the parent's tracker when they unlink a segment (:181); processes forked ahead must inherit it as well
+    from multiprocessing import resource_tracker
+    resource_tracker.ensure_running()
+    ex = cf.ProcessPoolExecutor(max_workers=n)
+    try:
+        # a submit forks a new process when no idle one is waiting (concurrent/futures/process.py _adjust_process_count):
+        # n tasks that outlast the n forks make n processes
+        for f in [ex.submit(time.sleep, 0.05) for _ in range(n)]:
+            f.result()
+    except Exception:  # noqa: BLE001  (no pool here is not an error: the loop creates its own)
+        ex.shutdown(wait=False, cancel_futures=True)
+        return None
+    _PREFORKED = (ex, n)
+    atexit.register(_drop_preforked)  # a loop that never asks for its pool must not leave processes behind
+    return ex
+
+
+def _drop_preforked():
+    global _PREFORKED
+    pre, _PREFORKED = _PREFORKED, None
+    if pre is not None:
+        pre[0].shutdown(wait=False, cancel_futures=True)
+
+
+def _make_pool_factory(original):
+    def ProcessPoolExecutor(max_workers=None, *args, **kwargs):
+        global _PREFORKED
+        pre, _PREFORKED = _PREFORKED, None
+        if pre is not None:
+            if max_workers == pre[1] and not args and not kwargs:
+                return pre[0]
+            pre[0].shutdown(wait=False, cancel_futures=True)
+        return original(max_workers, *args, **kwargs)
+
+    ProcessPoolExecutor._c3hip_original = original
+    return ProcessPoolExecutor
+
+
+def _select_device_for_cffi_worker(use_gpu):
+    """_select_device of the stage-B worker: on the GPU branch the decode pool is forked first (see above)."""
+    if use_gpu and _PREFORKED is None and os.environ.get("C3HIP_PREFORK_POOL", "1").strip().lower() not in ("0", "false", "no", "off"):
+        _prefork_decode_pool(_cpu_threads_from_argv())
+    return _select_device_for_worker(use_gpu)
+
+
 def _limit_gpu_memory(memory_mb, device):
     return  # libc3hip sizes its own workspace (c3_mem_info is the accounting hook); nothing to cap
 
@@ -97,13 +179,15 @@ def install(worker=True, gpu_wrapper=True, decoder=False):
         import clair3.CallVariantsFromCffi as w
         w._torch_predict = predict._hip_predict
         w._load_torch_checkpoint = predict._load_torch_checkpoint
-        w._select_device = _select_device_for_worker
+        w._select_device = _select_device_for_cffi_worker
         w._limit_gpu_memory = _limit_gpu_memory
         if not hasattr(w.tensor_generator_for_chunk, "_c3hip_original"):
             w.tensor_generator_for_chunk = _make_batch_generator(w.tensor_generator_for_chunk)
+        if not hasattr(w.ProcessPoolExecutor, "_c3hip_original"):
+            w.ProcessPoolExecutor = _make_pool_factory(w.ProcessPoolExecutor)
         done += ["clair3.CallVariantsFromCffi." + n for n in
                  ("_torch_predict", "_load_torch_checkpoint", "_select_device", "_limit_gpu_memory",
-                  "tensor_generator_for_chunk")]
+                  "tensor_generator_for_chunk", "ProcessPoolExecutor")]
     if worker:
         # the twins of the same four functions in the legacy stdin-pipe worker (clair3/CallVariants.py:54-87; call_variants
         # :1456 ff. imports the model classes when it runs, i.e. it gets the rebound ones): same model call, its own transport

@@ -86,23 +86,32 @@ def load(m, path, device):
     return r
 
 
-class Pool(cf.ProcessPoolExecutor):
-    def __init__(self, *a, **k):
-        t0 = time.time()
-        super().__init__(*a, **k)
-        ev("pool_init", t0, time.time())
+_pool_factory = w.ProcessPoolExecutor  # callvar's: hands out the pool it forked before the device was in use (C3HIP_PREFORK_POOL)
 
-    def submit(self, *a, **k):
+
+def Pool(*a, **k):
+    t0 = time.time()
+    ex = _pool_factory(*a, **k)
+    ev("pool_init", t0, time.time(), len(getattr(ex, "_processes", {}) or {}))  # n = processes that exist already
+    _submit, _exit = ex.submit, type(ex).__exit__
+
+    def submit(*sa, **sk):
         t0 = time.time()
-        f = super().submit(*a, **k)
+        f = _submit(*sa, **sk)
         ev("submit", t0, time.time())
         return f
 
-    def __exit__(self, *a):
-        t0 = time.time()
-        r = super().__exit__(*a)
-        ev("pool_exit", t0, time.time())
-        return r
+    ex.submit = submit
+
+    class Timed(type(ex)):
+        def __exit__(self, *xa):
+            t0 = time.time()
+            r = _exit(self, *xa)
+            ev("pool_exit", t0, time.time())
+            return r
+
+    ex.__class__ = Timed
+    return ex
 
 
 # the pool pickles the task function by name: the wrapper answers to the name it replaces (this script is not importable as __main__
@@ -171,7 +180,8 @@ tot = lambda tag: sum(b - a for _, t, a, b, _ in main if t == tag)  # noqa: E731
 first = lambda tag: min((a for _, t, a, _, _ in E if t == tag), default=t0) - t0  # noqa: E731
 n = per_file * files
 out = {
-    "job": f"{name}: {n} windows in {files} files, {threads} decode processes, decoder columns {os.environ.get('C3_TL_DECODER', '1')}",
+    "job": f"{name}: {n} windows in {files} files, {threads} decode processes, decoder columns {os.environ.get('C3_TL_DECODER', '1')}"
+           + ", decode pool forked ahead by callvar: C3HIP_PREFORK_POOL=" + os.environ.get("C3HIP_PREFORK_POOL", "1"),
     "loop_seconds (the reference's 'Total time elapsed')": round(t1 - t0, 3),
     "windows_per_s_in_the_loop": round(n / (t1 - t0)),
     "main thread, seconds inside": {
@@ -181,6 +191,7 @@ out = {
         "as_completed until one decode is done (pending full, or the generator is exhausted)": round(tot("wait_one_done"), 3),
         "SharedMemory(create=True)": round(tot("shm_open"), 3),
         "pool construction": round(tot("pool_init"), 3),
+        "decode processes that existed when the loop asked for its pool": next((k for _, t, _, _, k in main if t == "pool_init"), None),
         "pool exit (join the decode processes)": round(tot("pool_exit"), 3),
     },
     "as_completed calls with fewer than 2 x cpu_threads pending (the tail: generator exhausted)": sum(1 for _, t, _, _, k in main if t == "wait_one_done" and k < 2 * threads),

@@ -1,4 +1,7 @@
 """Host-side logic that needs no GPU: state_dict specs, synthetic recipes, sharding arithmetic."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -65,7 +68,7 @@ def test_install_rebinds_the_reference_call_sites():
         from clair3_amd import callvar, predict
         from clair3_amd.model import Clair3_F, Clair3_P
         names = callvar.install()
-        assert len(names) == 13
+        assert len(names) == 14 and "clair3.CallVariantsFromCffi.ProcessPoolExecutor" in names
         assert w.tensor_generator_for_chunk._c3hip_original.__module__ == "clair3.CallVariantsFromCffi"
         assert callvar.install() == names  # idempotent: the generator is wrapped once
         assert not hasattr(w.tensor_generator_for_chunk._c3hip_original, "_c3hip_original")
@@ -88,7 +91,7 @@ def test_install_rebinds_the_reference_call_sites():
         unpatched = cv.batch_output
         assert not predict.DECODER_COLUMNS
         names = callvar.install(decoder=True)
-        assert len(names) == 15 and predict.DECODER_COLUMNS
+        assert len(names) == 16 and predict.DECODER_COLUMNS
         assert cv.batch_output is not unpatched and w.batch_output is cv.batch_output
         for n, params in sig.items():
             assert list(inspect.signature(getattr(cv, n)).parameters) == params, n
@@ -130,3 +133,49 @@ def test_gpu_slots_on_a_288_gb_device(monkeypatch, capsys):
         predict.check_gpu_memory(8000, [], print_log=False)
     monkeypatch.setattr(_lib, "device_count", lambda: 0)
     assert predict.check_gpu_memory(8000, None, print_log=False) is None
+
+
+def _forked_pid():  # (module level: the pool pickles its task by name)
+    return os.getpid()
+
+
+def test_the_decode_pool_is_forked_before_the_device_is_in_use(monkeypatch):
+    """callvar: on the GPU branch _select_device (the loop's first call into rebound code, before any HIP call) creates the
+    ProcessPoolExecutor the loop is going to ask for -- every process forked -- and the module's name ProcessPoolExecutor hands
+    exactly that executor to `ProcessPoolExecutor(max_workers=args.cpu_threads)`; any other request gets an ordinary executor
+    (profiles/r05_l_fork_stall.txt: a fork of the interpreter's process with the device at work costs the loop ~0.3 s)."""
+    import concurrent.futures as cf
+    from clair3_amd import callvar
+    monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi", "--cpu_threads", "3", "--use_gpu", "True"])
+    assert callvar._cpu_threads_from_argv() == 3
+    monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi", "--cpu_threads=2"])
+    assert callvar._cpu_threads_from_argv() == 2
+    monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi"])
+    assert callvar._cpu_threads_from_argv() == 4  # the reference's default (clair3/CallVariantsFromCffi.py:569)
+    factory = callvar._make_pool_factory(cf.ProcessPoolExecutor)
+    monkeypatch.setattr(callvar, "_lib", type("L", (), {"device_count": staticmethod(lambda: 1)}))
+    monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi", "--cpu_threads", "2"])
+    callvar._drop_preforked()
+    try:
+        monkeypatch.setenv("C3HIP_PREFORK_POOL", "0")
+        assert callvar._select_device_for_cffi_worker(True) == "cuda:0" and callvar._PREFORKED is None
+        monkeypatch.setenv("C3HIP_PREFORK_POOL", "1")
+        assert str(callvar._select_device_for_cffi_worker(False)) == "cpu" and callvar._PREFORKED is None  # the CPU branch has no pool
+        assert callvar._select_device_for_cffi_worker(True) == "cuda:0"
+        ex, n = callvar._PREFORKED
+        assert n == 2 and len(ex._processes) == 2  # both processes exist already
+        before = set(ex._processes)
+        with factory(max_workers=2) as got:  # what the loop does (:302)
+            assert got is ex and callvar._PREFORKED is None
+            pids = {got.submit(_forked_pid).result() for _ in range(8)}
+            assert pids <= before and os.getpid() not in pids  # no new fork: the tasks ran in the processes forked ahead
+        with factory(max_workers=2) as other:  # a second pool is an ordinary one
+            assert other is not ex and other.submit(_forked_pid).result() != os.getpid()
+        # a request of another size: the pool forked ahead is dropped, the caller gets what it asked for
+        assert callvar._select_device_for_cffi_worker(True) == "cuda:0"
+        ex2 = callvar._PREFORKED[0]
+        with factory(max_workers=1) as small:
+            assert small is not ex2 and callvar._PREFORKED is None
+            assert small.submit(_forked_pid).result() != os.getpid()
+    finally:
+        callvar._drop_preforked()
