@@ -79,8 +79,13 @@ def _prefork_decode_pool(n):
     try:
         # a submit forks a new process when no idle one is waiting (concurrent/futures/process.py _adjust_process_count):
         # n tasks that outlast the n forks make n processes
-        for f in [ex.submit(time.sleep, 0.05) for _ in range(n)]:
-            f.result()
+        nap = 0.05
+        for _ in range(3):  # (on a busy host a process may finish its task before the last fork: again, with longer tasks)
+            for f in [ex.submit(time.sleep, nap) for _ in range(n)]:
+                f.result()
+            if len(getattr(ex, "_processes", None) or range(n)) >= n:
+                break
+            nap *= 3
     except Exception:  # noqa: BLE001  (no pool here is not an error: the loop creates its own)
         ex.shutdown(wait=False, cancel_futures=True)
         return None
