@@ -278,11 +278,8 @@ def run_workload(name, args, rank, world, local):
                                 "frac_of_device_resident": el_dev / el}
             # the reference loop's own call: ONE blocking _torch_predict per batch (predict._hip_predict -> c3_predict, which cuts
             # the batch into chunks that travel through the ring), every piece through the staging buffer: the product's default.
-            # --page-locked-legs adds the same call with the caller's windows page-locked for its duration (c3_model_set_lock_sources, ~2 %
-            # faster) -- NOT part of the default run: on ROCm 7.2 a process that hipHostRegisters / unregisters host ranges and ALSO lets
-            # PyTorch copy from host memory that later occupies those addresses faults the GPU sooner or later
-            # (tests/diag/register_vs_torch_probe.py; round 5's collection lost a --steps 20 run to exactly that: "Memory access fault by GPU"
-            # on a host address), and the bench line must not depend on that lottery
+            # (until round 5 a --page-locked-legs switch timed the same call on hipHostRegister'ed windows; the entries are gone from the ABI,
+            # include/c3hip.h says why)
             xs = np.array(xb, copy=True)
             for _ in range(3):
                 y = model.predict_numpy(xs)
@@ -293,17 +290,6 @@ def run_workload(name, args, rank, world, local):
             hl["batch_1000"]["sync_call"] = {"value": bref * k / el_sync, "ms_per_call": 1e3 * el_sync / k,
                                              "frac_of_device_resident": el_dev / el_sync,
                                              "path": "_hip_predict on the worker's model = c3_predict, every piece through the staging buffer (the default): one blocking call per batch"}
-            if args.page_locked_legs:
-                model.lock_sources(True)
-                for _ in range(3):
-                    y = model.predict_numpy(xs)
-                t0 = time.perf_counter()
-                for _ in range(k):
-                    y = model.predict_numpy(xs)
-                el_lock = time.perf_counter() - t0
-                model.lock_sources(False)
-                hl["batch_1000"]["sync_call"]["windows_page_locked"] = {"value": bref * k / el_lock,
-                                                                        "note": "c3_model_set_lock_sources: the caller's windows page-locked for the duration of the call"}
             del xs
             # what the UNMODIFIED reference loop gets after callvar.install(): its batch generator rebound to
             # worker.lookahead_batches over the tensor FILES of stage A (memory-mapped .npy + .info, batches of 1000 that never
@@ -364,20 +350,6 @@ def run_workload(name, args, rank, world, local):
                 el3, y = host_leg(models, xb, k, 3, slots=2)
                 hl["batch_1000"]["all_handles"] = {"value": bref * k / el3, "ms_per_step": 1e3 * el3 / k, "handles": len(models),
                                                    "slots_in_flight_per_handle": 2}
-            # zero-copy variant (--page-locked-legs only, see above): the source buffer page-locked once (c3_host_register), no staging copy
-            if args.page_locked_legs:
-                try:
-                    from clair3_amd import _lib
-                    xr = np.array(xb, copy=True)
-                    t0 = time.perf_counter()
-                    _lib.host_register(xr)
-                    t_reg = time.perf_counter() - t0
-                    el, y = host_leg(model, xr, k, 3)
-                    _lib.host_unregister(xr)
-                    hl["batch_1000_registered_source"] = {"value": bref * k / el, "ms_per_step": 1e3 * el / k,
-                                                          "register_ms": 1e3 * t_reg, "bytes": int(xr.nbytes)}
-                except Exception as e:  # registration is an optional fast path; never fail the line on it
-                    hl["batch_1000_registered_source"] = {"error": repr(e)}
         res["host_inclusive"] = hl
 
     if args.no_profiled_pass:
@@ -818,8 +790,6 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
-    ap.add_argument("--page-locked-legs", action="store_true", help="also time the blocking call with the caller's windows page-locked and the ring on a "
-                    "registered source buffer (hipHostRegister in a process that also runs PyTorch: off by default, see the comment in run_workload)")
     ap.add_argument("--no-profiled-pass", action="store_true", help="skip the HIP-event pass (for rocprofv3 runs of one leg)")
     ap.add_argument("--no-reference-gpu", action="store_true", help="skip the leg that times the reference's own modules on the GPU through PyTorch-ROCm")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of K steps each; value = the median block")

@@ -19,7 +19,7 @@ DTYPE_I8, DTYPE_I32, DTYPE_F32, DTYPE_I64 = 0, 1, 2, 3
 EXPORTS = (
     "c3_version", "c3_last_error", "c3_device_count", "c3_mem_info", "c3_model_create", "c3_model_set_geometry",
     "c3_model_load", "c3_model_output_size", "c3_model_row_size", "c3_model_set_decode_columns", "c3_model_window_bytes", "c3_predict", "c3_predict_submit", "c3_predict_submit_dev",
-    "c3_predict_wait", "c3_comm_unique_id", "c3_comm_create", "c3_comm_destroy", "c3_gather_rows", "c3_comm_count", "c3_comm_abort", "c3_stream_wait", "c3_model_describe", "c3_model_set_sharing", "c3_model_set_lock_sources", "c3_host_register", "c3_host_unregister", "c3_predict_device", "c3_predict_device_checked", "c3_model_range_status", "c3_predict_pileup_region", "c3_outcome_maxima", "c3_decode_columns", "c3_model_synchronize", "c3_model_destroy", "c3_debug_fetch",
+    "c3_predict_wait", "c3_comm_unique_id", "c3_comm_create", "c3_comm_destroy", "c3_gather_rows", "c3_comm_count", "c3_comm_abort", "c3_stream_wait", "c3_model_describe", "c3_model_set_sharing", "c3_predict_device", "c3_predict_device_checked", "c3_model_range_status", "c3_predict_pileup_region", "c3_outcome_maxima", "c3_decode_columns", "c3_model_synchronize", "c3_model_destroy", "c3_debug_fetch",
     "c3_debug_keep_activations", "c3_profile_enable", "c3_profile_reset", "c3_profile_read",
 )
 
@@ -104,9 +104,6 @@ def lib():
     L.c3_stream_wait.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.c3_model_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.c3_model_set_sharing.argtypes = [C.c_void_p, C.c_int]
-    L.c3_model_set_lock_sources.argtypes = [C.c_void_p, C.c_int]
-    L.c3_host_register.argtypes = [C.c_void_p, C.c_size_t]
-    L.c3_host_unregister.argtypes = [C.c_void_p]
     L.c3_predict_device_checked.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
     L.c3_model_range_status.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.c3_predict_pileup_region.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
@@ -132,16 +129,6 @@ def last_error():
 def check(rc, what):
     if rc != 0:
         raise C3Error(f"{what}: {last_error()}")
-
-
-def host_register(arr):
-    """Page-lock a numpy array for zero-copy H2D (c3_host_register); returns the array for chaining."""
-    check(lib().c3_host_register(arr.ctypes.data, arr.nbytes), "c3_host_register")
-    return arr
-
-
-def host_unregister(arr):
-    check(lib().c3_host_unregister(arr.ctypes.data), "c3_host_unregister")
 
 
 def device_count():

@@ -84,7 +84,9 @@ __device__ __forceinline__ void split2_f16_mix(const f32x4 x, u32x2 (&piece)[2])
 
 // ABL (tools/wino_probe.hip only; 0 in the product): 1 no weight loads, 2 no transform after the first slab of the first tile,
 // 4 no epilogue, 8 no matrix instructions, 32 shader-clock trace of workgroups 0 and 256 (wave 0) at phase boundaries, 16 the transform's loads NOT requested ahead (round-5 first cut: each item's loads issued
-// and waited for at the slab switch).  MIX = false: the transform on plain conversions (the probe checks the two forms agree bit for bit).
+// and waited for at the slab switch), 64 the UPPER BOUND of a split-K launch (round 6): p.tiles is twice the real
+// count, workgroups 2k and 2k + 1 run the same tile on half of its slabs each and both store their (partial) result -- the time of
+// a split-K pair WITHOUT its exchange.  MIX = false: the transform on plain conversions (the probe checks the two forms agree bit for bit).
 //
 // Where the transform's memory latency goes.  A thread owns two items (row r = (tid + 256 it) >> 2 of the 128 V rows, 8-channel group
 // g = tid & 3) per slab.  The 16 buffer loads of BOTH items of the next slab go out right behind the slab's last matrix instruction,
@@ -121,8 +123,10 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
         if (t < 4 * 8) *reinterpret_cast<pl_u32x4 *>(vlds + (t >> 3) * kWPlaneB + T * kWRowB + (t & 7) * 16) = pl_u32x4{z, z, z, z};
     };
 
+    constexpr int SPLIT = (ABL & 64) ? 1 : 0;  // probe only: two workgroups per tile, half the slabs each
+    constexpr int NSL = SPLIT ? NS32 / 2 : NS32;
     int v = blockIdx.x;
-    int tile = xcd_tile_index(v, p.tiles);
+    int tile = xcd_tile_index(v, p.tiles) >> SPLIT;
     const int tn = tile % NS;
     int m0 = (tile / NS) * kWTM;
 
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
         }
         const int vn = v + G;
         const bool more = vn < p.tiles;
-        const int m0n = more ? (xcd_tile_index(vn, p.tiles) / NS) * kWTM : 0;
+        const int m0n = more ? ((xcd_tile_index(vn, p.tiles) >> SPLIT) / NS) * kWTM : 0;
         make_rowinfo(rnext, m0n, more);  // (read from the first slab switch on; a tile has at least two slabs)
 
         f32x16 acc[4][2];
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
         };
 
 #pragma unroll 1
-        for (int s32 = 0; s32 < NS32; ++s32) {
-            const bool last_slab = s32 + 1 == NS32;
+        for (int s32 = 0; s32 < NSL; ++s32) {
+            const bool last_slab = s32 + 1 == NSL;
             frags(0, 0, 0);
 #pragma unroll
             for (int tap = 0; tap < 12; ++tap) {

@@ -1,7 +1,7 @@
 // c3_hostring.h -- the host <-> device side of the model call: c3_predict (the reference's blocking _torch_predict,
 // clair3/CallVariantsFromCffi.py:48-52), its asynchronous pair c3_predict_submit / c3_predict_wait (a ring of C3_HOST_SLOTS
-// batches in flight: staging copy, H2D, kernels, D2H, range guard), the region form of the pileup call, zero-copy sources, and
-// the decoder entry points that take host rows.
+// batches in flight: staging copy, H2D, kernels, D2H, range guard), the region form of the pileup call, and the decoder entry
+// points that take host rows.  The library never page-locks CALLER memory (see stage_h2d).
 #pragma once
 #include "c3_forward.h"
 
@@ -9,19 +9,12 @@
 // The caller's windows are pageable numpy memory (clair3/CallVariantsFromCffi.py:112-133: np.load slices); they go
 // through a pinned buffer, cut into pieces: the H2D transfer of a piece is queued as soon as it is staged, so the DMA of
 // piece i runs under the memcpy of piece i + 1, and every piece's memcpy is split over the staging pool (c3_host.h).
-// Buffers the caller has registered (c3_host_register: page-locked for the device) skip the staging copy altogether.
-struct HostRange {
-    const char *p;
-    size_t n;
-};
-static std::vector<HostRange> g_registered;
-static std::mutex g_registered_mu;
-static bool is_registered(const void *p, size_t n) {
-    std::lock_guard<std::mutex> lk(g_registered_mu);
-    for (const HostRange &r : g_registered)
-        if ((const char *)p >= r.p && (const char *)p + n <= r.p + r.n) return true;
-    return false;
-}
+// There is NO zero-copy source path: until round 5 the ABI could page-lock caller memory (hipHostRegister: c3_host_register,
+// c3_model_set_lock_sources).  On ROCm 7.2 a process that registers / unregisters host ranges and also lets another HIP user (PyTorch)
+// copy from pageable memory takes "Memory access fault by GPU" sooner or later (tests/diag/register_vs_torch_probe.py reproduces it
+// with hipHostRegister and torch alone), and a C ABI cannot know who else lives in its process: the entry points are gone, every
+// caller buffer -- numpy, a memory-mapped tensor file, libclair3's fa_data.matrix -- is staged through the library's own pinned,
+// MADV_DONTFORK memory.  Price: 0.86 instead of 0.88 of the device-resident rate on a blocking call of 1000 full-alignment windows.
 
 // Rows always leave through a copy kernel on the COMPUTE stream (host_copy_kernel writes the pinned, device-mapped result
 // buffer): handing them to a transfer stream -- event, cross-queue wait, DMA copies, event -- cost the compute queue ~75 us per
@@ -47,11 +40,7 @@ __global__ void rows_finite_kernel(const float *y, int64_t n, uint32_t *flag) {
 static unsigned rows_out_grid(size_t bytes) { return (unsigned)std::min<size_t>(256, std::max<size_t>(32, bytes / 4096)); }
 
 // stage [src, src + bytes) through `pin` into `dev` on stream s, piecewise
-static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s, bool src_locked = false) {
-    if (src_locked || is_registered(src, bytes)) {  // zero-copy: the DMA engine reads the caller's pages
-        HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, s));
-        return 0;
-    }
+static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStream_t s) {
     // >= 4 MiB and at most four pieces: every queued transfer costs ~15 us of host time (2 MiB x 8 was slower again)
     const size_t piece = std::max<size_t>((size_t)4 << 20, ((bytes / 4) + 4095) & ~(size_t)4095);
     for (size_t off = 0; off < bytes; off += piece) {
@@ -100,21 +89,17 @@ static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     return 0;
 }
 
-static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked,
-                          float *y_dev_out = nullptr);
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, float *y_dev_out = nullptr);
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot) {
-    return predict_submit(m, x_host, x_dtype, batch, y_host, slot, false);
+    return predict_submit(m, x_host, x_dtype, batch, y_host, slot);
 }
 // the ring with the rows LEFT ON THE DEVICE (a rank of a sharded job: its rows go to the RCCL gather, not to this host): the
 // forward pass writes them straight into the caller's device buffer, only the range flag crosses PCIe
 int c3_predict_submit_dev(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_dev, int slot) {
     if (batch > 0 && !y_dev) return fail("null device buffer");
-    return predict_submit(m, x_host, x_dtype, batch, nullptr, slot, false, y_dev);
+    return predict_submit(m, x_host, x_dtype, batch, nullptr, slot, y_dev);
 }
-// src_locked: the caller (c3_predict) has page-locked x_host for the duration of ITS call -- a private fact of that call, not
-// published in g_registered, so no other thread or handle ever DMAs from pages that are about to be unlocked
-static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, bool src_locked,
-                          float *y_dev_out) {
+static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot, float *y_dev_out) {
     if (!m) return fail("null model");
     if (slot < 0 || slot >= kHostSlots) return fail("slot must be in [0, %d)", kHostSlots);
     if (batch < 0) return fail("negative batch");
@@ -132,7 +117,7 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     // chunk 3.87 M against 3.64 M)
     bool alone = true;
     for (int k = 0; k < kHostSlots; ++k) alone &= !m->slot[k].busy;
-    if (batch > 0 && m->host_copy_kernel && alone && xb <= kcopy_max && yb <= kcopy_max && !src_locked && !is_registered(x_host, xb)) {
+    if (batch > 0 && m->host_copy_kernel && alone && xb <= kcopy_max && yb <= kcopy_max) {
         TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, y_dev_out ? 0 : (yb + 255) & ~(size_t)255));  // (rows that stay on the device need no slot buffers)
         StagePool::get().copy(sl.pin_x, x_host, xb);  // (plain memcpy below 1 MB, split over the helpers above)
         hipLaunchKernelGGL(host_copy_kernel, dim3(128), dim3(256), 0, m->stream, (const uint4 *)sl.pin_x, (uint4 *)sl.dev_x, (xb + 15) / 16,
@@ -151,7 +136,7 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     if (batch > 0) {
         // the slot becomes busy only once everything has been queued: a failure on the way leaves it free
         TRY(ensure_slot(m, sl, xb, y_dev_out ? 0 : yb));  // (rows that stay on the device need no slot buffers)
-        TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream, src_locked));
+        TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream));
         HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
         const bool f16 = m->f16_ok;
@@ -184,7 +169,7 @@ int c3_predict_wait(c3_model *m, int slot) {
         if (sl.used_f16 && *sl.pin_flag != 0) {
             if (m->f16_ok)
                 fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
-            m->f16_ok = false;
+            m->f16_ok = false, m->precision = "fp32-range-guard";
             TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.y_dev_out));
             HIP_TRY(hipStreamSynchronize(m->stream));
         }
@@ -201,7 +186,7 @@ int c3_predict_wait(c3_model *m, int slot) {
         if (bad) {
             if (m->f16_ok)
                 fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
-            m->f16_ok = false;
+            m->f16_ok = false, m->precision = "fp32-range-guard";
             TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.dev_y));
             HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, sl.y_bytes, hipMemcpyDeviceToHost, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
@@ -231,25 +216,8 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
     }
     constexpr int kRing = 3;
     const int64_t wbytes = c3_model_window_bytes(m, x_dtype);
-    // A blocking call cannot hide its staging copy behind a previous batch, and that copy (pageable -> pinned, ~16 GB/s with the
-    // staging pool) is as long as the kernels of a full-alignment batch.  Where the caller allows it (c3_model_set_lock_sources:
-    // see the header for why it is not the default) its pages are page-locked for the duration of the call (~0.1 ms per 24 MB,
-    // hipHostRegister) and the DMA engine reads them directly; otherwise, or if the range cannot be registered, the pieces go
-    // through the staging buffer.
-    const size_t xbytes = (size_t)(batch * wbytes);
-    void *reg_base = nullptr;
-    if (m->lock_sources && xbytes >= ((size_t)4 << 20) && !is_registered(x_host, xbytes)) {
-        const uintptr_t lo = (uintptr_t)x_host & ~(uintptr_t)4095, hi = ((uintptr_t)x_host + xbytes + 4095) & ~(uintptr_t)4095;
-        (void)hipSetDevice(m->device);
-        // read-only first: the device only reads the windows, and a read-only registration is the cheaper one (c3_host_register)
-        if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterReadOnly) == hipSuccess) {
-            reg_base = (void *)lo;
-        } else {
-            (void)hipGetLastError();
-            if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) reg_base = (void *)lo;
-            else (void)hipGetLastError();  // not fatal: staged copy
-        }
-    }
+    // A blocking call cannot hide its FIRST staging copy behind a previous batch (pageable -> pinned, ~16 GB/s with the staging pool);
+    // every later piece's copy and transfer run under the kernels of the piece before it.
     int64_t n_sub = 0, n_done = 0;  // chunks submitted / waited for
     int rc = 0;
     // piece sizes grow threefold from a quarter of the batch (between chunk / 2 and chunk): the kernels start after a SHORT first
@@ -264,8 +232,7 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
         take = std::min(take, max_microbatch(m));
         if (n_sub - n_done == kRing) rc = c3_predict_wait(m, (int)(n_done++ % kRing));
         if (rc == 0)
-            rc = predict_submit(m, (const char *)x_host + off * wbytes, x_dtype, take, y_host + off * m->row, (int)(n_sub % kRing),
-                                reg_base != nullptr);
+            rc = predict_submit(m, (const char *)x_host + off * wbytes, x_dtype, take, y_host + off * m->row, (int)(n_sub % kRing));
         if (rc != 0) break;
         off += take;
         next = std::min(3 * next, 4 * chunk);
@@ -275,7 +242,6 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
         const int r = c3_predict_wait(m, (int)(n_done % kRing));
         if (rc == 0) rc = r;
     }
-    if (reg_base) (void)hipHostUnregister(reg_base);  // every chunk has been waited for: nothing reads the pages any more
     if (!first_error.empty()) g_err = first_error;
     return rc;
 }
@@ -389,36 +355,6 @@ int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *ro
     hipLaunchKernelGGL(outcome_maxima_kernel<true>, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, m->stream, dp);
     HIP_TRY(hipGetLastError());
     TRY(d2h_staged(rows_host, rows, total, m->stream));
-    return 0;
-}
-
-int c3_host_register(void *p, size_t bytes) {
-    if (!p || !bytes) return fail("null buffer");
-    // the device only ever READS a registered source.  Saying so matters for read-only, file-backed mappings (a memory-mapped
-    // tensor file): registered with the default flags their first transfer faults the pages in at 11 GB/s, read-only it runs
-    // at 56 GB/s (tests/diag/register_mmap_probe.py).  Runtimes that do not know the flag get the default registration.
-    if (hipHostRegister(p, bytes, hipHostRegisterReadOnly) != hipSuccess) {
-        (void)hipGetLastError();
-        HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
-    }
-    std::lock_guard<std::mutex> lk(g_registered_mu);
-    g_registered.push_back({(const char *)p, bytes});
-    return 0;
-}
-
-int c3_host_unregister(void *p) {
-    {
-        std::lock_guard<std::mutex> lk(g_registered_mu);
-        bool found = false;
-        for (size_t i = 0; i < g_registered.size(); ++i)
-            if (g_registered[i].p == (const char *)p) {
-                g_registered.erase(g_registered.begin() + i);
-                found = true;
-                break;
-            }
-        if (!found) return fail("buffer was not registered with c3_host_register");
-    }
-    HIP_TRY(hipHostUnregister(p));
     return 0;
 }
 

@@ -162,6 +162,15 @@ struct c3_model {
     uint32_t *range_flag = nullptr;  // device word set by the fp16x3 kernels when an activation nears the fp16 range (c3_gemm.h kF16Range)
     uint32_t *pin_flag = nullptr;    // pinned copy of range_flag for c3_predict_device_checked
     bool f16_ok = true;              // cleared when a batch came back out of range / non-finite (or by C3HIP_FP32=1): every layer then runs its fp32-MFMA form
+    // Precision escalation decided at c3_model_load (pileup only, c3_pack.h lstm_sensitivity): a recurrence whose weights hold an entry of
+    // magnitude >= auto_fp32_at amplifies the 2^-22 of the fp16 piece pairs over its 33 steps beyond north_star's 1e-4 on rare windows
+    // (tests/diag/sensitive_window.py), so such a handle STARTS on the fp32 matrix instructions.  C3HIP_FP32 set (0 or 1) is an explicit
+    // choice and switches the automatism off; C3HIP_AUTO_FP32=<threshold> moves it (0 = never).
+    bool precision_forced = false;   // C3HIP_FP32 was given
+    float auto_fp32_at = 4.0f;
+    float lstm_wmax = 0.f;           // max |w| over W_hh of both LSTMs and W_ih of LSTM2 (what the decision looked at)
+    float lstm_hh_norm = 0.f;        // max abs row sum of W_hh (reported, not decided on: ordinary LSTMs reach ~6)
+    const char *precision = "fp16x3";  // "fp16x3" | "fp32-forced" (C3HIP_FP32=1) | "fp32-auto" (this decision) | "fp32-range-guard"
 
     // ---- switches (README) ----
     bool spp_fused = true;    // PyramidPolling as the epilogue of res3b (c3_conv3.h SPPF; 12 x 5 windows); env C3HIP_SPP_FUSED
@@ -173,7 +182,6 @@ struct c3_model {
     int sharing = 1;          // handles the CALLER says feed this GPU side by side (c3_model_set_sharing): beside other batches the chip is
                               // full, so the recurrences stay on full tiles and the projection launches half as many, twice as long workgroups
     int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
-    bool lock_sources = false;  // c3_model_set_lock_sources: c3_predict may page-lock the caller's windows for the duration of a call
     bool tail_fused = false;  // the split-K sum of L4 inside fc_tail_mfma_kernel (c3_tail.h) instead of its own launch: on for the pileup network (+0.7 %:
                               // 15 partials of 128 features), off for full alignment (-1 %: four branch workgroups re-read 28 partials of 256); env C3HIP_TAIL_FUSED
     int duo = 0;              // a micro-batch as two halves on two streams inside one call (c3_forward.h forward_device); env C3HIP_DUO

@@ -80,7 +80,11 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
         return nullptr;
     }
     if (getenv("C3HIP_KEEP_ACTIVATIONS")) m->keep = true;
-    if (const char *e = getenv("C3HIP_FP32")) m->f16_ok = atoi(e) == 0;  // start on the fp32-MFMA forms (what the range guard falls back to)
+    if (const char *e = getenv("C3HIP_FP32")) {  // an explicit choice: 1 = start on the fp32-MFMA forms (what the range guard falls back to), 0 = fp16x3, no automatism
+        m->f16_ok = atoi(e) == 0, m->precision_forced = true;
+        if (!m->f16_ok) m->precision = "fp32-forced";
+    }
+    if (const char *e = getenv("C3HIP_AUTO_FP32")) m->auto_fp32_at = (float)atof(e);
     if (const char *e = getenv("C3HIP_CONV1_FUSED")) m->conv1_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_WINO")) m->wino = atoi(e);
     if (const char *e = getenv("C3HIP_DUO")) m->duo = atoi(e);
@@ -151,9 +155,19 @@ int c3_model_load(c3_model *m, const c3_tensor_desc *tensors, int n_tensors) {
     }
     size_t expected = 0;
     if (m->kind == C3_KIND_PILEUP) {
+        m->lstm_wmax = m->lstm_hh_norm = 0.f;
         TRY(pack_lstm(m, tm, 0, 128, m->C, 32));
         TRY(pack_lstm(m, tm, 1, 160, 256, 256));
         expected = 16;
+        // precision escalation without a user switch (c3_model.h): decided once per load, from the weights alone
+        if (!m->precision_forced) {
+            const bool up = m->auto_fp32_at > 0.f && m->lstm_wmax >= m->auto_fp32_at;
+            if (up)
+                fprintf(stderr, "libc3hip: LSTM weights reach |w| = %.3g (>= %.3g): this pileup handle runs on the fp32 matrix instructions "
+                                "(C3HIP_FP32=0 keeps the fp16x3 kernels)\n", (double)m->lstm_wmax, (double)m->auto_fp32_at);
+            // (new weights, new decision: a reload also ends what the range guard decided for the weights before)
+            m->f16_ok = !up, m->precision = up ? "fp32-auto" : "fp16x3";
+        }
     } else {
         int cin = m->C;
         if (3 * cin > 32) return fail("full-alignment input_channels %d not supported (3*C must be <= 32)", cin);
@@ -206,7 +220,7 @@ int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64
     HIP_TRY(hipStreamSynchronize(s));
     if (*m->pin_flag) {
         fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
-        m->f16_ok = false;
+        m->f16_ok = false, m->precision = "fp32-range-guard";
         TRY(forward_device(m, s, x_dev, x_dtype, batch, y_dev));
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -231,17 +245,12 @@ int c3_model_set_sharing(c3_model *m, int handles) {
     return 0;
 }
 
-int c3_model_set_lock_sources(c3_model *m, int on) {
-    if (!m) return fail("null model");
-    m->lock_sources = on != 0;
-    return 0;
-}
-
 int c3_model_describe(c3_model *m, char *buf, int n) {
     if (!m || !buf || n <= 0) return fail("null argument");
     if (m->kind == C3_KIND_PILEUP)
-        snprintf(buf, (size_t)n, "sharing=%d duo=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d", m->sharing, m->duo, m->choice_lstm1, m->choice_proj2, m->choice_lstm2,
-                 (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d duo=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d precision=%s lstm_wmax=%.4g lstm_hh_norm=%.4g auto_fp32_at=%.4g", m->sharing,
+                 m->duo, m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok, m->precision, (double)m->lstm_wmax, (double)m->lstm_hh_norm,
+                 (double)(m->precision_forced ? 0.f : m->auto_fp32_at));
     else
         snprintf(buf, (size_t)n, "sharing=%d duo=%d conv_stack=%s stride1=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->duo, m->choice_fa, m->choice_s1,
                  m->choice_s2[0], m->choice_s2[1], (int)!m->f16_ok);

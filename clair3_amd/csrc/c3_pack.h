@@ -158,10 +158,35 @@ static int pack_tail(c3_model *m, const TensorMap &tm, const std::vector<int> *l
 // LSTM layer `layer` (0 = LSTM1: fused projection + recurrence, c3_lstm_fused.h; 1 = LSTM2: hoisted projection on c3_dense.h,
 // recurrence lstm_recurrent_kernel_v2): hidden H, input size `in`, PyTorch gate row order i, f, g, o (gate*H + unit).
 //   LSTM1 whh fragments: [dir][wave][gate][q][lane][e] = W_hh[gate*H + wave*16 + (lane&15)][16q + 4*(lane>>4) + e]
+// What the load-time precision decision looks at (c3_model.h auto_fp32_at): the largest |w| of the recurrent matrices (and of
+// LSTM2's input matrix, whose inputs are LSTM1's bounded outputs; LSTM1's input matrix multiplies raw counts of up to +-100 and is
+// scaled accordingly by training: not comparable) and the largest absolute row sum of W_hh.
+static int lstm_sensitivity(c3_model *m, const TensorMap &tm, const std::string &base, int layer, int H, int in) {
+    for (int dir = 0; dir < 2; ++dir) {
+        const std::string sfx = dir ? "_reverse" : "";
+        const float *wih, *whh;
+        TRY(want(tm, base + ".weight_ih_l0" + sfx, {4 * H, in}, &wih));
+        TRY(want(tm, base + ".weight_hh_l0" + sfx, {4 * H, H}, &whh));
+        for (int r = 0; r < 4 * H; ++r) {
+            double row = 0.0;
+            for (int k = 0; k < H; ++k) {
+                const float a = std::fabs(whh[(size_t)r * H + k]);
+                row += a;
+                if (a > m->lstm_wmax) m->lstm_wmax = a;  // (NaN never compares greater: a NaN weight is the range guard's business)
+            }
+            if ((float)row > m->lstm_hh_norm) m->lstm_hh_norm = (float)row;
+            if (layer == 1)
+                for (int k = 0; k < in; ++k) m->lstm_wmax = std::max(m->lstm_wmax, std::fabs(wih[(size_t)r * in + k]));
+        }
+    }
+    return 0;
+}
+
 static int pack_lstm(c3_model *m, const TensorMap &tm, int layer, int H, int in, int Kp) {
     const bool v2 = layer == 1;
     const std::string base = layer == 0 ? "LSTM1" : "LSTM2";
     const int NW = H / 16, NQ = H / 16;
+    TRY(lstm_sensitivity(m, tm, base, layer, H, in));
     if (v2) {
         // lstm_recurrent_kernel_v2: projection rows in PyTorch order (n = dir*4H + gate*H + unit); W_hh fragments
         // [dir][block = n/16][q][lane][e] = W_hh[block*16 + (lane&15)][16q + 4*(lane>>4) + e]

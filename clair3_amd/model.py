@@ -42,7 +42,6 @@ class _HipModel:
         self._keep = False
         self._geometry = None
         self._decode_cols = False
-        self._lock_sources = False
         if device is not None:
             self.to(device)
 
@@ -64,8 +63,6 @@ class _HipModel:
             _lib.check(_lib.lib().c3_debug_keep_activations(self._handle, 1), "c3_debug_keep_activations")
         if self._decode_cols:
             _lib.check(_lib.lib().c3_model_set_decode_columns(self._handle, 1), "c3_model_set_decode_columns")
-        if self._lock_sources:
-            _lib.check(_lib.lib().c3_model_set_lock_sources(self._handle, 1), "c3_model_set_lock_sources")
         if sd is not None:
             self._load(sd)
         return self
@@ -240,18 +237,10 @@ class _HipModel:
         _lib.check(_lib.lib().c3_model_set_sharing(self._handle, int(handles)), "c3_model_set_sharing")
         return self
 
-    def lock_sources(self, on=True):
-        """Allow the blocking call to page-lock the caller's windows for its duration (c3_model_set_lock_sources: faster, but
-        not for processes that also let PyTorch copy from the same host arrays -- see include/c3hip.h)."""
-        self._lock_sources = bool(on)
-        if self._handle is not None:
-            _lib.check(_lib.lib().c3_model_set_lock_sources(self._handle, int(on)), "c3_model_set_lock_sources")
-        return self
-
     def describe(self):
         """which kernel forms the last forward pass took (c3_model_describe)"""
-        buf = C.create_string_buffer(256)
-        _lib.check(_lib.lib().c3_model_describe(self._handle, buf, 256), "c3_model_describe")
+        buf = C.create_string_buffer(512)
+        _lib.check(_lib.lib().c3_model_describe(self._handle, buf, 512), "c3_model_describe")
         return buf.value.decode()
 
     def range_status(self):

@@ -21,14 +21,6 @@ def _load_torch_checkpoint(model, checkpoint_path, device=None):
     else:
         state_dict = checkpoint
     model.load_state_dict(state_dict)
-    if hasattr(model, "lock_sources"):
-        # OFF unless asked for: every piece of a blocking call goes through the staging buffer.  C3HIP_LOCK_SOURCES=1 lets the
-        # call page-lock the caller's windows for its duration (include/c3hip.h c3_model_set_lock_sources; ~2 % on a blocking call
-        # of 1000 windows) -- safe for the worker's own windows (np.load / the tensor generators: they never meet PyTorch), but a
-        # process that ALSO lets PyTorch copy from the same host arrays faults the GPU on ROCm 7.2, and 2 %
-        # does not pay for that hazard as a default
-        import os
-        model.lock_sources(os.environ.get("C3HIP_LOCK_SOURCES", "0").strip().lower() in ("1", "true", "yes", "on"))
     _register_current(model)
 
 

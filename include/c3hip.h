@@ -102,8 +102,8 @@ int c3_model_row_size(const c3_model *m);
 int64_t c3_model_window_bytes(const c3_model *m, int x_dtype);
 
 /* y_host[batch][24|90 (c3_model_row_size)] = forward(x_host[batch][...]); synchronous.  A batch of two or more chunks (256
- * full-alignment / 4096 pileup windows) travels through slots 0..2 of the submit / wait ring below in growing pieces, from the
- * caller's pages page-locked for the duration of the call: no c3_predict_submit of this handle may be pending on those slots. */
+ * full-alignment / 4096 pileup windows) travels through slots 0..2 of the submit / wait ring below in growing pieces:
+ * no c3_predict_submit of this handle may be pending on those slots. */
 int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host);
 /* Note on the arithmetic: the contractions form their fp32 products from two fp16 pieces per operand (fp16x3, DESIGN.md 1:
  * fp32-level parity).  Should a checkpoint ever drive an activation towards the fp16 range (|x| >= 16000), c3_predict /
@@ -121,15 +121,14 @@ int c3_predict_wait(c3_model *m, int slot);
  * disk (clair3/CallVariantsFromCffiGPU.py:138-199); here they meet on rank 0 over xGMI and cross PCIe once, there.
  * c3_predict_wait(slot) runs the range guard (flag + a device-side scan for non-finite rows) and re-runs on fp32 if needed. */
 int c3_predict_submit_dev(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_dev, int slot);
-/* Optional zero-copy input: page-lock a host range the caller will feed windows from -- a whole np.load'ed
- * tensor file, or libclair3's fa_data.matrix buffer (preprocess/CreateTensorFullAlignmentFromCffi.py:136-168) -- so that
- * c3_predict / c3_predict_submit on any sub-range of it DMA straight from the caller's pages instead of staging through the
- * library's pinned buffer.  A registered source must stay unmodified until the matching c3_predict_wait returns (an
- * unregistered one may be reused as soon as submit returns).  Unregister before freeing the memory.  The range may be a
- * read-only, file-backed mapping (a memory-mapped tensor file: the DMA engine then reads the page cache); the device never writes
- * to a registered range. */
-int c3_host_register(void *host_ptr, size_t bytes);
-int c3_host_unregister(void *host_ptr);
+/* There is deliberately NO entry that page-locks caller memory.  Rounds 3-5 exported c3_host_register /
+ * c3_host_unregister / c3_model_set_lock_sources (hipHostRegister on a whole np.load'ed tensor file or on libclair3's
+ * fa_data.matrix buffer, preprocess/CreateTensorFullAlignmentFromCffi.py:136-168).  On ROCm 7.2 a process that registers and
+ * unregisters host ranges while ANOTHER HIP user in it (PyTorch) copies from pageable memory dies with "Memory access fault
+ * by GPU" sooner or later (tests/diag/register_vs_torch_probe.py shows it with hipHostRegister and torch alone), and a C ABI
+ * cannot see who shares its process: the entries were retired in round 6.  A foreign buffer -- numpy, a memory-mapped tensor
+ * file, libclair3's matrix -- is handed to c3_predict / c3_predict_submit as it is and staged through the library's own
+ * pinned memory (kept out of forked children); x_host may be reused as soon as the call returns. */
 /* device-resident forward: x_dev / y_dev are device pointers on the model's device, stream is a
  * hipStream_t (NULL = the HIP null stream, i.e. PyTorch's default stream).  Asynchronous with respect to the
  * host; ordered like any other work on that stream.  Calls on one handle must not overlap each other (one
@@ -202,16 +201,6 @@ int c3_stream_wait(void *stream, int device, int timeout_ms);
  * kernels follow it (alone: 8-window LSTM tiles and 240 projection workgroups so that a 1024-window batch reaches every CU;
  * sharing: 16-window tiles and 120 workgroups, because the other batches fill the rest).  Rows are bit-identical either way. */
 int c3_model_set_sharing(c3_model *m, int handles);
-/* May the blocking c3_predict page-lock the CALLER's windows for the duration of a call (hipHostRegister around a batch of
- * >= 4 MB that is cut into pieces: the DMA engine then reads the caller's pages instead of a staged copy -- 0.88 instead of
- * 0.86 of the device-resident rate for 1000 full-alignment windows, and no host core busy copying)?  Off by default, because of what the ROCm 7.2 runtime
- * does and not of anything in this library: a process that ALSO lets PyTorch copy from the same host array
- * (torch.from_numpy(x).cuda()) and registers / unregisters sub-ranges of it gets "Memory access fault by GPU" sooner or
- * later (tests/diag/register_vs_torch_probe.py reproduces it with hipHostRegister and torch alone).  The reference's worker
- * never hands its windows to PyTorch once callvar.install() is active, so the rebound loader
- * (clair3_amd.predict._load_torch_checkpoint) switches it on for the worker's model.  The same care applies to
- * c3_host_register. */
-int c3_model_set_lock_sources(c3_model *m, int on);
 /* which kernel forms the handle's last forward pass took, as "key=value ..." text; bench.py reports it next to its rates */
 int c3_model_describe(c3_model *m, char *buf, int buf_bytes);
 /* blocks until everything enqueued on the model's own stream has finished */

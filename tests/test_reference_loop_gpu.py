@@ -152,7 +152,7 @@ def test_unmodified_worker_command_on_libc3hip(name, ref, jobs):
 
 def test_blocking_calls_without_the_lookahead_generator(ref, jobs):
     """C3HIP_PREFETCH_DEPTH=0: the reference's own generator and one blocking c3_predict per batch (chunks through the ring, every
-    piece through the staging buffer: page-locking the batch for the call is off unless C3HIP_LOCK_SOURCES=1 says otherwise) -- same VCF"""
+    piece through the staging buffer) -- same VCF"""
     job = jobs("full_alignment")
     got = os.path.join(job["dir"], "hip_blocking.vcf")
     rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, False, True, hip=True, extra_env={"C3HIP_PREFETCH_DEPTH": "0"})

@@ -139,8 +139,10 @@ def test_batches_equal_the_reference_generator(tmp_path):
 def test_windows_fed_straight_from_a_foreign_buffer(tmp_path):
     """SURVEY 8f N2 remainder: libclair3 hands its tensors over as one calloc'ed int8 block (`fa_data.matrix`,
     preprocess/CreateTensorFullAlignmentFromCffi.py:136-168, src/clair3_full_alignment_dwell.h:184-190) that the reference
-    copies into numpy before anything else.  The C ABI takes the block as it is: page-lock it once (c3_host_register) and submit
-    sub-ranges of it -- no numpy copy, no staging copy.  Rows against the oracle, registered == unregistered bit for bit."""
+    copies into numpy before anything else.  The C ABI takes the block as it is -- plain malloc'ed memory the library has never
+    seen, no numpy copy: sub-ranges of it are submitted straight through the C ABI and staged by the library (nothing page-locks
+    caller memory since round 6, include/c3hip.h).  The block may be reused as soon as submit returns: it is overwritten before the
+    waits.  Rows against the oracle and against the numpy path bit for bit; the retired entries are not exported any more."""
     import ctypes as C
     from clair3_amd import _lib
     from clair3_amd.model import Clair3_F
@@ -157,16 +159,16 @@ def test_windows_fed_straight_from_a_foreign_buffer(tmp_path):
     block = libc.calloc(n * wbytes, 1)  # what calculate_clair3_full_alignment returns in fa_data.matrix
     C.memmove(block, x.ctypes.data, n * wbytes)
     L = _lib.lib()
-    _lib.check(L.c3_host_register(C.c_void_p(block), n * wbytes), "c3_host_register")
+    for gone in ("c3_host_register", "c3_host_unregister", "c3_model_set_lock_sources"):
+        assert not hasattr(C.CDLL(_lib.LIB_PATH), gone), gone
     y = np.empty((n, 90), np.float32)
     cuts = [0, 64, 65, 150]  # the reference's batches are slices of the block
     for k, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
         _lib.check(L.c3_predict_submit(m._handle, C.c_void_p(block + lo * wbytes), _lib.DTYPE_I8, hi - lo,
                                        C.c_void_p(y.ctypes.data + lo * 90 * 4), k), "c3_predict_submit")
+    C.memset(block, 0x55, n * wbytes)  # "x_host may be reused as soon as submit returns"
     for k in range(3):
         _lib.check(L.c3_predict_wait(m._handle, k), "c3_predict_wait")
-    assert util.assert_rows_match(y, oracle.fa_forward(sd, x, True), what="rows from the registered block") < 2e-5
-    assert np.array_equal(y, m.predict_numpy(x))
-    _lib.check(L.c3_host_unregister(C.c_void_p(block)), "c3_host_unregister")
-    assert L.c3_host_unregister(C.c_void_p(block)) != 0  # second time: not registered any more
     libc.free(block)
+    assert util.assert_rows_match(y, oracle.fa_forward(sd, x, True), what="rows from the foreign block") < 2e-5
+    assert np.array_equal(y, m.predict_numpy(x))

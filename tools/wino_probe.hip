@@ -48,7 +48,7 @@ template <int C, bool RES, int ABL, int RT = 2, int WD = 4> static void launch_w
     hipLaunchKernelGGL((conv3x3_wino16_planes_kernel<C, RES, ABL, RT, WD>), dim3(grid), dim3(kPlThreads), 0, 0, wp);
 }
 
-template <int C> static int shape(const char *name, int B, int H, int W, int cus, bool timing) {
+template <int C> static int shape(const char *name, int B, int H, int W, int cus, bool timing, bool split_only = false) {
     constexpr int NS = C / 64, NS32 = C / 32;
     const int M = B * H * W, Hj = (H + 1) / 2, Mp = B * Hj * W;
     const size_t bytes = (size_t)M * C * 4;
@@ -215,7 +215,20 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
     printf("  vs fp64 host on %d sampled outputs: direct %.3e  wino %.3e;  words differing between the two transform forms: %zu\n", samples + 4, ed, ew, mixdiff);
     printf("  wino16 (LDS-DMA, 16-channel slabs) against wino: %zu values differ, max |difference| %.3e\n", w16diff, w16max);
     printf("  wino16 with 64-row tiles against wino: %zu values differ, max |difference| %.3e\n", s16diff, s16max);
-    if (timing) {
+    if (timing && split_only) {
+        // split-K over the input channels for the launches that leave workgroup slots empty at B = 256.  ABL 64 runs every
+        // tile as TWO workgroups on half of the slabs each, with no exchange of the partial sums: an upper bound of what the real thing
+        // (partial tile through L2 / memory, second half adds and runs the epilogue) could gain.
+        WinoConvParams w2 = wp;
+        w2.tiles = 2 * wp.tiles;
+        const int g2 = grid_for(w2.tiles, 2 * cus);
+        for (int rep = 0; rep < 3; ++rep) {
+            printf("  wino full                    %6.1f us  (%d tiles, grid %d)\n", time_it([&] { launch_w<C, true, 0>(wp, gw); }), wp.tiles, gw);
+            printf("  wino split-K bound           %6.1f us  (%d half tiles, grid %d; no exchange)\n", time_it([&] { launch_w<C, true, 64>(w2, g2); }), w2.tiles, g2);
+            printf("  wino split-K, no epilogue    %6.1f us\n", time_it([&] { launch_w<C, true, 64 | 4>(w2, g2); }));
+            printf("  direct full                  %6.1f us  (%d tiles, grid %d)\n", time_it([&] { hipLaunchKernelGGL((conv3x3_planes_kernel<C, true>), dim3(gd), dim3(kPlThreads), 0, 0, cp); }), cp.tiles, gd);
+        }
+    } else if (timing) {
         const double mfd = 2.0 * tiles_m * kPlBM * (double)C * 9.0 * C * 3, mfw = 2.0 * tiles_w * kWRows * (double)C * 12.0 * C * 3;
         printf("  executed matrix work: direct %.1f GFLOP (%.1f us at 2500 TF), wino %.1f GFLOP (%.1f us)\n", mfd / 1e9, mfd / 2500e6, mfw / 1e9, mfw / 2500e6);
         printf("  direct full                  %6.1f us\n", time_it([&] { hipLaunchKernelGGL((conv3x3_planes_kernel<C, true>), dim3(gd), dim3(kPlThreads), 0, 0, cp); }));
@@ -298,6 +311,11 @@ int main(int argc, char **argv) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    if (argc > 1 && !strcmp(argv[1], "split")) {  // round 6: what a split-K launch of the under-filled layers could take at most (no exchange)
+        if (shape<256>("res3 split-K bound", 256, 12, 5, cus, true, true)) return 1;
+        if (shape<128>("res2 split-K bound", 256, 23, 9, cus, true, true)) return 1;
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "big")) {  // the counter passes of tools/wino_pmc.sh: the two res2 batches only
         if (shape<128>("res2", 256, 23, 9, cus, true)) return 1;
         if (shape<128>("res2 B=1000", 1000, 23, 9, cus, true)) return 1;
