@@ -748,6 +748,9 @@ def short_line(full, names, full_path):
     return line
 
 
+PLACEMENT = {}  # dist.pin_to_device_numa's report of this rank (N > 1), printed in the full record
+
+
 def self_launch(n):
     """`python bench.py --gpus N` typed plainly, N > 1: no torchrun environment around this process, so it starts its own N
     ranks -- exactly the command the module docstring names (one process per GPU, rendezvous on 127.0.0.1 at a free port) with
@@ -810,6 +813,19 @@ def main():
         sys.exit(self_launch(args.gpus))
 
     from clair3_amd import dist as c3dist
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("C3_BENCH_DEVICE"):
+        # preflight of a rank (the driver's torch.distributed.run launch; self_launch checks before it starts anything): one process per
+        # GPU needs that many devices -- say so in one sentence and stop with rc 2 instead of a traceback out of set_device per rank
+        from clair3_amd import _lib
+        lrank = int(os.environ.get("LOCAL_RANK", "0"))
+        err = c3dist.preflight(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])), _lib.device_count(), lrank)
+        if err:
+            if lrank == 0:
+                print(f"[bench] {err}", file=sys.stderr)
+            sys.exit(2)
+        # every rank's host side on the NUMA node of its GPU, before the runtime and the library start their threads (N > 1 only: the
+        # one-GPU line keeps the whole host for its cpu_baseline leg)
+        PLACEMENT.update(c3dist.pin_to_device_numa(lrank))
     rank, world, local = c3dist.init_from_env()
     if world != args.gpus:
         if rank == 0:
@@ -862,6 +878,8 @@ def main():
         }
         for n in names[1:]:
             full[n] = sub_line(n, results[n], args.cpu_budget / 2 if n == "pileup" else 0)
+        if world > 1:
+            full["placement_rank0"] = PLACEMENT  # dist.pin_to_device_numa: which NUMA node / how many CPUs rank 0's host side got
         # everything measured goes to a file; stdout carries ONE short line the driver can parse (round 3's 21 KB line could not be)
         full_path = os.environ.get("C3_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
         try:

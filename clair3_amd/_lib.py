@@ -17,7 +17,7 @@ DTYPE_I8, DTYPE_I32, DTYPE_F32, DTYPE_I64 = 0, 1, 2, 3
 
 # every symbol include/c3hip.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = (
-    "c3_version", "c3_last_error", "c3_device_count", "c3_mem_info", "c3_model_create", "c3_model_set_geometry",
+    "c3_version", "c3_last_error", "c3_device_count", "c3_mem_info", "c3_device_pci_bus_id", "c3_model_create", "c3_model_set_geometry",
     "c3_model_load", "c3_model_output_size", "c3_model_row_size", "c3_model_set_decode_columns", "c3_model_window_bytes", "c3_predict", "c3_predict_submit", "c3_predict_submit_dev",
     "c3_predict_wait", "c3_comm_unique_id", "c3_comm_create", "c3_comm_destroy", "c3_gather_rows", "c3_comm_count", "c3_comm_abort", "c3_stream_wait", "c3_model_describe", "c3_model_set_sharing", "c3_predict_device", "c3_predict_device_checked", "c3_model_range_status", "c3_predict_pileup_region", "c3_outcome_maxima", "c3_decode_columns", "c3_model_synchronize", "c3_model_destroy", "c3_debug_fetch",
     "c3_debug_keep_activations", "c3_profile_enable", "c3_profile_reset", "c3_profile_read",
@@ -80,6 +80,7 @@ def lib():
     L.c3_last_error.restype = C.c_char_p
     L.c3_device_count.restype = C.c_int
     L.c3_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.c3_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.c3_model_create.restype = C.c_void_p
     L.c3_model_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.c3_model_set_geometry.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -136,6 +137,13 @@ def device_count():
     if n < 0:
         raise C3Error(f"c3_device_count: {last_error()}")
     return n
+
+
+def pci_bus_id(device=0):
+    """PCI address of a visible device as sysfs spells it (c3_device_pci_bus_id)."""
+    buf = C.create_string_buffer(32)
+    check(lib().c3_device_pci_bus_id(int(device), buf, 32), "c3_device_pci_bus_id")
+    return buf.value.decode()
 
 
 def mem_info(device=0):

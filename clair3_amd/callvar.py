@@ -47,6 +47,7 @@ def _select_device_for_worker(use_gpu):
 # args.cpu_threads)` (:302).  Any other request (another size, other arguments, a second pool) gets an ordinary executor.
 # C3HIP_PREFORK_POOL=0 leaves the loop's pool alone.
 _PREFORKED = None  # (executor, max_workers) waiting for the loop to ask for it
+PLACEMENT = None  # what dist.pin_to_device_numa did for this worker (a dict), once _select_device has run on the GPU branch
 
 
 def _cpu_threads_from_argv(default=4):
@@ -117,6 +118,13 @@ def _make_pool_factory(original):
 
 def _select_device_for_cffi_worker(use_gpu):
     """_select_device of the stage-B worker: on the GPU branch the decode pool is forked first (see above)."""
+    if use_gpu:
+        # the worker on the NUMA node of ITS GPU -- the reference has just set CUDA_VISIBLE_DEVICES to --gpu_id
+        # (clair3/CallVariantsFromCffi.py:216), so ordinal 0 is that device -- from sysfs alone (no HIP call yet) and BEFORE the pool is
+        # forked: the decode processes and the library's staging threads inherit the placement (C3HIP_NUMA_PIN=0 = off)
+        global PLACEMENT
+        from . import dist as c3dist
+        PLACEMENT = c3dist.pin_to_device_numa(0, use_hip=False)
     if use_gpu and _PREFORKED is None and os.environ.get("C3HIP_PREFORK_POOL", "1").strip().lower() not in ("0", "false", "no", "off"):
         _prefork_decode_pool(_cpu_threads_from_argv())
     return _select_device_for_worker(use_gpu)

@@ -36,6 +36,13 @@ int c3_mem_info(int device, size_t *free_bytes, size_t *total_bytes) {
     return 0;
 }
 
+int c3_device_pci_bus_id(int device, char *buf, int buf_bytes) {
+    if (!buf || buf_bytes < 16) return fail("c3_device_pci_bus_id: buffer of at least 16 bytes needed");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, buf_bytes, device));
+    for (char *c = buf; *c; ++c) *c = (char)tolower((unsigned char)*c);  // sysfs spells the address in lower case
+    return 0;
+}
+
 c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int device) {
     if (kind != C3_KIND_PILEUP && kind != C3_KIND_FULL_ALIGNMENT) {
         fail("unknown model kind %d", kind);

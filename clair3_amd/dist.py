@@ -20,6 +20,164 @@ def shard_range(n_windows, rank, world_size):
     return start, start + base + (1 if rank < extra else 0)
 
 
+# ---------------------------------------------------------------------------------------------- placement of a rank's host side
+# The reference starts one worker process per GPU slot with GNU parallel and leaves CPU placement to the OS
+# (clair3/CallVariantsFromCffiGPU.py:138-156).  On an 8-GPU node the host side of a rank -- the staging copies into pinned memory,
+# the forked decode workers that read the rows -- wants the NUMA node its GPU hangs off (SURVEY 8e names it as a scaling limiter).
+# Everything here reads sysfs and the environment only, so it is testable without a GPU (tests/test_dist_cpu.py).
+
+def visible_device_ids(env=None):
+    """The physical device ids behind the ordinals 0..n-1 this process sees, or None when no variable restricts them.
+    HIP honours ROCR_VISIBLE_DEVICES (runtime level) and then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (HIP level, indices into
+    what ROCR left visible): the composition of the two lists is what a LOCAL_RANK indexes into."""
+    env = os.environ if env is None else env
+
+    def ids(name):
+        v = env.get(name)
+        if v is None or v.strip() == "":
+            return None
+        out = []
+        for t in v.split(","):
+            t = t.strip()
+            if not t.lstrip("-").isdigit() or int(t) < 0:  # HIP stops at the first entry it cannot use (UUIDs are not handled here)
+                break
+            out.append(int(t))
+        return out
+
+    rocr = ids("ROCR_VISIBLE_DEVICES")
+    hip = ids("HIP_VISIBLE_DEVICES")
+    if hip is None:
+        hip = ids("CUDA_VISIBLE_DEVICES")
+    if rocr is None:
+        return hip
+    if hip is None:
+        return rocr
+    return [rocr[i] for i in hip if i < len(rocr)]
+
+
+def device_for_local_rank(local_rank, n_visible, env=None):
+    """(ordinal, physical id) of the device rank `local_rank` of this node uses: ordinal = LOCAL_RANK (one process per GPU, the
+    launcher's numbering), physical = what that ordinal means under the *_VISIBLE_DEVICES permutation in force -- the id the
+    reference's --gpu_id / physical device lists speak (clair3/CallVariantsFromCffiGPU.py:45-73).  Raises ValueError with one clear
+    sentence when the node does not show that many devices."""
+    local_rank, n_visible = int(local_rank), int(n_visible)
+    if not 0 <= local_rank < n_visible:
+        raise ValueError(f"LOCAL_RANK {local_rank} needs device ordinal {local_rank}, but this process sees {n_visible} HIP device(s)"
+                         " (check --nproc-per-node against the node and *_VISIBLE_DEVICES)")
+    vis = visible_device_ids(env)
+    if vis is None:
+        return local_rank, local_rank
+    if local_rank >= len(vis):
+        raise ValueError(f"LOCAL_RANK {local_rank} is beyond the {len(vis)} device(s) *_VISIBLE_DEVICES names")
+    return local_rank, vis[local_rank]
+
+
+def preflight(n_ranks_on_node, n_visible, local_rank=0):
+    """None if `n_ranks_on_node` ranks fit the devices this process sees, else ONE sentence for stderr (bench.py --gpus N exits 2
+    with it before any rendezvous; only local rank 0 prints)."""
+    if n_visible >= n_ranks_on_node:
+        return None
+    return (f"{n_ranks_on_node} ranks on this node but only {n_visible} HIP device(s) visible: one process per GPU is the contract "
+            f"(local rank {local_rank} stops here)")
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def numa_cpus_of_pci(pci_bus_id, sysfs="/sys"):
+    """(node, cpus) of the NUMA node a PCI device hangs off: /sys/bus/pci/devices/<id>/numa_node and
+    /sys/devices/system/node/node<N>/cpulist; (-1, empty set) when the platform does not say (one-socket boxes, VMs)."""
+    try:
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", pci_bus_id, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return -1, set()
+    if node < 0:
+        return -1, set()
+    try:
+        cpus = _parse_cpulist(open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")).read())
+    except (OSError, ValueError):
+        return node, set()
+    return node, cpus
+
+
+def pci_bus_id_from_kfd(physical_id, sysfs="/sys"):
+    """PCI address of the physical_id-th GPU in the order the runtime enumerates them (the kfd topology's GPU nodes), read from
+    sysfs alone: NO HIP call, so a worker can place itself before it forks its decode pool and before the runtime starts
+    (clair3_amd/callvar.py: a fork behind HIP's initialisation stalls the device, profiles/r05_l_fork_stall.txt).  None if the
+    topology is not there."""
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    try:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
+        return None
+    gpus = []
+    for n in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(base, str(n), "properties")).read().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue  # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        except (OSError, KeyError, ValueError):
+            continue
+        gpus.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}")
+    return gpus[physical_id] if 0 <= physical_id < len(gpus) else None
+
+
+def pin_to_device_numa(device, sysfs="/sys", pci_bus_id=None, setaffinity=None, getaffinity=None, use_hip=True):
+    """Restrict THIS process (and everything it starts afterwards: the library's staging threads are created on the first staged
+    copy, the decode pool is forked by the loop) to the CPUs of the NUMA node of HIP device ordinal `device`.  Never widens the
+    set the process already has (cgroup / taskset), never leaves it empty, C3HIP_NUMA_PIN=0 switches it off.  Returns a dict that
+    says what happened (job.py / bench.py put it in their reports)."""
+    info = {"device": int(device), "pinned": False}
+    if os.environ.get("C3HIP_NUMA_PIN", "1").strip().lower() in ("0", "false", "no", "off"):
+        info["why"] = "C3HIP_NUMA_PIN=0"
+        return info
+    setaffinity = setaffinity or getattr(os, "sched_setaffinity", None)
+    getaffinity = getaffinity or getattr(os, "sched_getaffinity", None)
+    if setaffinity is None or getaffinity is None:
+        info["why"] = "no sched_setaffinity on this platform"
+        return info
+    if pci_bus_id is None:  # sysfs first (no HIP call: see pci_bus_id_from_kfd), the runtime's own answer second
+        vis = visible_device_ids()
+        physical = vis[device] if vis is not None and 0 <= int(device) < len(vis) else int(device)
+        pci_bus_id = pci_bus_id_from_kfd(physical, sysfs)
+        info["pci_from"] = "kfd topology"
+    if pci_bus_id is None and use_hip:
+        try:
+            from . import _lib
+            pci_bus_id = _lib.pci_bus_id(device)
+            info["pci_from"] = "c3_device_pci_bus_id"
+        except Exception as e:  # no device, no library: placement is an optimisation, never an error
+            info["why"] = f"no PCI address ({e})"
+            return info
+    if pci_bus_id is None:
+        info["why"] = "no PCI address (no kfd topology in sysfs)"
+        return info
+    node, cpus = numa_cpus_of_pci(pci_bus_id, sysfs)
+    info.update(pci=pci_bus_id, numa_node=node)
+    have = set(getaffinity(0))
+    want = cpus & have
+    if node < 0 or not cpus:
+        info["why"] = "the platform names no NUMA node for the device"
+    elif not want:
+        info["why"] = "none of the node's CPUs is in this process's allowed set"
+    elif want == have:
+        info["why"] = "already inside the node"
+        info["cpus"] = len(have)
+    else:
+        setaffinity(0, want)
+        info.update(pinned=True, cpus=len(want), of=len(have))
+    return info
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank); a no-op for a single process."""

@@ -152,6 +152,10 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
 
     m0 = model[0] if isinstance(model, (list, tuple)) else model
     on_gpu = False
+    # the rank's host side (staging copies, whatever `consume` forks) on the NUMA node of its GPU -- before the first staged copy
+    # creates the library's helper threads; a stand-in model (CPU tests) has no device to ask about
+    placement = c3dist.pin_to_device_numa(int(getattr(m0, "_device", 0) or 0)) if getattr(m0, "_handle", None) is not None else None
+    t_setup = time.perf_counter()
     if world > 1 or comm is not None:
         import torch
     device = comm.device if comm is not None else (exchange.device if exchange is not None else int(getattr(m0, "_device", 0) or 0))
@@ -169,6 +173,9 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
     keep_on_device = (rows_on_device and consume is None and hasattr(m0, "submit_dev") and not isinstance(model, (list, tuple))
                       and same_device)
     t0 = time.perf_counter()
+    # (making the exchange -- RCCL rendezvous, ncclCommInitRank, up to the gather timeout -- happens before t0: reported on its own
+    # and counted in total_s, so that a job's wall time does not get better by what moved in front of the compute phase)
+    exchange_setup_s = t0 - t_setup
     y_dev = None
     if keep_on_device:
         y_dev = torch.empty((per_rank[rank], int(m0.row_size)), dtype=torch.float32, device=f"cuda:{device}")
@@ -194,11 +201,14 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
     assert n_done == per_rank[rank], (n_done, per_rank, rank)
     y_local = np.concatenate(rows) if rows else None
     out = {"rank": rank, "windows_local": n_done, "compute_s": t_compute, "segments_local": len(mine), "per_rank": per_rank,
-           "files_local": len({f for f, _, _ in mine}), "rows_path": "device" if keep_on_device else "host"}
+           "files_local": len({f for f, _, _ in mine}), "rows_path": "device" if keep_on_device else "host",
+           "exchange_setup_s": exchange_setup_s}
+    if placement is not None:
+        out["placement"] = placement
     if world == 1:
         if y_dev is not None:  # a one-rank job handed a communicator: the rows took the device path, one copy brings them home
             y_local = y_dev.cpu().numpy()
-        out.update(rows=y_local, positions=positions, gather_s=0.0, total_s=time.perf_counter() - t0, gather="single")
+        out.update(rows=y_local, positions=positions, gather_s=0.0, total_s=time.perf_counter() - t_setup, gather="single")
         return out
     # the row width follows from the model; a stand-in without row_size (tests) asks the other ranks.  EVERY rank takes part,
     # each with the width it knows (0 if none): a conditional collective deadlocks the ranks that skip it
@@ -221,7 +231,7 @@ def run_job(model, list_fn, rank=0, world=1, batch_size=1000, comm=None, consume
     if y_t.is_cuda:
         torch.cuda.synchronize(device)
     y_all = got.cpu().numpy() if got is not None else None
-    out.update(gather_s=time.perf_counter() - t1, total_s=time.perf_counter() - t0,
+    out.update(gather_s=time.perf_counter() - t1, total_s=time.perf_counter() - t_setup,
                gather="rccl_direct" if comm is not None else exchange.mode)
     if exchange is not None:
         out.update(exchange.report())

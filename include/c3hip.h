@@ -72,6 +72,11 @@ const char *c3_last_error(void);
 /* number of visible HIP devices (honours HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES); <0 on error */
 int c3_device_count(void);
 int c3_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
+/* PCI address of a visible device as sysfs spells it ("0000:c5:00.0"): /sys/bus/pci/devices/<address>/numa_node is the NUMA
+ * node the host side of a rank -- staging copies, the forked decode workers -- belongs on (clair3_amd/dist.py pin_to_device_numa).
+ * The reference starts one worker process per GPU slot and leaves placement to the OS (clair3/CallVariantsFromCffiGPU.py:138-156,
+ * parallel -j); SURVEY 8e names NUMA placement as a limiter of the 1 -> 8 GPU scaling. */
+int c3_device_pci_bus_id(int device, char *buf, int buf_bytes);
 
 /* kind: C3_KIND_*; in_channels: 18 (pileup) / 8 or 9 (full alignment, 9 = dwell time);
  * add_indel_length: 0 -> (B,24) output, 1 -> (B,90).  Returns NULL on failure. */

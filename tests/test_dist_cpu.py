@@ -189,3 +189,104 @@ def test_row_exchange_falls_back_together(tmp_path):
     assert _run_exchange(tmp_path, "rccl_sees_one_rank") == (("torch_fallback", 1, True), "torch_fallback")
     assert _run_exchange(tmp_path, "first_gather_times_out_on_rank_0") == (("torch_fallback", 2, True), "torch_fallback")
     assert _run_exchange(tmp_path, "unique_id_fails_on_rank_0") == (("torch_fallback", 1, True), "torch_fallback")
+
+
+# ---------------------------------------------------------------------------------------------- placement of a rank
+def test_local_rank_to_device_under_visible_devices_permutations():
+    """LOCAL_RANK is the device ORDINAL (one process per GPU); the physical id behind it follows the *_VISIBLE_DEVICES permutation in
+    force -- what the reference's --gpu_id lists speak (clair3/CallVariantsFromCffiGPU.py:45-73, CallVariantsFromCffi.py:216)"""
+    from clair3_amd import dist as d
+    assert d.visible_device_ids({}) is None
+    assert d.device_for_local_rank(3, 8, {}) == (3, 3)
+    env = {"HIP_VISIBLE_DEVICES": "7,6,5,4,3,2,1,0"}
+    assert [d.device_for_local_rank(r, 8, env) for r in range(8)] == [(r, 7 - r) for r in range(8)]
+    assert d.device_for_local_rank(1, 2, {"CUDA_VISIBLE_DEVICES": "5,2"}) == (1, 2)
+    assert d.device_for_local_rank(0, 1, {"HIP_VISIBLE_DEVICES": "4", "CUDA_VISIBLE_DEVICES": "6"}) == (0, 4)  # HIP's own variable wins
+    # ROCR_VISIBLE_DEVICES restricts first, the HIP-level list indexes into what it left
+    assert d.visible_device_ids({"ROCR_VISIBLE_DEVICES": "2,3,6,7", "HIP_VISIBLE_DEVICES": "3,0"}) == [7, 2]
+    assert d.visible_device_ids({"ROCR_VISIBLE_DEVICES": "4,5"}) == [4, 5]
+    assert d.visible_device_ids({"HIP_VISIBLE_DEVICES": "1,-1,3"}) == [1]  # the runtime stops at the first entry it cannot use
+    assert d.visible_device_ids({"HIP_VISIBLE_DEVICES": ""}) is None
+    import pytest
+    with pytest.raises(ValueError, match="sees 4 HIP device"):
+        d.device_for_local_rank(4, 4, {})
+    with pytest.raises(ValueError, match="beyond the 2 device"):
+        d.device_for_local_rank(2, 8, {"HIP_VISIBLE_DEVICES": "0,1"})
+    assert d.preflight(8, 8) is None and d.preflight(1, 8) is None
+    assert "8 ranks on this node but only 1 HIP device(s) visible" in d.preflight(8, 1, 3)
+
+
+def _fake_sysfs(root, gpus, nodes):
+    """gpus: [(domain, bus, dev, fn, numa_node)] in runtime order; nodes: {node: cpulist text}"""
+    topo = os.path.join(root, "class/kfd/kfd/topology/nodes")
+    os.makedirs(os.path.join(topo, "0"))
+    open(os.path.join(topo, "0", "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")  # a CPU node
+    for i, (dom, bus, dev, fn, numa) in enumerate(gpus):
+        os.makedirs(os.path.join(topo, str(i + 1)))
+        open(os.path.join(topo, str(i + 1), "properties"), "w").write(
+            f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {(bus << 8) | (dev << 3) | fn}\ndomain {dom}\n")
+        pci = os.path.join(root, "bus/pci/devices", f"{dom:04x}:{bus:02x}:{dev:02x}.{fn:x}")
+        os.makedirs(pci)
+        open(os.path.join(pci, "numa_node"), "w").write(f"{numa}\n")
+    for node, cpus in nodes.items():
+        os.makedirs(os.path.join(root, "devices/system/node", f"node{node}"))
+        open(os.path.join(root, "devices/system/node", f"node{node}", "cpulist"), "w").write(cpus + "\n")
+
+
+def test_a_rank_is_pinned_to_the_numa_node_of_its_gpu(tmp_path, monkeypatch):
+    """dist.pin_to_device_numa on a made-up sysfs tree: PCI address from the kfd topology (no HIP call), numa_node and cpulist from
+    sysfs, the affinity narrowed to node CPUs the process is allowed -- never widened, never emptied, C3HIP_NUMA_PIN=0 = off"""
+    from clair3_amd import dist as d
+    root = str(tmp_path)
+    _fake_sysfs(root, [(0, 0x05, 0, 0, 0), (0, 0x15, 0, 0, 0), (0, 0x85, 0, 0, 1), (0x1, 0xc5, 0x1f, 7, 1), (0, 0xe5, 0, 0, -1)],
+                {0: "0-31,64-95", 1: "32-63,96-127"})
+    monkeypatch.delenv("C3HIP_NUMA_PIN", raising=False)
+    for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert d.pci_bus_id_from_kfd(0, root) == "0000:05:00.0" and d.pci_bus_id_from_kfd(3, root) == "0001:c5:1f.7"
+    assert d.pci_bus_id_from_kfd(5, root) is None and d.pci_bus_id_from_kfd(0, os.path.join(root, "nope")) is None
+    assert d.numa_cpus_of_pci("0000:85:00.0", root) == (1, set(range(32, 64)) | set(range(96, 128)))
+    state = {"aff": set(range(128))}
+    kw = dict(sysfs=root, use_hip=False, setaffinity=lambda pid, cpus: state.update(aff=set(cpus)), getaffinity=lambda pid: set(state["aff"]))
+    r = d.pin_to_device_numa(2, **kw)
+    assert r["pinned"] and r["numa_node"] == 1 and r["cpus"] == 64 and r["of"] == 128 and r["pci"] == "0000:85:00.0" and r["pci_from"] == "kfd topology"
+    assert state["aff"] == set(range(32, 64)) | set(range(96, 128))
+    r = d.pin_to_device_numa(3, **kw)  # the same node again: nothing to do
+    assert not r["pinned"] and r["why"] == "already inside the node"
+    r = d.pin_to_device_numa(0, **kw)  # node 0 has no CPU this process may use any more: left alone
+    assert not r["pinned"] and "allowed set" in r["why"] and len(state["aff"]) == 64
+    # a cgroup that allows eight CPUs of node 0: the intersection, not the node
+    state["aff"] = set(range(4, 12))
+    assert not d.pin_to_device_numa(1, **kw)["pinned"] and state["aff"] == set(range(4, 12))  # all eight are node 0's: already inside
+    state["aff"] = set(range(28, 36))
+    r = d.pin_to_device_numa(1, **kw)
+    assert r["pinned"] and state["aff"] == {28, 29, 30, 31} and r["of"] == 8
+    # a platform that names no node; the ordinal under a permutation; the switch
+    state["aff"] = set(range(128))
+    assert d.pin_to_device_numa(4, **kw)["why"].startswith("the platform names no NUMA node") and len(state["aff"]) == 128
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    r = d.pin_to_device_numa(0, **kw)  # ordinal 0 = physical 2
+    assert r["pinned"] and r["pci"] == "0000:85:00.0" and r["numa_node"] == 1
+    monkeypatch.setenv("C3HIP_NUMA_PIN", "0")
+    state["aff"] = set(range(128))
+    assert d.pin_to_device_numa(1, **kw) == {"device": 1, "pinned": False, "why": "C3HIP_NUMA_PIN=0"} and len(state["aff"]) == 128
+    monkeypatch.delenv("C3HIP_NUMA_PIN")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert "no PCI address" in d.pin_to_device_numa(0, sysfs=os.path.join(root, "nope"), use_hip=False, setaffinity=kw["setaffinity"], getaffinity=kw["getaffinity"])["why"]
+
+
+def test_bench_rank_preflight_says_one_sentence_and_exits_2(tmp_path):
+    """`bench.py --gpus 4` launched as ranks (the driver's torch.distributed.run command) on a host that shows fewer devices: one
+    clear sentence from local rank 0 and rc 2 from every rank, before any rendezvous -- here: zero devices, no launcher needed"""
+    env = dict(os.environ, WORLD_SIZE="4", LOCAL_WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("C3_BENCH_DEVICE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    if "HIP device(s) visible" not in r.stderr:  # (a host WITH four or more GPUs cannot show this)
+        import pytest
+        pytest.skip("this host has the devices")
+    assert r.returncode == 2 and r.stdout.strip() == "" and "4 ranks on this node but only 0 HIP device(s) visible" in r.stderr, (r.returncode, r.stderr[-500:])
+    env["LOCAL_RANK"] = env["RANK"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "HIP device(s) visible" not in r.stderr  # only local rank 0 speaks

@@ -40,6 +40,13 @@ def main():
     from clair3_amd import dist as c3dist, job, synthetic as syn
     from clair3_amd.model import Clair3_F, Clair3_P
     rank, world, local = c3dist.init_from_env(backend="gloo" if os.environ.get("C3_JOB_GLOO") else None)
+    n_vis = torch.cuda.device_count()
+    err = c3dist.preflight(int(os.environ.get("LOCAL_WORLD_SIZE", world)), n_vis, local)
+    if err:
+        if local == 0:
+            print(f"[wgs_job] {err}", file=sys.stderr)
+        sys.exit(2)
+    c3dist.pin_to_device_numa(local)  # this rank's staging threads on its GPU's NUMA node (before the first staged copy)
     torch.cuda.set_device(local)
     exchange = c3dist.RowExchange(rank, world, device=local)  # RCCL directly; torch.distributed if that does not come up
     base = args.dir or tempfile.mkdtemp(prefix="c3_wgs_job_")
