@@ -259,6 +259,11 @@ def run_workload(name, args, rank, world, local):
         assert y.shape == (batch, 90 if indel else 24) and np.isfinite(y).all()
         hl.update({"value": batch * hsteps / el, "ms_per_step": 1e3 * el / hsteps, "batch": batch, "steps": hsteps,
                    "frac_of_device_resident_one_in_flight": (batch * hsteps / el) / res["one_batch_in_flight"]["value"]})
+        # the same ring over EXACTLY the driver's --steps / --warmup (the figure above runs >= 100 steps, outside the
+        # driver's consistency check): filling and draining three slots is part of these few steps
+        el_d, _ = host_leg(model, x_host, args.steps, args.warmup)
+        hl["at_driver_steps"] = {"value": batch * args.steps / el_d, "ms_per_step": 1e3 * el_d / max(args.steps, 1), "steps": args.steps,
+                                 "warmup": args.warmup}
         if not args.batch:
             bref = 1000  # the reference's GPU batch (CallVariantsFromCffi.py:265-269: predictBatchSize * 5)
             xb = syn.make_windows(kind, bref, seed=2000, channels=channels)
@@ -416,7 +421,12 @@ def run_workload(name, args, rank, world, local):
         "share_of_step_time": share,
         "kernel_us_per_step": fam_us,  # the dominant family's share of the free-running step: <= ms_per_step of one batch in flight
         "step_us_one_batch_in_flight": step_us,
+        # the RAW event-based figures next to the share-based ones (a share of the free-running step also carries that step's
+        # launch gaps): the family's bracketed launch durations as measured, and the fraction they give -- comparable with round 4's lines
         "events": {"family_us_per_step": 1e3 * ms / max(args.steps, 1), "all_kernels_us_per_step": 1e3 * step_ms_profiled,
+                   "achieved": (fl_step / (1e3 * ms / max(args.steps, 1)) / 1e6) if ms > 0 else None,
+                   "frac": (fl_step / (1e3 * ms / max(args.steps, 1)) / 1e6 / peak) if ms > 0 else None,
+                   "avg_launch_us": 1e3 * ms / max(launches, 1),
                    "note": "raw HIP-event sums of the profiled pass (every launch bracketed): longer than the free-running step"},
         "kernel_variants": describe(model),
         "whole_network_frac": whole_one, "whole_network_achieved": whole_one * peak,
@@ -434,7 +444,11 @@ def run_workload(name, args, rank, world, local):
 def family_time(family_event_ms, all_kernels_event_ms, step_us):
     """(share, microseconds per step) of a kernel family: its share of the event-bracketed kernel time of the profiled pass,
     applied to the FREE-RUNNING step -- never longer than the step it is a part of (tests/test_bench_line.py)."""
-    share = min(1.0, family_event_ms / max(all_kernels_event_ms, 1e-12))
+    # the family's launches are a subset of the launches of the pass: a share above one means the profile is inconsistent (a family
+    # counted twice, a stale record) and is an error, not something to clamp (ADVICE r5)
+    if family_event_ms > all_kernels_event_ms * (1.0 + 1e-9):
+        raise ValueError(f"inconsistent profile: the family's bracketed time {family_event_ms} exceeds that of all kernels {all_kernels_event_ms}")
+    share = family_event_ms / max(all_kernels_event_ms, 1e-12)
     return share, share * step_us
 
 
@@ -653,6 +667,9 @@ def short_line(full, names, full_path):
             return None
         out = {k: _r(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_util", "traffic",
                                          "avg_launch_us", "launches", "kernel_us_per_step", "step_us_one_batch_in_flight")}
+        ev = r.get("events") or {}
+        if ev.get("frac") is not None:  # the raw event-bracketed launch durations and the fraction they give (the share-based one is `frac`)
+            out["events"] = {"family_us_per_step": _r(ev.get("family_us_per_step")), "frac": _r(ev.get("frac")), "avg_launch_us": _r(ev.get("avg_launch_us"))}
         out["whole_network_frac"] = _r(r.get("whole_network_frac", r.get("whole_forward_frac_one_in_flight")))
         out["fabric_frac_of_hbm_peak"] = _r(r.get("fabric_frac_of_hbm_peak", r.get("hbm_frac")))
         out["kernel"] = "Clair3_F 3x3 convolution launches (fa.conv* / fa.res*)" if "convolution" in r.get("kernel", "") else \
@@ -680,7 +697,9 @@ def short_line(full, names, full_path):
         if not hl:
             return None
         out = {"value": _r(hl["value"]), "unit": "candidate-windows/s", "batch": hl["batch"], "slots_in_flight": hl["slots_in_flight"],
-               "frac_of_device_resident": _r(hl["frac_of_device_resident_one_in_flight"])}
+               "frac_of_device_resident": _r(hl["frac_of_device_resident_one_in_flight"]), "steps": hl.get("steps")}
+        if hl.get("at_driver_steps"):
+            out["at_driver_steps"] = {"value": _r(hl["at_driver_steps"]["value"]), "steps": hl["at_driver_steps"]["steps"]}
         b = hl.get("batch_1000")
         if b:
             out["batch_1000"] = {"ring": _r(b["value"]), "device_resident": _r(b["device_resident_one_in_flight"]),

@@ -19,9 +19,17 @@ DTYPE_I8, DTYPE_I32, DTYPE_F32, DTYPE_I64 = 0, 1, 2, 3
 EXPORTS = (
     "c3_version", "c3_last_error", "c3_device_count", "c3_mem_info", "c3_device_pci_bus_id", "c3_model_create", "c3_model_set_geometry",
     "c3_model_load", "c3_model_output_size", "c3_model_row_size", "c3_model_set_decode_columns", "c3_model_window_bytes", "c3_predict", "c3_predict_submit", "c3_predict_submit_dev",
-    "c3_predict_wait", "c3_comm_unique_id", "c3_comm_create", "c3_comm_destroy", "c3_gather_rows", "c3_comm_count", "c3_comm_abort", "c3_stream_wait", "c3_model_describe", "c3_model_set_sharing", "c3_predict_device", "c3_predict_device_checked", "c3_model_range_status", "c3_predict_pileup_region", "c3_outcome_maxima", "c3_decode_columns", "c3_model_synchronize", "c3_model_destroy", "c3_debug_fetch",
+    "c3_predict_wait", "c3_comm_unique_id", "c3_comm_create", "c3_comm_destroy", "c3_gather_rows", "c3_comm_count", "c3_comm_abort", "c3_stream_wait", "c3_model_describe", "c3_model_set_sharing", "c3_predict_device", "c3_predict_device_checked", "c3_model_range_status", "c3_predict_pileup_region", "c3_outcome_maxima", "c3_decode_columns", "c3_vcf_rows", "c3_model_synchronize", "c3_model_destroy", "c3_debug_fetch",
     "c3_debug_keep_activations", "c3_profile_enable", "c3_profile_reset", "c3_profile_read",
 )
+
+
+class RowsConfig(C.Structure):
+    """c3_rows_config (include/c3hip.h)"""
+    _fields_ = [("width", C.c_int32), ("flank", C.c_int32), ("show_reference", C.c_int32), ("keep_iupac", C.c_int32),
+                ("has_qs_pass", C.c_int32), ("pileup", C.c_int32), ("max_len", C.c_int32), ("infer", C.c_int32),
+                ("f32_arith", C.c_int32), ("walk", C.c_int32), ("qs_pass", C.c_double), ("phred_trans", C.c_double),
+                ("gt", (C.c_char * 8) * 4)]
 
 
 class TensorDesc(C.Structure):
@@ -80,6 +88,8 @@ def lib():
     L.c3_last_error.restype = C.c_char_p
     L.c3_device_count.restype = C.c_int
     L.c3_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.c3_vcf_rows.argtypes = [C.POINTER(RowsConfig), C.c_int64, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                              C.c_void_p, C.c_void_p]
     L.c3_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.c3_model_create.restype = C.c_void_p
     L.c3_model_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]

@@ -47,18 +47,28 @@ def _select_device_for_worker(use_gpu):
 # args.cpu_threads)` (:302).  Any other request (another size, other arguments, a second pool) gets an ordinary executor.
 # C3HIP_PREFORK_POOL=0 leaves the loop's pool alone.
 _PREFORKED = None  # (executor, max_workers) waiting for the loop to ask for it
+STATS = {"prefork_mismatch": 0}  # pools forked ahead with a size the loop did not ask for
 PLACEMENT = None  # what dist.pin_to_device_numa did for this worker (a dict), once _select_device has run on the GPU branch
 
 
 def _cpu_threads_from_argv(default=4):
-    """--cpu_threads of the worker command line (clair3/CallVariantsFromCffi.py:569, default 4)"""
+    """--cpu_threads of the worker command line (clair3/CallVariantsFromCffi.py:569, default 4).  C3HIP_DECODE_PROCS (set by a
+    launcher that knows better than the command line, or by a programmatic caller of call_variants_from_cffi) wins; on the command
+    line argparse's unambiguous prefixes of --cpu_threads are recognised too (--cpu_t 8, --cpu_threads=8): the worker has no
+    other option that starts with --cpu."""
+    env = os.environ.get("C3HIP_DECODE_PROCS", "").strip()
+    if env.isdigit() and int(env) > 0:
+        return int(env)
     argv = sys.argv
     for i, a in enumerate(argv):
+        name, eq, value = a.partition("=")
+        if not (name.startswith("--cpu") and "--cpu_threads".startswith(name)):
+            continue
         try:
-            if a == "--cpu_threads" and i + 1 < len(argv):
+            if eq:
+                return int(value)
+            if i + 1 < len(argv):
                 return int(argv[i + 1])
-            if a.startswith("--cpu_threads="):
-                return int(a.split("=", 1)[1])
         except ValueError:
             return default
     return default
@@ -109,6 +119,11 @@ def _make_pool_factory(original):
         if pre is not None:
             if max_workers == pre[1] and not args and not kwargs:
                 return pre[0]
+            # the size guessed from the command line is not the size the loop asks for: the idle processes are dropped and the loop
+            # forks its own pool behind the first model call (the ~0.3 s stall this was meant to remove) -- said once, on stderr
+            print(f"[clair3_amd] the decode pool forked ahead has {pre[1]} processes, the loop asks for {max_workers}: dropped "
+                  f"(set C3HIP_DECODE_PROCS={max_workers} to fork the right size ahead, C3HIP_PREFORK_POOL=0 to fork none)", file=sys.stderr)
+            STATS["prefork_mismatch"] += 1
             pre[0].shutdown(wait=False, cancel_futures=True)
         return original(max_workers, *args, **kwargs)
 

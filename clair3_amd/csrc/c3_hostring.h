@@ -57,15 +57,16 @@ extern "C" {
 // eight forks 155 -> 97 ms, profiles/r05_k_host_loop_feeder_not_kept.txt).
 static int ensure_slot(c3_model *m, HostSlot &sl, size_t xb, size_t yb) {
     // host_copy_kernel moves whole 16-byte pieces ((bytes + 15) / 16 of them): every buffer it touches is sized to a multiple of
-    // 256 bytes here, for every path (90-column rows of an odd batch, 121-float decoder rows: yb % 16 != 0)
-    xb = (xb + 255) & ~(size_t)255, yb = (yb + 255) & ~(size_t)255;
+    // 256 bytes here, for every path (90-column rows of an odd batch, 121-float decoder rows: yb % 16 != 0) -- and to whole pages, so that
+    // the pinned halves can be kept out of forked children page by page (keep_out_of_children)
+    xb = (xb + 4095) & ~(size_t)4095, yb = (yb + 4095) & ~(size_t)4095;
     if (!sl.ev_h2d) {
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
     }
     if (!sl.pin_flag) {
-        HIP_TRY(hipHostMalloc((void **)&sl.pin_flag, 64, hipHostMallocDefault));
-        keep_out_of_children(sl.pin_flag, 64);
+        HIP_TRY(hipHostMalloc((void **)&sl.pin_flag, 4096, hipHostMallocDefault));  // (a whole page: MADV_DONTFORK works on pages)
+        keep_out_of_children(sl.pin_flag, 4096);
     }
     if (xb > sl.cap_x) {
         if (sl.pin_x) (void)hipHostFree(sl.pin_x);

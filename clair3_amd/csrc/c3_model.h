@@ -13,9 +13,11 @@
 // one fp32-MFMA form that the range guard falls back to (and that C3HIP_FP32=1 selects from the start).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <errno.h>
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -289,36 +291,59 @@ static int dev_alloc(c3_model *m, void **p, size_t bytes) {
 // (clair3/CallVariantsFromCffi.py:302): with the weights uploaded from the state dict's pageable arrays that fork cost ~0.3 s of
 // every run of the loop (tests/diag/fork_stall.py: first call after the forks 320 ms, then 2.8 ms).  So every such copy goes through
 // ONE pinned bounce buffer that forked children do not inherit.
+// Handles must not be used in a forked child: their pinned buffers are not there (MADV_DONTFORK) and a touch faults.
 static void keep_out_of_children(void *p, size_t bytes) {  // (what ibv_fork_init does for RDMA buffers; a child could not use the handle anyway)
-    if (p && bytes) (void)madvise(p, (bytes + 4095) & ~(size_t)4095, MADV_DONTFORK);
+    if (!p || !bytes) return;
+    // madvise works on whole pages: every caller allocates page-multiples with hipHostMalloc (page-aligned, page-exclusive); anything
+    // else would take a neighbour's bytes out of the children too, so it is refused here and said once
+    static std::atomic<bool> said{false};
+    if (((uintptr_t)p & 4095) != 0 || (bytes & 4095) != 0) {
+        if (!said.exchange(true)) fprintf(stderr, "libc3hip: a pinned buffer of %zu bytes at %p is not page-granular: left visible to forked children\n", bytes, p);
+        return;
+    }
+    if (madvise(p, bytes, MADV_DONTFORK) != 0 && !said.exchange(true))
+        fprintf(stderr, "libc3hip: madvise(MADV_DONTFORK) failed (%s): pinned staging memory stays visible to forked children (a fork then stalls the device longer)\n", strerror(errno));
 }
+// One bounce buffer PER DEVICE, each with its own lock (round 5 had one for the process: weight uploads, c3_outcome_maxima and
+// c3_decode_columns of handles on different GPUs serialised on it), portable (usable by every device's copies whatever device was
+// current when it was made), in two halves: the host memcpy of chunk i + 1 runs under the DMA of chunk i.
 struct BounceBuf {
-    static constexpr size_t kBytes = (size_t)8 << 20;
+    static constexpr size_t kBytes = (size_t)8 << 20, kHalf = kBytes / 2;
     std::mutex mu;
     void *pin = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
 };
 static BounceBuf &bounce_buf() {
-    static BounceBuf *b = new BounceBuf;  // never destroyed (handles may outlive static destruction at exit)
-    return *b;
+    constexpr int kMaxDev = 64;
+    static BounceBuf *b = new BounceBuf[kMaxDev];  // never destroyed (handles may outlive static destruction at exit)
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) d = 0;
+    return b[d];
 }
 static int bounce_ready(BounceBuf &b) {
     if (!b.pin) {
-        HIP_TRY(hipHostMalloc(&b.pin, BounceBuf::kBytes, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&b.pin, BounceBuf::kBytes, hipHostMallocPortable));
         keep_out_of_children(b.pin, BounceBuf::kBytes);
+        for (hipEvent_t &e : b.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     return 0;
 }
-// dev[0, bytes) = src[0, bytes): synchronous (src may be reused on return); s orders the copy behind the stream's work
+// dev[0, bytes) = src[0, bytes): synchronous (src may be reused on return); s orders the copy behind the stream's work.  The device
+// whose buffer is used is the CURRENT one: every caller has made the handle's device current (hipSetDevice) before it gets here.
 static int h2d_staged(void *dev, const void *src, size_t bytes, hipStream_t s = nullptr) {
     BounceBuf &b = bounce_buf();
     std::lock_guard<std::mutex> lk(b.mu);
     TRY(bounce_ready(b));
-    for (size_t off = 0; off < bytes; off += BounceBuf::kBytes) {
-        const size_t n = std::min(BounceBuf::kBytes, bytes - off);
-        memcpy(b.pin, (const char *)src + off, n);
-        HIP_TRY(hipMemcpyAsync((char *)dev + off, b.pin, n, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
+    int i = 0;
+    for (size_t off = 0; off < bytes; off += BounceBuf::kHalf, ++i) {
+        const size_t n = std::min(BounceBuf::kHalf, bytes - off);
+        char *half = (char *)b.pin + (i & 1) * BounceBuf::kHalf;
+        if (i >= 2) HIP_TRY(hipEventSynchronize(b.ev[i & 1]));  // the DMA that read this half two chunks ago
+        memcpy(half, (const char *)src + off, n);
+        HIP_TRY(hipMemcpyAsync((char *)dev + off, half, n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(b.ev[i & 1], s));
     }
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 // dst[0, bytes) = dev[0, bytes) behind the stream's work: synchronous
@@ -326,11 +351,22 @@ static int d2h_staged(void *dst, const void *dev, size_t bytes, hipStream_t s = 
     BounceBuf &b = bounce_buf();
     std::lock_guard<std::mutex> lk(b.mu);
     TRY(bounce_ready(b));
-    for (size_t off = 0; off < bytes; off += BounceBuf::kBytes) {
-        const size_t n = std::min(BounceBuf::kBytes, bytes - off);
-        HIP_TRY(hipMemcpyAsync(b.pin, (const char *)dev + off, n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        memcpy((char *)dst + off, b.pin, n);
+    int i = 0;
+    size_t prev_off = 0, prev_n = 0;
+    for (size_t off = 0; off < bytes; off += BounceBuf::kHalf, ++i) {
+        const size_t n = std::min(BounceBuf::kHalf, bytes - off);
+        char *half = (char *)b.pin + (i & 1) * BounceBuf::kHalf;
+        HIP_TRY(hipMemcpyAsync(half, (const char *)dev + off, n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(b.ev[i & 1], s));
+        if (i >= 1) {  // chunk i - 1 leaves the other half while chunk i arrives
+            HIP_TRY(hipEventSynchronize(b.ev[(i - 1) & 1]));
+            memcpy((char *)dst + prev_off, (char *)b.pin + ((i - 1) & 1) * BounceBuf::kHalf, prev_n);
+        }
+        prev_off = off, prev_n = n;
+    }
+    if (i >= 1) {
+        HIP_TRY(hipEventSynchronize(b.ev[(i - 1) & 1]));
+        memcpy((char *)dst + prev_off, (char *)b.pin + ((i - 1) & 1) * BounceBuf::kHalf, prev_n);
     }
     return 0;
 }

@@ -6,6 +6,7 @@
 #include "c3_hostring.h"
 #include "c3_comm.h"
 #include "c3_debug.h"
+#include "c3_rows.h"
 
 extern "C" {
 
@@ -217,8 +218,8 @@ int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64
     TRY(forward_device(m, s, x_dev, x_dtype, batch, y_dev));
     if (!f16 || batch == 0) return 0;
     if (!m->pin_flag) {
-        HIP_TRY(hipHostMalloc((void **)&m->pin_flag, 64, hipHostMallocDefault));
-        keep_out_of_children(m->pin_flag, 64);
+        HIP_TRY(hipHostMalloc((void **)&m->pin_flag, 4096, hipHostMallocDefault));  // (a whole page: MADV_DONTFORK works on pages)
+        keep_out_of_children(m->pin_flag, 4096);
     }
     const int64_t nf = batch * m->row;
     hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, y_dev, nf, m->range_flag);

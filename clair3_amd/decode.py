@@ -319,28 +319,26 @@ def install_decoder():
         if printer.usable:
             # rows whose first decision stands are printed from the columns (vcf_rows.py); every other row goes through the
             # reference's own output_with, on the look-alike lists when the rows carry indel lengths
-            from .vcf_rows import FALLBACK
-            texts = printer.rows(batch_chr_pos_seq, alt_info_list, batch_Y)
             cum = cv.param.label_shape_cum
             if output_config.add_indel_length:
                 cur.base = batch_Y.__array_interface__["data"][0]
                 cur.stride = batch_Y.strides[0]
                 cur.nbytes = cur.stride * len(batch_Y)
                 cur.cols = batch_Y[:, width:]
+            def print_with_reference(i):
+                y = batch_Y[i]
+                p1, p2 = (y[cum[1]:cum[2]], y[cum[2]:cum[3]]) if output_config.add_indel_length else (0, 0)
+                return cv.output_with(batch_chr_pos_seq[i], alt_info_list[i], y[:cum[0]], y[cum[0]:cum[1]], p1, p2, output_config, output_utilities)
+
             try:
-                out = []
-                for i, text in enumerate(texts):
-                    if text is FALLBACK:
-                        y = batch_Y[i]
-                        p1, p2 = (y[cum[1]:cum[2]], y[cum[2]:cum[3]]) if output_config.add_indel_length else (0, 0)
-                        text = cv.output_with(batch_chr_pos_seq[i], alt_info_list[i], y[:cum[0]], y[cum[0]:cum[1]], p1, p2,
-                                              output_config, output_utilities)
-                    if text is not None:
-                        if args is not None:
-                            args.output_file.write(text)
-                        else:
-                            out.append(text)
-                return "".join(out)
+                # one string for the batch (vcf_rows.RowPrinter.batch_text: the rows c3_vcf_rows printed are never cut into per-row
+                # strings), written once -- the reference writes row by row to the same file object, in the same order
+                text = printer.batch_text(batch_chr_pos_seq, alt_info_list, batch_Y, print_with_reference)
+                if args is not None:
+                    if text:
+                        args.output_file.write(text)
+                    return ""
+                return text
             finally:
                 cur.cols = None
         if not output_config.add_indel_length:

@@ -87,6 +87,31 @@ def _text(x):
     return x
 
 
+def _bytes(x):
+    """chr_pos_seq / alt_info as bytes for the C pass (the same three kinds _text accepts)"""
+    if type(x) == np.memmap:
+        return bytes(x[0])
+    if type(x) == np.bytes_ or type(x) == bytes:
+        return bytes(x)
+    return x.encode()
+
+
+def _joined(texts, n):
+    """the first n texts NUL-separated as bytes: one join when they are all str or all bytes (what a worker's lists are), else per item"""
+    seq = texts if len(texts) == n and type(texts) is list else [texts[i] for i in range(n)]
+    if n and type(seq[0]) is str:
+        try:
+            return "\0".join(seq).encode()
+        except TypeError:
+            pass
+    elif n and type(seq[0]) is bytes:
+        try:
+            return b"\0".join(seq)
+        except TypeError:
+            pass
+    return b"\0".join([_bytes(x) for x in seq])
+
+
 class _Lookups:
     """The allele lookups of one row: the reference's own functions on the row's alt_info dictionary, each distinct question
     asked once (they depend on the dictionary and a length / a base only, and a row that rejects many candidates asks the
@@ -136,7 +161,116 @@ class RowPrinter:
         self.info = "P" if c.pileup else "F"
         self.max_len = cv.VariantLength.max
         self.taken = self.retried = self.handed_back = 0  # rows printed here / of those after rejections / rows left to output_with
+        self.by_c = 0  # rows whose text came from the one-pass C printer (c3_vcf_rows)
         self._dead_cache = {}
+        self._c = self._c_config() if self.usable else None
+
+    # ------------------------------------------------------------------------------------------------ the one-pass C printer
+    def _c_config(self):
+        """c3_rows_config for libc3hip's c3_vcf_rows (csrc/c3_rows.h: the common rows of a batch printed in one pass of plain host
+        code), or None when the library is not there / C3HIP_ROWS_C=0 / a constant of the reference is not what the C side was
+        written for -- the per-row Python below then prints every row, as it did until round 5."""
+        import os
+        if os.environ.get("C3HIP_ROWS_C", "1").strip().lower() in ("0", "false", "no", "off"):
+            return None
+        try:
+            from . import _lib
+            L = _lib.lib()
+        except Exception:
+            return None
+        cv, c = self.cv, self.cfg
+        if self.max_len != dec.MAX_LEN or list(cv.HOMO_SNP_LABELS) != ["AA", "CC", "GG", "TT"] or \
+                list(cv.HETERO_SNP_LABELS) != ["AC", "AG", "AT", "CG", "CT", "GT"] or any(len(g) > 7 for g in self.gt + [self.gt_multi]):
+            return None
+        qs = c.quality_score_for_pass
+        if qs is not None and not isinstance(qs, (int, float)):
+            return None
+        cf = _lib.RowsConfig()
+        cf.width, cf.flank, cf.show_reference, cf.keep_iupac = self.width, int(self.flank), int(bool(c.is_show_reference)), int(bool(c.keep_iupac_bases))
+        cf.has_qs_pass, cf.qs_pass = int(qs is not None), float(qs if qs is not None else 0.0)
+        cf.pileup, cf.max_len, cf.infer = int(bool(c.pileup)), int(self.max_len), int(c.maximum_variant_length_that_need_infer)
+        cf.phred_trans = float(cv.Phred_Trans)
+        # quality_score_from (:375-381) computes (1.0 - p) on a numpy float32 scalar: float32 arithmetic under numpy >= 2, double before
+        cf.f32_arith = int((1.0 - np.float32(0.25)).dtype == np.float32)
+        cf.walk = int(os.environ.get("C3HIP_ROWS_C_WALK", "1").strip().lower() not in ("0", "false", "no", "off"))
+        for k, g in enumerate(self.gt + [self.gt_multi]):
+            cf.gt[k].value = g.encode()
+        self._lib = L
+        return cf
+
+    def _c_pass(self, batch_chr_pos_seq, alt_info_list, batch_Y):
+        """One call of c3_vcf_rows over the batch -> (text of all printed rows in row order, offsets (n + 1), status (n)) or None when
+        the pass could not run at all."""
+        n = len(batch_chr_pos_seq)
+        y = batch_Y
+        if not (isinstance(y, np.ndarray) and y.dtype == np.float32 and y.ndim == 2 and y.strides[1] == 4 and y.strides[0] % 4 == 0
+                and len(alt_info_list) >= n):
+            return None
+        try:
+            pos_b = _joined(batch_chr_pos_seq, n)
+            alt_b = _joined(alt_info_list, n)
+        except (TypeError, AttributeError, UnicodeError):
+            return None
+        if pos_b.count(b"\0") != n - 1 or alt_b.count(b"\0") != n - 1:
+            return None  # a NUL inside a text: not this path's business
+        cap = 192 * n + 2 * (len(pos_b) + len(alt_b)) + 4096  # (a row is its contig, two alleles out of its alt_info and ~60 bytes of fields)
+        out = np.empty(cap, np.uint8)
+        off = np.empty(n + 1, np.int64)
+        status = np.empty(n, np.uint8)
+        rc = self._lib.c3_vcf_rows(self._c, n, pos_b, len(pos_b), alt_b, len(alt_b), y.ctypes.data, y.strides[0] // 4, out.ctypes.data, cap,
+                                   off.ctypes.data, status.ctypes.data)
+        if rc != 0:
+            return None
+        return out[: int(off[n])].tobytes().decode("ascii"), off, status
+
+    def _rows_c(self, batch_chr_pos_seq, alt_info_list, batch_Y):
+        """-> (texts, todo): texts[i] = the row's text / None (prints nothing) where the C pass printed it, todo = the rows it handed
+        back; None when the pass could not run at all."""
+        got = self._c_pass(batch_chr_pos_seq, alt_info_list, batch_Y)
+        if got is None:
+            return None
+        text, off, status = got
+        n = len(status)
+        o = off.tolist()
+        st = status.tolist()
+        texts = [None] * n
+        todo = []
+        for i in range(n):
+            if st[i] == 1:
+                todo.append(i)
+            elif o[i + 1] > o[i]:
+                texts[i] = text[o[i]:o[i + 1]]
+        self.retried += st.count(2)
+        return texts, todo
+
+    def batch_text(self, batch_chr_pos_seq, alt_info_list, batch_Y, print_with_reference):
+        """The VCF text of the whole batch as ONE string, rows in order: the slice of the C pass's buffer between two rows it handed
+        back is taken as it is (no per-row strings), handed-back rows go through the per-row path, and what that leaves
+        (FALLBACK) through ``print_with_reference(i)`` (the reference's own output_with).  What batch_output writes."""
+        n = len(batch_chr_pos_seq)
+        got = self._c_pass(batch_chr_pos_seq, alt_info_list, batch_Y) if self._c is not None and n else None
+        if got is None:
+            texts = self._rows_py(batch_chr_pos_seq, alt_info_list, batch_Y)
+            parts = [print_with_reference(i) if t is FALLBACK else t for i, t in enumerate(texts)]
+            return "".join([t for t in parts if t is not None])
+        text, off, status = got
+        todo = np.flatnonzero(status == 1)
+        self.retried += int(np.count_nonzero(status == 2))
+        self.by_c += n - len(todo)
+        self.taken += n - len(todo)
+        if len(todo) == 0:
+            return text
+        rest = self._rows_py([batch_chr_pos_seq[i] for i in todo], [alt_info_list[i] for i in todo], batch_Y[todo])
+        parts, prev = [], 0
+        for i, t in zip(todo.tolist(), rest):
+            parts.append(text[int(off[prev]):int(off[i])])
+            if t is FALLBACK:
+                t = print_with_reference(i)
+            if t is not None:
+                parts.append(t)
+            prev = i + 1
+        parts.append(text[int(off[prev]):int(off[n])])
+        return "".join(parts)
 
     # ------------------------------------------------------------------------------------------------ one pass of output_from
     def _alleles(self, cls, pos, ref, look):
@@ -336,6 +470,24 @@ class RowPrinter:
     def rows(self, batch_chr_pos_seq, alt_info_list, batch_Y):
         """batch_Y: (B, 24|90 + DECODE_COLS) float32.  Returns a list with, per row, its VCF text, None (the reference prints
         nothing for it) or FALLBACK."""
+        n = len(batch_chr_pos_seq)
+        done = self._rows_c(batch_chr_pos_seq, alt_info_list, batch_Y) if self._c is not None and n else None
+        if done is not None:
+            # the common rows are printed; what was handed back -- rejected first candidates, shared maxima, odd texts -- goes through
+            # the per-row path below as a batch of its own
+            texts, todo = done
+            self.by_c += n - len(todo)
+            self.taken += n - len(todo)
+            if todo:
+                idx = np.asarray(todo)
+                rest = self._rows_py([batch_chr_pos_seq[i] for i in todo], [alt_info_list[i] for i in todo], batch_Y[idx])
+                for i, t in zip(todo, rest):
+                    texts[i] = t
+            return texts
+        return self._rows_py(batch_chr_pos_seq, alt_info_list, batch_Y)
+
+    def _rows_py(self, batch_chr_pos_seq, alt_info_list, batch_Y):
+        """the per-row path (round 5's ``rows``): every row of the batch it is given"""
         n = len(batch_chr_pos_seq)
         parsed = [None] * n
         centre = bytearray(n)

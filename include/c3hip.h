@@ -172,6 +172,30 @@ int c3_outcome_maxima(c3_model *m, const float *y_host, int64_t batch, const uin
 /* The decoder columns for rows that are already on the host: rows_host[batch][output_size + C3_DECODE_COLS] receives
  * y_host[b] followed by its columns (same kernel as the c3_model_set_decode_columns path).  Synchronous. */
 int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *rows_host);
+/* SURVEY 8f N1, the host side of the decoder: the VCF text of the rows of a batch whose first decision stands, in one pass over the
+ * batch -- what clair3/CallVariants.py does per row in batch_output (:1069-1116) -> output_with (:1119-1394) -> output_from's first
+ * pass (:676-1008) with the allele lookups find_alt_base (:662-673), insertion_ / deletion_bases_using_alt_info_from (:117-201), for
+ * rows that carry the decoder columns.  Plain host code (no device, safe in the forked decode workers of
+ * clair3/CallVariantsFromCffi.py:302-353).  An accelerator of clair3_amd/vcf_rows.py, not a second decoder: rows that are not
+ * plainly the common case get status 1 and are printed by the caller's Python path (the walk over rejected candidates, shared
+ * maxima, odd bytes).
+ *   cfg         what the reference's OutputConfig / param say: width 24|90, flank = param.flankingBaseNum, show_reference,
+ *               keep_iupac, has_qs_pass / qs_pass = quality_score_for_pass, pileup ('P' / 'F' in INFO), max_len = VariantLength.max,
+ *               infer = maximum_variant_length_that_need_infer, phred_trans = CallVariants.Phred_Trans, f32_arith = 1 when the
+ *               caller's numpy evaluates `1.0 - float32` in float32 (numpy >= 2: quality_score_from :375-381 depends on it),
+ *               gt[4] = genotype_string_from of homo_reference, homo_variant, hetero_variant, hetero_variant_multi; walk = 1: rows
+ *               whose first candidate the reads do not offer are walked here too (the later passes of output_from's loop), 0: handed back
+ *   pos_text / alt_text   the n chr_pos_seq / alt_info strings, NUL-separated
+ *   rows        n rows of row_stride_floats floats: width probabilities + C3_DECODE_COLS columns
+ *   out, out_off[n + 1], status[n]   text of row i = out[out_off[i] .. out_off[i + 1]) when status[i] is 0 (first decision) or 2 (after
+ *               rejected candidates); empty: the reference prints nothing for it.  status[i] == 1: the caller prints the row itself */
+typedef struct {
+    int32_t width, flank, show_reference, keep_iupac, has_qs_pass, pileup, max_len, infer, f32_arith, walk;
+    double qs_pass, phred_trans;
+    char gt[4][8];
+} c3_rows_config;
+int c3_vcf_rows(const c3_rows_config *cfg, int64_t n, const char *pos_text, int64_t pos_bytes, const char *alt_text, int64_t alt_bytes,
+                const float *rows, int64_t row_stride_floats, char *out, int64_t out_cap, int64_t *out_off, uint8_t *status);
 /* ---- the collective of the sharded job ----
  * The reference meets its per-GPU workers on disk (one VCF shard per worker, merged by SortVcf:
  * clair3/CallVariantsFromCffiGPU.py:138-199, preprocess/SortVcf.py:290-362).  Here the probability rows of every

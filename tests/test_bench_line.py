@@ -68,7 +68,9 @@ def test_family_time_is_a_share_of_the_free_running_step():
     ev_family, ev_all, step = r["kernel_us_per_step"], r["step_us_sum_of_kernels"], r["step_us_one_batch_in_flight"]
     share, fam = bench.family_time(ev_family, ev_all, step)
     assert 0.9 < share <= 1.0 and fam <= step and abs(fam - ev_family / ev_all * step) < 1e-9
-    assert bench.family_time(10.0, 5.0, 100.0) == (1.0, 100.0)  # a share is never above one
+    import pytest
+    with pytest.raises(ValueError, match="inconsistent profile"):  # a share above one is an error, not something to clamp
+        bench.family_time(10.0, 5.0, 100.0)
     # and every line committed from round 5 on keeps the inequality
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
         if name.startswith("r05_") and name.endswith(("bench.json", "bench20.json")):

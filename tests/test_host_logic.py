@@ -152,6 +152,13 @@ def test_the_decode_pool_is_forked_before_the_device_is_in_use(monkeypatch):
     assert callvar._cpu_threads_from_argv() == 2
     monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi"])
     assert callvar._cpu_threads_from_argv() == 4  # the reference's default (clair3/CallVariantsFromCffi.py:569)
+    monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi", "--cpu_t", "6", "--cpu", "x"])  # argparse's unambiguous prefixes
+    assert callvar._cpu_threads_from_argv() == 6
+    monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi", "--cpu_thr=5"])
+    assert callvar._cpu_threads_from_argv() == 5
+    monkeypatch.setenv("C3HIP_DECODE_PROCS", "7")  # a launcher / a programmatic caller says it outright
+    assert callvar._cpu_threads_from_argv() == 7
+    monkeypatch.delenv("C3HIP_DECODE_PROCS")
     factory = callvar._make_pool_factory(cf.ProcessPoolExecutor)
     monkeypatch.setattr(callvar, "_lib", type("L", (), {"device_count": staticmethod(lambda: 1)}))
     monkeypatch.setattr(sys, "argv", ["clair3.py", "CallVariantsFromCffi", "--cpu_threads", "2"])
@@ -174,8 +181,10 @@ def test_the_decode_pool_is_forked_before_the_device_is_in_use(monkeypatch):
         # a request of another size: the pool forked ahead is dropped, the caller gets what it asked for
         assert callvar._select_device_for_cffi_worker(True) == "cuda:0"
         ex2 = callvar._PREFORKED[0]
+        misses = callvar.STATS["prefork_mismatch"]
         with factory(max_workers=1) as small:
             assert small is not ex2 and callvar._PREFORKED is None
             assert small.submit(_forked_pid).result() != os.getpid()
+        assert callvar.STATS["prefork_mismatch"] == misses + 1  # (and one line on stderr says which size to ask for)
     finally:
         callvar._drop_preforked()

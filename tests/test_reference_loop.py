@@ -55,14 +55,19 @@ def run_worker(tmp_path, lst, decoder, tag, prefetch=False, batch=0):
             return real_outcome(*a, **k)
         decode.outcome_from_columns = counting_outcome
         from clair3_amd import vcf_rows
-        real_rows = vcf_rows.RowPrinter.rows
+        real_rows = vcf_rows.RowPrinter.batch_text
 
-        def counting_rows(self, *a, **k):  # rows printed straight from the columns (vcf_rows.py); the others reach counting_outcome
-            out = real_rows(self, *a, **k)
+        def counting_rows(self, pos, alt, y, print_with_reference):  # rows printed straight from the columns (vcf_rows.py: c3_vcf_rows or
+            back = [0]                                                # the per-row path); the others reach counting_outcome
+
+            def counted(i):
+                back[0] += 1
+                return print_with_reference(i)
+            out = real_rows(self, pos, alt, y, counted)
             with from_columns.get_lock():
-                from_columns.value += sum(1 for v in out if v is not vcf_rows.FALLBACK)
+                from_columns.value += len(pos) - back[0]
             return out
-        vcf_rows.RowPrinter.rows = counting_rows
+        vcf_rows.RowPrinter.batch_text = counting_rows
         names = callvar.install(gpu_wrapper=False, decoder=decoder)
         assert ("clair3.CallVariants.batch_output" in names) == decoder
         calls = {"plain": 0, "wide": 0, "submitted": 0, "max_in_flight": 0}
@@ -138,7 +143,7 @@ def run_worker(tmp_path, lst, decoder, tag, prefetch=False, batch=0):
         if "real_outcome" in locals():
             _d.outcome_from_columns = real_outcome
         if "real_rows" in locals():
-            vcf_rows.RowPrinter.rows = real_rows
+            vcf_rows.RowPrinter.batch_text = real_rows
         sys.path.remove(REF)
         for k in [k for k in sys.modules if k == "clair3" or k.startswith("clair3.") or k.startswith("shared")
                   or k.startswith("preprocess") or k == "libclair3"]:
