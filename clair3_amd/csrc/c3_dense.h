@@ -256,7 +256,8 @@ struct DenseWresParams {
 };
 
 // ABL (tools/dense_probe.hip only; 0 in the product): 1 no activation loads, 2 no LDS staging writes, 4 no matrix instructions,
-// 8 no fragment reads, 16 no result stores, 32 no barriers; 64 (product A/B knob C3HIP_GX2_NT): non-temporal result stores.
+// 8 no fragment reads, 16 no result stores, 32 no barriers; 64 (product A/B knob C3HIP_GX2_NT): non-temporal result stores; 128 / 256
+// (probe only) the results stored in two / three bytes per value.
 template <int ABL = 0>
 __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_wres_kernel(DenseWresParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * kWrStage + 8192];
@@ -329,6 +330,18 @@ __global__ __launch_bounds__(kDnThreads, 2) void dense_planes_wres_kernel(DenseW
         for (int e = 0; e < 4; ++e) val[e] = __builtin_fmaf(val[e], p.post_scale, bv[e]);
         if constexpr (ABL & 16) {
             if (val[0] == 1234.5f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 0);
+        } else if constexpr (ABL & 128) {
+            // tools/dense_probe.hip `gx2` only (round 6): what the launch takes when the pre-activations leave in TWO
+            // bytes per value -- the four values of a piece as fp16, one 8-byte store at half the offset.  Timing only: an upper bound of
+            // what any narrower gx2 format can save in this kernel (a 3-byte format lies between this and the fp32 stores)
+            const f16x2 a = __builtin_convertvector(f32x2{val[0], val[1]}, f16x2), b = __builtin_convertvector(f32x2{val[2], val[3]}, f16x2);
+            const u32x2 hv = {__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)};
+            __builtin_amdgcn_raw_buffer_store_b64(hv, crsrc, rowoff == kPlOob ? kPlOob : (rowoff + 32 * q) / 2, 0, 0);
+        } else if constexpr (ABL & 256) {
+            // ... and in THREE bytes per value: 12 of the piece's 16 bytes, one 12-byte store at three quarters of the offset
+            const pl_u32x4 w = __builtin_bit_cast(pl_u32x4, val);
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            __builtin_amdgcn_raw_buffer_store_b96(u32x3{w[0], w[1], w[2]}, crsrc, rowoff == kPlOob ? kPlOob : (rowoff + 32 * q) / 4 * 3, 0, 0);
         } else if constexpr (ABL & 64) {  // A/B knob (C3HIP_GX2_NT=1): the 173 MB of pre-activations leave with the non-temporal hint
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pl_u32x4, val), crsrc, rowoff + 32 * q, 0, 2);
         } else {

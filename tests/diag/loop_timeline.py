@@ -27,6 +27,8 @@ kind, channels, indel, pileup = (syn.PILEUP, 18, False, True) if name == "pileup
 
 ref = refloop.reference_root()
 d = tempfile.mkdtemp(prefix="c3_timeline_")
+import atexit, shutil  # noqa: E401,E402
+atexit.register(shutil.rmtree, d, ignore_errors=True)
 lst = refloop.write_job(d, kind, [per_file] * files, channels=channels)
 ck = os.path.join(d, "model.pt")
 refloop.write_checkpoint(ck, kind, channels, indel)

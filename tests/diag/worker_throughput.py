@@ -2,9 +2,11 @@
 model -> decode processes -> VCF) on libc3hip, with and without the decoder columns, next to the same command on the reference's
 modules through PyTorch (GPU if torch sees one, as --use_gpu does there).  Needs an MI355X and oracle/_ref.
 python tests/diag/worker_throughput.py [windows per file] [files] [cpu_threads]"""
+import atexit
 import json
 import os
 import re
+import shutil
 import sys
 import tempfile
 import time
@@ -25,6 +27,7 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
     if only and only != name:
         continue
     d = tempfile.mkdtemp(prefix="c3_worker_")
+    atexit.register(shutil.rmtree, d, ignore_errors=True)  # 5.6 GB of tensor files per 240 k-window job: a sweep that leaves them fills /tmp
     n = per_file * files * (3 if pileup else 1)
     lst = refloop.write_job(d, kind, [per_file * (3 if pileup else 1)] * files, channels=channels)
     ck = os.path.join(d, "model")

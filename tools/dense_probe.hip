@@ -2,6 +2,7 @@
 // K = 256): both kernels of c3_dense.h with parts switched off (ABL bits).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-gpu-flush-denormals-to-zero -w -I clair3_amd/csrc tools/dense_probe.hip -o tools/bin/dense_probe
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -75,6 +76,15 @@ int main(int argc, char **argv) {
         wp.M = M, wp.N = N, wp.tiles_m = (M + kWrBM - 1) / kWrBM, wp.tiles_n = N / kWrBN, wp.lanes_per_xcd = 6;
         const int gw = 8 * wp.lanes_per_xcd * wp.tiles_n;
 #define RUNR(abl, name) report(name, time_us([&] { hipLaunchKernelGGL((dense_planes_wres_kernel<abl>), dim3(gw), dim3(kDnThreads), 0, 0, wp); }, 20))
+        if (argc > 2 && !strcmp(argv[2], "gx2")) {  // round 6: the upper bound of a narrower gx2, three alternating repeats
+            for (int rep = 0; rep < 3; ++rep) {
+                RUNR(0, "weights-resident kernel, fp32 pre-activations (173 MB at B = 1024)");
+                RUNR(256, "  three bytes per value (12-byte stores, 130 MB)");
+                RUNR(128, "  two bytes per value (fp16, 8-byte stores, 86 MB)");
+                RUNR(16, "  no result stores");
+            }
+            return 0;
+        }
         RUNR(0, "weights-resident kernel (240 workgroups)");
         RUNR(16, "  - result stores");
         RUNR(1, "  - activation loads");
