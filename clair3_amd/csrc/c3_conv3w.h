@@ -86,7 +86,7 @@ __device__ __forceinline__ void split2_f16_mix(const f32x4 x, u32x2 (&piece)[2])
 // 4 no epilogue, 8 no matrix instructions, 32 shader-clock trace of workgroups 0 and 256 (wave 0) at phase boundaries, 16 the transform's loads NOT requested ahead (round-5 first cut: each item's loads issued
 // and waited for at the slab switch), 64 the UPPER BOUND of a split-K launch (round 6): p.tiles is twice the real
 // count, workgroups 2k and 2k + 1 run the same tile on half of its slabs each and both store their (partial) result -- the time of
-// a split-K pair WITHOUT its exchange.  MIX = false: the transform on plain conversions (the probe checks the two forms agree bit for bit).
+// a split-K pair WITHOUT its exchange; 128 start / end stamps of every workgroup (device-wide counter).  MIX = false: the transform on plain conversions (the probe checks the two forms agree bit for bit).
 //
 // Where the transform's memory latency goes.  A thread owns two items (row r = (tid + 256 it) >> 2 of the 128 V rows, 8-channel group
 // g = tid & 3) per slab.  The 16 buffer loads of BOTH items of the next slab go out right behind the slab's last matrix instruction,
@@ -239,6 +239,11 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
         }
     };
     trace(1);
+    // ABL 128 (probe only, round 6): every workgroup stamps its start and its end with the device-wide 100 MHz counter -- when do the
+    // tiles of a launch finish relative to each other, i.e. how early could a consumer tile of the NEXT layer start
+    if constexpr (ABL & 128) {
+        if (tid == 0) p.trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
     const int lrow[2] = {wm * 64 + frow, wm * 64 + 32 + frow};  // this lane's V rows (tile-pixel m0 - 1 + lrow; its column taps: lrow + kw - 1)
     const int cb0 = wn * 32 + 4 * kh;                            // first of this lane's output channels inside the column tile
     float omax = 0.f;
@@ -468,6 +473,10 @@ __global__ __launch_bounds__(kPlThreads, 2) void conv3x3_wino_planes_kernel(Wino
         lds_barrier();
         trace(36);
         v = vn, m0 = m0n, cur ^= 1;
+    }
+    if constexpr (ABL & 128) {
+        __builtin_amdgcn_s_waitcnt(0);  // (the tile's stores have been issued and acknowledged)
+        if (tid == 0) p.trace[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
     if (p.range_flag && !(omax < kF16Range)) atomicOr(p.range_flag, 1u);
 }

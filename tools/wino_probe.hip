@@ -6,6 +6,7 @@
 // 2. time: direct whole, Winograd whole and with parts switched off (ABL bits: 1 no weight loads, 2 no transform after the first,
 //    4 no epilogue, 8 no matrix instructions, 16 transform loads not requested ahead), one and two workgroups per CU.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -216,6 +217,39 @@ template <int C> static int shape(const char *name, int B, int H, int W, int cus
     printf("  wino16 (LDS-DMA, 16-channel slabs) against wino: %zu values differ, max |difference| %.3e\n", w16diff, w16max);
     printf("  wino16 with 64-row tiles against wino: %zu values differ, max |difference| %.3e\n", s16diff, s16max);
     if (timing && split_only) {
+        {   // when do the workgroups of ONE launch start and finish (100 MHz device-wide counter: 10 ns ticks)?  A
+            // consumer tile of the next layer needs its three producer tiles: it cannot start before they have finished.
+            long long *tb; CK(hipMalloc(&tb, (size_t)2 * 1024 * 8)); CK(hipMemset(tb, 0, (size_t)2 * 1024 * 8));
+            WinoConvParams wt = wp; wt.trace = tb;
+            launch_w<C, true, 128>(wt, gw); CK(hipDeviceSynchronize());
+            launch_w<C, true, 128>(wt, gw); CK(hipDeviceSynchronize());
+            std::vector<long long> ht(2 * 1024);
+            CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> st, en;
+            long long t0 = ht[0];
+            for (int i = 0; i < gw; ++i) t0 = std::min(t0, ht[2 * i]);
+            for (int i = 0; i < gw; ++i) st.push_back((ht[2 * i] - t0) * 0.01), en.push_back((ht[2 * i + 1] - t0) * 0.01);
+            std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+            auto q = [&](const std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+            printf("  one launch, %d workgroups of one tile each (us after the first workgroup's start): starts min %.2f p50 %.2f max %.2f; ends min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+                   gw, q(st, 0), q(st, 0.5), q(st, 1), q(en, 0), q(en, 0.1), q(en, 0.5), q(en, 0.9), q(en, 1));
+            // how early could tile t of the NEXT layer start?  It reads the pixels of tiles t - 1, t, t + 1 (same column tile order): when the last of the three has finished
+            std::vector<double> ready, end_of_tile(wp.tiles, 0.0);
+            auto tile_of = [&](int block) {  // xcd_tile_index (c3_gemm.h): block b runs on XCD b % 8, an XCD owns a contiguous run of tiles
+                const int xcd = block & 7, slot = block >> 3, qq = wp.tiles >> 3, r = wp.tiles & 7;
+                return (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+            };
+            for (int i = 0; i < gw; ++i) end_of_tile[tile_of(i)] = (ht[2 * i + 1] - t0) * 0.01;  // (grid == tiles here: one tile per workgroup)
+            for (int t = 0; t < wp.tiles; ++t) {
+                double r = 0;
+                for (int d = -NS; d <= NS; d += NS) { const int j = t + d; if (j >= 0 && j < wp.tiles) r = std::max(r, end_of_tile[j]); }
+                ready.push_back(r);
+            }
+            std::sort(ready.begin(), ready.end());
+            printf("  a consumer tile is runnable when its (up to) three producer workgroups have ended: min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f us -- a launch boundary releases all of them at %.2f us\n",
+                   q(ready, 0), q(ready, 0.1), q(ready, 0.5), q(ready, 0.9), q(ready, 1), q(en, 1));
+            hipFree(tb);
+        }
         // split-K over the input channels for the launches that leave workgroup slots empty at B = 256.  ABL 64 runs every
         // tile as TWO workgroups on half of the slabs each, with no exchange of the partial sums: an upper bound of what the real thing
         // (partial tile through L2 / memory, second half adds and runs the epilogue) could gain.
