@@ -84,12 +84,25 @@ def test_family_time_is_a_share_of_the_free_running_step():
             assert abs(roof["whole_network_frac"] - line["value"] * 451538432 / 2500e12) < 2e-3, name
 
 
+def test_the_round_6_line_carries_what_round_5s_review_asked_for():
+    """profiles/r06_final_bench*.json: the raw event-based family time and fraction next to the share-based ones, and the host-to-host
+    ring timed over exactly the driver's --steps next to the >= 100-step figure"""
+    for name, steps in (("r06_final_bench.json", 200), ("r06_final_bench20.json", 20)):
+        line = json.loads(open(os.path.join(ROOT, "profiles", name)).read())
+        roof, host = line["roofline"], line["host_inclusive"]
+        ev = roof["events"]
+        assert ev["family_us_per_step"] >= roof["kernel_us_per_step"] and abs(ev["frac"] * ev["family_us_per_step"] / (roof["frac"] * roof["kernel_us_per_step"]) - 1) < 1e-3
+        assert line["steps"] == steps and host["at_driver_steps"]["steps"] == steps and host["steps"] == max(steps, 100)
+        assert 0.8 < host["at_driver_steps"]["value"] / host["value"] < 1.2
+        assert "page_locked" not in json.dumps(line) and "registered_source" not in json.dumps(line)  # no page-locked legs any more
+
+
 def test_the_round_5_collections_are_consistent():
-    """profiles/r05_g_* and r05_final_* (the round's tree on two boxes): one parseable line under 4 KB, value / ms_per_step / roofline on the
+    """profiles/r05_g_*, r05_final_* and r06_final_* (round 6 changed no kernel of the product path): one parseable line under 4 KB, value / ms_per_step / roofline on the
     same leg, the family's time inside the step, fabric-byte names, and the roofline fraction recomputed from the rocprofv3 kernel statistics
     of the same box within 3 % (eight convolution launches per step: five direct / stride-2 kernels and three on the F(2,3) form)"""
     import csv
-    for tag in ("r05_g", "r05_final"):
+    for tag in ("r05_g", "r05_final", "r06_final"):
         for name in (f"{tag}_bench.json", f"{tag}_bench20.json"):
             raw = open(os.path.join(ROOT, "profiles", name)).read().strip()
             assert len(raw.splitlines()) == 1 and len(raw) <= 4096, (name, len(raw))
