@@ -145,21 +145,22 @@ def pin_to_device_numa(device, sysfs="/sys", pci_bus_id=None, setaffinity=None, 
     if setaffinity is None or getaffinity is None:
         info["why"] = "no sched_setaffinity on this platform"
         return info
-    if pci_bus_id is None:  # sysfs first (no HIP call: see pci_bus_id_from_kfd), the runtime's own answer second
-        vis = visible_device_ids()
-        physical = vis[device] if vis is not None and 0 <= int(device) < len(vis) else int(device)
-        pci_bus_id = pci_bus_id_from_kfd(physical, sysfs)
-        info["pci_from"] = "kfd topology"
-    if pci_bus_id is None and use_hip:
+    why = None
+    if pci_bus_id is None and use_hip:  # the runtime's own answer where the runtime may be asked (a rank of a job, bench.py) ...
         try:
             from . import _lib
             pci_bus_id = _lib.pci_bus_id(device)
             info["pci_from"] = "c3_device_pci_bus_id"
         except Exception as e:  # no device, no library: placement is an optimisation, never an error
-            info["why"] = f"no PCI address ({e})"
-            return info
+            why = f"{e}"
+    if pci_bus_id is None:  # ... the kfd topology in sysfs otherwise (no HIP call: the stage-B worker before it forks its pool)
+        vis = visible_device_ids()
+        physical = vis[device] if vis is not None and 0 <= int(device) < len(vis) else int(device)
+        pci_bus_id = pci_bus_id_from_kfd(physical, sysfs)
+        info["pci_from"] = "kfd topology"
     if pci_bus_id is None:
-        info["why"] = "no PCI address (no kfd topology in sysfs)"
+        info.pop("pci_from", None)
+        info["why"] = "no PCI address (no kfd topology in sysfs" + (f"; the runtime: {why})" if why else ")")
         return info
     node, cpus = numa_cpus_of_pci(pci_bus_id, sysfs)
     info.update(pci=pci_bus_id, numa_node=node)

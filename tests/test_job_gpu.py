@@ -109,3 +109,34 @@ def test_describe_names_the_kernel_forms():
     text = buf.value.decode()
     assert "lstm1=fused-f16x3-half-tiles" in text and "proj2=weights-resident" in text and "lstm2=f16x3-half-tiles" in text, text
     assert "on_fp32=0" in text
+
+
+def test_a_rank_finds_the_numa_node_of_its_gpu_on_this_box(tmp_path):
+    """dist.pin_to_device_numa against the REAL sysfs of the GPU box (the CPU suite runs it on a made-up tree): the PCI address read from the kfd
+    topology without any HIP call is the one the runtime reports (c3_device_pci_bus_id), the node's CPU list parses, and the pin -- done in a
+    child process so that this one keeps its affinity -- never widens or empties the allowed set.  On a box whose platform names no NUMA node for
+    the device the function says so and leaves the affinity alone."""
+    import json
+    import subprocess
+    import sys
+    from clair3_amd import _lib, dist as d
+    from tests.util import ROOT
+    hip_pci = _lib.pci_bus_id(0)
+    vis = d.visible_device_ids()
+    kfd_pci = d.pci_bus_id_from_kfd(vis[0] if vis else 0)
+    print(f"device 0: PCI {hip_pci} (runtime) / {kfd_pci} (kfd topology); visible ids {vis}")
+    assert kfd_pci is None or kfd_pci == hip_pci, (kfd_pci, hip_pci)
+    node, cpus = d.numa_cpus_of_pci(hip_pci)
+    print(f"numa node {node}, {len(cpus)} CPUs")
+    code = ("import json, os, sys; sys.path.insert(0, %r); from clair3_amd import dist as d; a = sorted(os.sched_getaffinity(0)); "
+            "r = d.pin_to_device_numa(0); b = sorted(os.sched_getaffinity(0)); print(json.dumps({'before': len(a), 'after': len(b), "
+            "'subset': set(b) <= set(a), 'report': r}))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    print(r)
+    assert r["subset"] and r["after"] >= 1 and r["report"]["device"] == 0
+    if r["report"]["pinned"]:
+        assert r["after"] == r["report"]["cpus"] < r["before"] and r["report"]["numa_node"] == node >= 0
+    else:
+        assert r["after"] == r["before"] and r["report"]["why"]
