@@ -23,6 +23,11 @@
  *   c3_predict_device               the forward pass alone on tensors already resident in HBM
  *                                   (what bench.py times; also the hook for the RCCL gather of SURVEY 8e).
  *   c3_model_destroy                model going out of scope at process exit.
+ *   c3_vcf_rows                     the per-row Python of the decoder: batch_output -> output_with -> output_from with its allele
+ *                                   lookups (clair3/CallVariants.py:1069-1394, :676-1016, :117-201, :662-673) for rows that carry the
+ *                                   decoder columns -- one pass of plain host code per batch.
+ *   c3_device_pci_bus_id            where a GPU slot's worker belongs on the host (the reference leaves placement to the OS,
+ *                                   clair3/CallVariantsFromCffiGPU.py:138-156).
  *
  * Conventions (mirroring libclair3's cffi surface, build.py:38-85, src/clair3_pileup.h:90-113):
  *   - plain C types only; the library owns all device memory; the caller owns host x / y buffers
