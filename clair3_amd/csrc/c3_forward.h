@@ -4,10 +4,44 @@
 #pragma once
 #include "c3_model.h"
 
+// ------------------------------------------------------------------------------------------ the FC chain on its own stream (ring only)
+// tail_begin: the stream the chain of THIS forward pass runs on -- tail_stream, behind everything queued on s so far, when the ring's
+// submit asked for it (m->tail_now), else s itself.  tail_end: marks the chain's end.  tail_guard: called on s right before the first
+// launch that overwrites what a chain reads (the pooled tensor / lstm2_out of the handle's one workspace): waits for the chain that may
+// still be running -- by then it finished a whole network ago, so the wait costs nothing.
+static int tail_guard(c3_model *m, hipStream_t s);
+static int tail_begin(c3_model *m, hipStream_t s, hipStream_t *ts) {
+    *ts = s;
+    if (!m->tail_now) return tail_guard(m, s);  // (a chain on s itself: behind one that may still be running on tail_stream -- they share the partials)
+    if (!m->tail_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m->tail_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_body_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_tail_done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(m->ev_body_done, s));
+    HIP_TRY(hipStreamWaitEvent(m->tail_stream, m->ev_body_done, 0));
+    *ts = m->tail_stream;
+    return 0;
+}
+static int tail_end(c3_model *m, hipStream_t ts) {
+    if (ts != m->tail_stream || !m->tail_stream) return 0;
+    HIP_TRY(hipEventRecord(m->ev_tail_done, ts));
+    m->tail_pending = true;
+    return 0;
+}
+static int tail_guard(c3_model *m, hipStream_t s) {
+    if (!m->tail_pending) return 0;
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_tail_done, 0));
+    m->tail_pending = false;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ FC tail (both networks)
 // L4 as a split-K contraction -> splitk_reduce_selu_kernel -> fc_tail_mfma_kernel (c3_tail.h); the decoder columns behind it
-static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int64_t n, float *y, const char *tag_l4,
+static int run_tail(c3_model *m, hipStream_t s0, const float *a, int64_t lda, int64_t n, float *y, const char *tag_l4,
                     const char *tag_tail) {
+    hipStream_t s;
+    TRY(tail_begin(m, s0, &s));  // (the ring: the chain on its own stream, behind the layers queued on s0)
     const int FC = m->FC, K4 = m->K4;
     const int nk_total = K4 / kBK;
     const int S = l4_splits(m);
@@ -53,7 +87,7 @@ static int run_tail(c3_model *m, hipStream_t s, const float *a, int64_t lda, int
         hipLaunchKernelGGL(outcome_maxima_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dp);
         HIP_TRY(hipGetLastError());
     }
-    return 0;
+    return tail_end(m, s);
 }
 
 // ------------------------------------------------------------------------------------------ full alignment
@@ -116,6 +150,7 @@ static int run_fa_planes(c3_model *m, hipStream_t s, const int8_t *x, int64_t n,
             cin = Cout;
             continue;
         }
+        if (l == 8) TRY(tail_guard(m, s));  // res3b (and the pooling behind it) overwrites what a chain still on tail_stream reads
         double flops = 2.0 * M * Cout * 9.0 * cin;
         double bytes = (l == 0 ? 1.0 : 4.0) * n * hh[l] * ww[l] * cin + 4.0 * M * Cout * (l % 3 == 2 ? 2 : 1) + 4.0 * Cout * 9.0 * cin;
         if (fuse1 && l == 1) flops += 2.0 * M * 64.0 * 9.0 * m->C, bytes += 1.0 * n * hh[0] * ww[0] * m->C - 4.0 * M * 64;  // conv1's algorithmic work rides here
@@ -276,6 +311,7 @@ static int run_fa_fp32(c3_model *m, hipStream_t s, const int8_t *x, int64_t n, f
     for (int l = 0; l < 9; ++l) {
         const int Cout = kConvCout[l];
         const int M = (int)(n * hh[l + 1] * ww[l + 1]);
+        if (l == 8) TRY(tail_guard(m, s));
         const double flops = 2.0 * M * Cout * 9.0 * cin;
         const double bytes = (l == 0 ? 1.0 : 4.0) * n * hh[l] * ww[l] * cin + 4.0 * M * Cout * (l % 3 == 2 ? 2 : 1) + 4.0 * Cout * 9.0 * cin;
         ProfScope ps(m, s, kFaLayerTag[l], flops, bytes);
@@ -394,6 +430,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             TRY((launch_gemm<DenseLoader<4>, EPI_BIAS, 128, 128>(s, lp, m->proj_w[1], 256, M, 1280, 8, 1, ep)));
         }
     }
+    TRY(tail_guard(m, s));  // LSTM2 overwrites lstm2_out, which a chain still on tail_stream reads
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
         const bool l2_f16 = m->f16_ok && m->whh16[1];

@@ -51,6 +51,17 @@ static int stage_h2d(void *dev, void *pin, const void *src, size_t bytes, hipStr
     return 0;
 }
 
+// The forward pass of a batch of the ring on the handle's stream, its FC chain on tail_stream (c3_forward.h tail_begin): *outs is the stream the
+// rows are complete on -- where the copy-out kernel and the slot's event go.  The next batch's layers are queued on m->stream right behind this
+// batch's LAST LAYER, not behind its chain.
+static int ring_forward(c3_model *m, const void *x_dev, int x_dtype, int64_t batch, float *y_dev, hipStream_t *outs) {
+    m->tail_now = m->tail_split && !m->keep && m->duo == 0 && !m->prof;
+    const int rc = forward_device(m, m->stream, x_dev, x_dtype, batch, y_dev);
+    *outs = (m->tail_now && m->tail_stream && batch > 0) ? m->tail_stream : m->stream;
+    m->tail_now = false;
+    return rc;
+}
+
 extern "C" {
 
 // Pinned staging memory stays out of forked children (keep_out_of_children, c3_model.h: the staging copies of the 40 groups after
@@ -125,13 +136,14 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
                            (const uint32_t *)nullptr, (uint32_t *)nullptr);
         HIP_TRY(hipGetLastError());
         const bool f16 = m->f16_ok;
-        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, y_dev_out ? y_dev_out : sl.dev_y));
+        hipStream_t outs;
+        TRY(ring_forward(m, sl.dev_x, x_dtype, batch, y_dev_out ? y_dev_out : sl.dev_y, &outs));
         if (y_dev_out && f16)
-            hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((batch * m->row + 255) / 256)), dim3(256), 0, m->stream, y_dev_out, batch * m->row, m->range_flag);
-        hipLaunchKernelGGL(host_copy_kernel, dim3(y_dev_out ? 1 : rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y,
+            hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((batch * m->row + 255) / 256)), dim3(256), 0, outs, y_dev_out, batch * m->row, m->range_flag);
+        hipLaunchKernelGGL(host_copy_kernel, dim3(y_dev_out ? 1 : rows_out_grid(yb)), dim3(256), 0, outs, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y,
                            y_dev_out ? 0 : (yb + 15) / 16, (const uint32_t *)m->range_flag, sl.pin_flag);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
+        HIP_TRY(hipEventRecord(sl.ev_out, outs));
         sl.used_f16 = f16;
     } else
     if (batch > 0) {
@@ -141,16 +153,17 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
         HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
         HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
         const bool f16 = m->f16_ok;
-        TRY(forward_device(m, m->stream, sl.dev_x, x_dtype, batch, y_dev_out ? y_dev_out : sl.dev_y));
+        hipStream_t outs;
+        TRY(ring_forward(m, sl.dev_x, x_dtype, batch, y_dev_out ? y_dev_out : sl.dev_y, &outs));
         if (y_dev_out && f16)  // rows that stay on the device are scanned there (bit 1 of the flag: a non-finite row)
-            hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((batch * m->row + 255) / 256)), dim3(256), 0, m->stream, y_dev_out, batch * m->row, m->range_flag);
+            hipLaunchKernelGGL(rows_finite_kernel, dim3((unsigned)((batch * m->row + 255) / 256)), dim3(256), 0, outs, y_dev_out, batch * m->row, m->range_flag);
         // the rows (96 - 484 B per window) and the range flag leave through a copy kernel on the COMPUTE stream, whatever the
         // batch: handing them to a transfer stream (event, cross-queue wait, two DMA copies, event) cost the compute queue
         // ~75 us per batch -- 538 k -> 647 k windows/s host to host at B = 256 (profiles/r03_e_d2h_by_kernel.txt)
-        hipLaunchKernelGGL(host_copy_kernel, dim3(y_dev_out ? 1 : rows_out_grid(yb)), dim3(256), 0, m->stream, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y,
+        hipLaunchKernelGGL(host_copy_kernel, dim3(y_dev_out ? 1 : rows_out_grid(yb)), dim3(256), 0, outs, (const uint4 *)sl.dev_y, (uint4 *)sl.pin_y,
                            y_dev_out ? 0 : (yb + 15) / 16, (const uint32_t *)m->range_flag, sl.pin_flag);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(sl.ev_out, m->stream));
+        HIP_TRY(hipEventRecord(sl.ev_out, outs));
         sl.used_f16 = f16;
     }
     sl.y_dev_out = y_dev_out;

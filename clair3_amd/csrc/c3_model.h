@@ -123,6 +123,17 @@ struct c3_model {
     bool loaded = false;
     hipStream_t stream = nullptr, h2d_stream = nullptr;  // kernels (and the rows on their way out); staged windows on their way in
     hipStream_t duo_stream = nullptr;                    // the second half of a micro-batch (c3_forward.h forward_device, C3HIP_DUO)
+    // The FC chain of a batch of the submit / wait ring on a stream of its own (round 6, c3_forward.h tail_split): L4, the split-K sum and
+    // the tail are three small launches (224 / few / 64 workgroups, 20 - 30 us) behind which the NEXT batch's first layers would wait
+    // although they depend on nothing of them; on their own stream they run in the slots the next batch's under-filled launches leave
+    // free.  ev_body_done: the last layer in front of the chain; ev_tail_done: the chain (the next batch waits for it before it overwrites
+    // what the chain reads: the pooled tensor / lstm2_out).  Default: on for full alignment, off for pileup (c3_model_create says why); env
+    // C3HIP_TAIL_STREAM=0 / 1.
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_body_done = nullptr, ev_tail_done = nullptr;
+    bool tail_split = false;   // allowed (set in c3_model_create: the kind's default, or env)
+    bool tail_pending = false;  // a chain is (or may still be) running on tail_stream
+    bool tail_now = false;      // this forward pass puts its chain on tail_stream (set by the ring's submit around forward_device)
     hipEvent_t duo_fork = nullptr, duo_join = nullptr;
 
     // ---- packed weights (device) ----

@@ -100,6 +100,11 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     m->tail_fused = kind == C3_KIND_PILEUP;
     if (const char *e = getenv("C3HIP_TAIL_FUSED")) m->tail_fused = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HALF_TILES")) m->half_tiles = atoi(e) != 0;
+    // the ring's FC chain on its own stream: on for full alignment (same-box A/B, profiles/r06_h_ab_tail_stream.txt: ring 680 - 685 k -> 696 k windows/s at
+    // B = 256, 687 -> 705 - 709 k over the driver's 100 steps, 768 -> 778 - 780 k at B = 1000), off for the pileup network (4.09 - 4.14 M -> 4.03 M: a chain
+    // beside the next batch's latency-bound LSTM1 slows the recurrence more than it hides)
+    m->tail_split = kind == C3_KIND_FULL_ALIGNMENT;
+    if (const char *e = getenv("C3HIP_TAIL_STREAM")) m->tail_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
     {
         hipDeviceProp_t prop;
@@ -268,6 +273,7 @@ int c3_model_describe(c3_model *m, char *buf, int n) {
 int c3_model_synchronize(c3_model *m) {
     if (!m) return fail("null model");
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->tail_stream) HIP_TRY(hipStreamSynchronize(m->tail_stream));
     return 0;
 }
 
@@ -310,6 +316,9 @@ int c3_model_destroy(c3_model *m) {
     if (m->stream) (void)hipStreamDestroy(m->stream);
     if (m->h2d_stream) (void)hipStreamDestroy(m->h2d_stream);
     if (m->duo_stream) (void)hipStreamDestroy(m->duo_stream);
+    if (m->tail_stream) (void)hipStreamDestroy(m->tail_stream);
+    if (m->ev_body_done) (void)hipEventDestroy(m->ev_body_done);
+    if (m->ev_tail_done) (void)hipEventDestroy(m->ev_tail_done);
     if (m->duo_fork) (void)hipEventDestroy(m->duo_fork);
     if (m->duo_join) (void)hipEventDestroy(m->duo_join);
     delete m;

@@ -171,6 +171,48 @@ def test_async_submit_wait_and_device_paths_agree():
     assert yd.is_cuda and np.array_equal(yd.cpu().numpy(), ya)
 
 
+@pytest.mark.parametrize("kind", [syn.FULL_ALIGNMENT, syn.PILEUP])
+def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
+    """Round 6: a batch of the submit / wait ring runs its FC chain (L4, the split-K sum, the tail, the decoder columns, the copy-out) on
+    the handle's tail stream, so that the NEXT batch's first layers are queued behind this batch's last layer, not behind three small
+    launches they do not depend on; the next batch waits for the chain only before it overwrites what the chain reads (the pooled tensor /
+    lstm2_out).  Same kernels on the same data: rows bit-identical to C3HIP_TAIL_STREAM=0 and to the blocking call, for batches of
+    different sizes kept in flight on every slot, micro-batches beyond the workspace cap, decoder columns, and with the device-resident
+    entry (whose chain stays on the caller's stream) called between rounds."""
+    import torch
+    ch, indel = (8, True) if kind == syn.FULL_ALIGNMENT else (18, False)
+    sd = syn.make_state_dict(kind, ch, indel, seed=91)
+    sizes = [300, 17, 256, 1, 129, 64, 511, 33, 256, 256] if kind == syn.FULL_ALIGNMENT else [1024, 9, 4097, 16, 2000, 1, 777, 1024, 1024, 31]
+    xs = [syn.make_windows(kind, n, seed=92 + i, channels=ch) for i, n in enumerate(sizes)]
+    monkeypatch.setenv("C3HIP_TAIL_STREAM", "0")
+    m0 = make_model(kind, ch, indel, sd)
+    want = [m0.predict_numpy(x) for x in xs]
+    monkeypatch.setenv("C3HIP_TAIL_STREAM", "1")  # (the default for full alignment; off by default for the pileup network, where it measured a loss)
+    m = make_model(kind, ch, indel, sd)
+    for rounds in range(3):
+        tickets = []
+        got = [None] * len(xs)
+        for i, x in enumerate(xs):  # up to three batches in flight, slots reused as soon as they have been waited for
+            if len(tickets) == 3:
+                j, t = tickets.pop(0)
+                got[j] = m.wait(t)
+            tickets.append((i, m.submit(x, slot=i % 3)))
+        for j, t in tickets:
+            got[j] = m.wait(t)
+        # the device-resident entry between two rounds of the ring (calls on one handle must not overlap: the ring is drained): its chain
+        # runs on the CALLER's stream, behind the ring's last chain
+        yd = m(torch.from_numpy(xs[1]).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), want[1])
+        for i in range(len(xs)):
+            assert np.array_equal(got[i], want[i]), (rounds, i, sizes[i])
+    assert np.array_equal(m.predict_numpy(np.concatenate(xs[:4])), np.concatenate(want[:4]))  # the blocking call: chunks through the ring
+    m.decode_columns(True)
+    m0.decode_columns(True)
+    t1, t2 = m.submit(xs[0], slot=0), m.submit(xs[2], slot=1)
+    assert np.array_equal(m.wait(t1), m0.predict_numpy(xs[0])) and np.array_equal(m.wait(t2), m0.predict_numpy(xs[2]))
+
+
 def test_strict_state_dict_loading():
     sd = syn.make_state_dict(syn.PILEUP, seed=61)
     m = Clair3_P(predict=True).to("cuda:0")
