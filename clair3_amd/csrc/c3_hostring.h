@@ -120,6 +120,11 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     if (sl.busy) return fail("slot %d still in flight: call c3_predict_wait first", slot);
     HIP_TRY(hipSetDevice(m->device));
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
+    // the batch in slot k runs in lane k & 1 (c3_model.h Lane): its own workspace and kernel stream, so that it overlaps the batch of the
+    // neighbouring slot on the chip; keep mode, the two-halves knob and profiling stay in one lane
+    // -- and so does a batch that fills the chip by itself: two of those side by side only get in each other's way (same-box A/B,
+    // profiles/r06_i_ab_ring_lanes.txt: full alignment ring +5.5 % at B = 256, -4 % at B = 1000)
+    TRY(use_lane(m, (m->ring_lanes == 2 && batch <= m->lane_max_batch && !m->keep && m->duo == 0 && !m->prof) ? (slot & 1) : 0));
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
     const size_t yb = (size_t)batch * m->row * sizeof(float);
     // C3HIP_HOST_COPY_KERNEL: 0 = never, 1 = up to kKernelCopyMax, n > 1 = up to n KB (A/B of the threshold)
@@ -167,6 +172,7 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
         sl.used_f16 = f16;
     }
     sl.y_dev_out = y_dev_out;
+    sl.lane = m->lane_cur;
     sl.y_host = y_host, sl.y_bytes = yb, sl.batch = batch, sl.x_dtype = x_dtype, sl.busy = true;
     return 0;
 }
@@ -184,6 +190,7 @@ int c3_predict_wait(c3_model *m, int slot) {
             if (m->f16_ok)
                 fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
             m->f16_ok = false, m->precision = "fp32-range-guard";
+            TRY(use_lane(m, sl.lane));
             TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.y_dev_out));
             HIP_TRY(hipStreamSynchronize(m->stream));
         }
@@ -201,6 +208,7 @@ int c3_predict_wait(c3_model *m, int slot) {
             if (m->f16_ok)
                 fprintf(stderr, "libc3hip: activations beyond the range of the fp16x3 kernels; this handle continues on fp32 matrix instructions\n");
             m->f16_ok = false, m->precision = "fp32-range-guard";
+            TRY(use_lane(m, sl.lane));
             TRY(forward_device(m, m->stream, sl.dev_x, sl.x_dtype, sl.batch, sl.dev_y));
             HIP_TRY(hipMemcpyAsync(sl.pin_y, sl.dev_y, sl.y_bytes, hipMemcpyDeviceToHost, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
@@ -280,6 +288,7 @@ int c3_predict_pileup_region(c3_model *m, const void *region_host, int x_dtype, 
     if (sl.busy) return fail("slot 0 still in flight: call c3_predict_wait first");
     HIP_TRY(hipSetDevice(m->device));
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
+    TRY(use_lane(m, 0));
     const size_t item = x_dtype == C3_DTYPE_I32 ? 4 : 1;
     const size_t rb = ((size_t)n_cols * m->C * item + 255) & ~(size_t)255;
     const size_t sb = (size_t)batch * sizeof(int32_t);

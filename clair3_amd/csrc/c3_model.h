@@ -111,6 +111,7 @@ struct HostSlot {
     int x_dtype = 0;
     bool busy = false;
     bool used_f16 = false;  // the batch in flight was computed by the fp16x3 kernels (c3_predict_wait then checks its range)
+    int lane = 0;           // the lane (c3_model::Lane) the batch in flight runs in
 };
 
 constexpr int kHostSlots = 4;  // batches in flight per handle through c3_predict_submit / _wait (C3_HOST_SLOTS)
@@ -215,6 +216,27 @@ struct c3_model {
 
     HostSlot slot[kHostSlots];
 
+    // ---- the ring's second lane (round 6) ----
+    // Batches of the submit / wait ring used to run strictly one after the other: ONE workspace and ONE kernel stream per handle.  A lane is
+    // everything a forward pass writes -- the workspace, the kernel stream, the tail stream and its events: with two of them the batch in slot
+    // k runs on lane k & 1, consecutive batches overlap on the chip (what three HANDLES in flight do, 876 k against 735 k windows/s at
+    // B = 256, without a second copy of the weights) and fill each other's under-filled launches.  The fields above ARE the
+    // active lane; use_lane() swaps them with `other`.  Rows do not depend on the lane (same kernels, same data).  env C3HIP_RING_LANES=1: one lane.
+    struct Lane {
+        int64_t cap = 0;
+        bool last_planes = false, tail_pending = false;
+        std::vector<DevBuf> bufs;
+        float *act[9] = {};
+        float *spp = nullptr, *part = nullptr, *l4dbg = nullptr, *h1 = nullptr, *gx2 = nullptr, *h2 = nullptr;
+        int64_t last_n = 0;
+        hipStream_t stream = nullptr, tail_stream = nullptr;
+        hipEvent_t ev_body_done = nullptr, ev_tail_done = nullptr;
+    };
+    Lane other;        // the lane that is NOT active
+    int lane_cur = 0;  // which lane the fields above hold
+    int ring_lanes = 1;  // 1 or 2 (set in c3_model_create: the kind's default, or env)
+    int64_t lane_max_batch = 0;  // batches up to this many windows take the lane of their slot, larger ones the first lane (env C3HIP_RING_LANES_MAX_BATCH)
+
     // which kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
     const char *choice_lstm1 = "-", *choice_proj2 = "-", *choice_lstm2 = "-", *choice_fa = "-";
     const char *choice_s2[2] = {"-", "-"};  // conv3, conv5: one or two workgroups per CU (c3_conv3s2.h PAIR)
@@ -225,6 +247,22 @@ struct c3_model {
 };
 
 static int conv_out(int n, int s) { return (n - 1) / s + 1; }
+
+// make lane k the active one (c3_model::Lane): swap everything a forward pass writes with the lane kept aside
+static int use_lane(c3_model *m, int k) {
+    if (k == m->lane_cur) return 0;
+    c3_model::Lane &o = m->other;
+    std::swap(m->cap, o.cap), std::swap(m->last_planes, o.last_planes), std::swap(m->tail_pending, o.tail_pending);
+    m->bufs.swap(o.bufs);
+    for (int l = 0; l < 9; ++l) std::swap(m->act[l], o.act[l]);
+    std::swap(m->spp, o.spp), std::swap(m->part, o.part), std::swap(m->l4dbg, o.l4dbg);
+    std::swap(m->h1, o.h1), std::swap(m->gx2, o.gx2), std::swap(m->h2, o.h2), std::swap(m->last_n, o.last_n);
+    std::swap(m->stream, o.stream), std::swap(m->tail_stream, o.tail_stream);
+    std::swap(m->ev_body_done, o.ev_body_done), std::swap(m->ev_tail_done, o.ev_tail_done);
+    m->lane_cur = k;
+    if (!m->stream) HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));  // (the second lane's kernel stream, on first use)
+    return 0;
+}
 
 static void fa_geometry(const c3_model *m, int hh[10], int ww[10]) {
     hh[0] = m->depth, ww[0] = m->positions;
@@ -392,10 +430,16 @@ static int upload(c3_model *m, float **dst, const std::vector<float> &src) {
     return 0;
 }
 
-static void free_workspace(c3_model *m) {
+static void free_workspace(c3_model *m) {  // the active lane's
     for (auto &b : m->bufs) (void)hipFree(b.p);
     m->bufs.clear();
     m->cap = 0;
+}
+static void free_all_workspaces(c3_model *m) {  // both lanes' (geometry change, destruction)
+    free_workspace(m);
+    for (auto &b : m->other.bufs) (void)hipFree(b.p);
+    m->other.bufs.clear();
+    m->other.cap = 0;
 }
 
 static int64_t max_microbatch(const c3_model *m) { return m->kind == C3_KIND_PILEUP ? 16384 : 2048; }

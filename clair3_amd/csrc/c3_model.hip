@@ -104,6 +104,13 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     // B = 256, 687 -> 705 - 709 k over the driver's 100 steps, 768 -> 778 - 780 k at B = 1000), off for the pileup network (4.09 - 4.14 M -> 4.03 M: a chain
     // beside the next batch's latency-bound LSTM1 slows the recurrence more than it hides)
     m->tail_split = kind == C3_KIND_FULL_ALIGNMENT;
+    // two lanes for the ring (c3_model.h Lane): the kind's default follows the same-box A/B of profiles/r06_i_ab_ring_lanes.txt
+    // (one MI355X, alternating: full alignment ring 728 - 732 k -> 768 - 775 k windows/s at B = 256 but 807 - 809 k -> 768 - 778 k at B = 1000; pileup
+    // 4.24 M -> 4.32 - 4.33 M at B = 1024): two lanes, for batches that do not fill the chip by themselves
+    m->ring_lanes = 2;
+    m->lane_max_batch = kind == C3_KIND_FULL_ALIGNMENT ? 512 : 1024;
+    if (const char *e = getenv("C3HIP_RING_LANES")) m->ring_lanes = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("C3HIP_RING_LANES_MAX_BATCH")) m->lane_max_batch = atoll(e);
     if (const char *e = getenv("C3HIP_TAIL_STREAM")) m->tail_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
     {
@@ -126,7 +133,8 @@ int c3_model_set_geometry(c3_model *m, int depth, int positions) {
     m->depth = depth, m->positions = positions;
     if (m->kind == C3_KIND_PILEUP) m->K4 = positions * 320;
     if (m->K4 % kBK) return fail("unsupported geometry: L4 fan-in %d is not a multiple of %d", m->K4, kBK);
-    free_workspace(m);
+    HIP_TRY(hipDeviceSynchronize());
+    free_all_workspaces(m);
     m->loaded = false;
     return 0;
 }
@@ -211,6 +219,7 @@ int c3_predict_device(c3_model *m, const void *x_dev, int x_dtype, int64_t batch
     // NULL is the HIP null stream itself (what torch's default stream is): work queued there is ordered with the
     // caller's other default-stream work.  Mapping NULL to the model's private non-blocking stream would let a
     // following torch op (y.cpu(), an RCCL gather) overtake the kernels.
+    TRY(use_lane(m, 0));  // (calls on one handle must not overlap: the device-resident entries always work in the first lane)
     return forward_device(m, (hipStream_t)stream, x_dev, x_dtype, batch, y_dev);
 }
 
@@ -220,6 +229,7 @@ int c3_predict_device_checked(c3_model *m, const void *x_dev, int x_dtype, int64
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const bool f16 = m->f16_ok;
+    TRY(use_lane(m, 0));
     TRY(forward_device(m, s, x_dev, x_dtype, batch, y_dev));
     if (!f16 || batch == 0) return 0;
     if (!m->pin_flag) {
@@ -274,6 +284,8 @@ int c3_model_synchronize(c3_model *m) {
     if (!m) return fail("null model");
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->tail_stream) HIP_TRY(hipStreamSynchronize(m->tail_stream));
+    if (m->other.stream) HIP_TRY(hipStreamSynchronize(m->other.stream));
+    if (m->other.tail_stream) HIP_TRY(hipStreamSynchronize(m->other.tail_stream));
     return 0;
 }
 
@@ -281,7 +293,11 @@ int c3_model_destroy(c3_model *m) {
     if (!m) return 0;
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
-    free_workspace(m);
+    free_all_workspaces(m);
+    if (m->other.stream) (void)hipStreamDestroy(m->other.stream);
+    if (m->other.tail_stream) (void)hipStreamDestroy(m->other.tail_stream);
+    if (m->other.ev_body_done) (void)hipEventDestroy(m->other.ev_body_done);
+    if (m->other.ev_tail_done) (void)hipEventDestroy(m->other.ev_tail_done);
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
                    m->l4_w, m->l4_b, m->l4_wf, m->b5, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias, m->conv1_w16,
                    m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_pw, m->proj2_pwr, m->proj2_post, m->conv1_post,

@@ -176,7 +176,8 @@ def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
     """Round 6: a batch of the submit / wait ring runs its FC chain (L4, the split-K sum, the tail, the decoder columns, the copy-out) on
     the handle's tail stream, so that the NEXT batch's first layers are queued behind this batch's last layer, not behind three small
     launches they do not depend on; the next batch waits for the chain only before it overwrites what the chain reads (the pooled tensor /
-    lstm2_out).  Same kernels on the same data: rows bit-identical to C3HIP_TAIL_STREAM=0 and to the blocking call, for batches of
+    lstm2_out); and the ring has TWO lanes (workspace + streams): the batch in slot k runs in lane k & 1 and overlaps its neighbour.  Same
+    kernels on the same data: rows bit-identical to C3HIP_TAIL_STREAM=0 C3HIP_RING_LANES=1 and to the blocking call, for batches of
     different sizes kept in flight on every slot, micro-batches beyond the workspace cap, decoder columns, and with the device-resident
     entry (whose chain stays on the caller's stream) called between rounds."""
     import torch
@@ -185,9 +186,12 @@ def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
     sizes = [300, 17, 256, 1, 129, 64, 511, 33, 256, 256] if kind == syn.FULL_ALIGNMENT else [1024, 9, 4097, 16, 2000, 1, 777, 1024, 1024, 31]
     xs = [syn.make_windows(kind, n, seed=92 + i, channels=ch) for i, n in enumerate(sizes)]
     monkeypatch.setenv("C3HIP_TAIL_STREAM", "0")
-    m0 = make_model(kind, ch, indel, sd)
+    monkeypatch.setenv("C3HIP_RING_LANES", "1")
+    m0 = make_model(kind, ch, indel, sd)  # round 5's ring: one workspace, one kernel stream, every batch strictly behind the one before
     want = [m0.predict_numpy(x) for x in xs]
     monkeypatch.setenv("C3HIP_TAIL_STREAM", "1")  # (the default for full alignment; off by default for the pileup network, where it measured a loss)
+    monkeypatch.setenv("C3HIP_RING_LANES", "2")   # the batch in slot k in lane k & 1: consecutive batches overlap on the chip
+    monkeypatch.setenv("C3HIP_RING_LANES_MAX_BATCH", "100000")  # (by default only batches that leave the chip under-filled: here every size)
     m = make_model(kind, ch, indel, sd)
     for rounds in range(3):
         tickets = []
