@@ -120,11 +120,11 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     if (sl.busy) return fail("slot %d still in flight: call c3_predict_wait first", slot);
     HIP_TRY(hipSetDevice(m->device));
     if (!m->loaded) return fail("model has no weights: call c3_model_load first");
-    // the batch in slot k runs in lane k & 1 (c3_model.h Lane): its own workspace and kernel stream, so that it overlaps the batch of the
+    // the batch in slot k runs in lane k % lanes (c3_model.h Lane): its own workspace and kernel stream, so that it overlaps the batch of the
     // neighbouring slot on the chip; keep mode, the two-halves knob and profiling stay in one lane
     // -- and so does a batch that fills the chip by itself: two of those side by side only get in each other's way (same-box A/B,
     // profiles/r06_i_ab_ring_lanes.txt: full alignment ring +5.5 % at B = 256, -4 % at B = 1000)
-    TRY(use_lane(m, (m->ring_lanes == 2 && batch <= m->lane_max_batch && !m->keep && m->duo == 0 && !m->prof) ? (slot & 1) : 0));
+    TRY(use_lane(m, (m->ring_lanes > 1 && batch <= m->lane_max_batch && !m->keep && m->duo == 0 && !m->prof) ? slot % m->ring_lanes : 0));
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
     const size_t yb = (size_t)batch * m->row * sizeof(float);
     // C3HIP_HOST_COPY_KERNEL: 0 = never, 1 = up to kKernelCopyMax, n > 1 = up to n KB (A/B of the threshold)
@@ -248,6 +248,9 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
     // 750 instead of 128 + 256 + 616: 0.79 -> 0.82 of device-resident; a tail shorter than half the next size joins the last piece
     int64_t next = std::min<int64_t>(std::max<int64_t>(chunk / 2, batch / 4), chunk);
     next = std::max<int64_t>(next, 1);
+    // (Round 6 also tried EQUAL pieces that each take a lane of their own -- three of 334 windows instead of 250 + 750 for the reference's batch of
+    // 1000: 668 - 674 k -> 644 - 646 k windows/s, profiles/r06_i_ab_ring_lanes.txt: the call's one thread stages the pieces one after the other, so
+    // a bigger first piece only starts the kernels later.  Not kept.)
     for (int64_t off = 0; off < batch && rc == 0; ++n_sub) {
         int64_t take = std::min(next, batch - off);
         if (batch - off - take < next / 2 || batch - off - take < chunk / 2) take = batch - off;

@@ -219,9 +219,10 @@ struct c3_model {
     // ---- the ring's second lane (round 6) ----
     // Batches of the submit / wait ring used to run strictly one after the other: ONE workspace and ONE kernel stream per handle.  A lane is
     // everything a forward pass writes -- the workspace, the kernel stream, the tail stream and its events: with two of them the batch in slot
-    // k runs on lane k & 1, consecutive batches overlap on the chip (what three HANDLES in flight do, 876 k against 735 k windows/s at
+    // k runs on lane k % lanes, consecutive batches overlap on the chip (what three HANDLES in flight do, 876 k against 735 k windows/s at
     // B = 256, without a second copy of the weights) and fill each other's under-filled launches.  The fields above ARE the
-    // active lane; use_lane() swaps them with `other`.  Rows do not depend on the lane (same kernels, same data).  env C3HIP_RING_LANES=1: one lane.
+    // active lane; use_lane() parks them and takes another lane's out of `parked`.  Rows do not depend on the lane (same kernels, same data).
+    // env C3HIP_RING_LANES=1: one lane.
     struct Lane {
         int64_t cap = 0;
         bool last_planes = false, tail_pending = false;
@@ -232,9 +233,10 @@ struct c3_model {
         hipStream_t stream = nullptr, tail_stream = nullptr;
         hipEvent_t ev_body_done = nullptr, ev_tail_done = nullptr;
     };
-    Lane other;        // the lane that is NOT active
+    static constexpr int kMaxLanes = 3;  // = the batches a worker keeps in flight (ring of three slots)
+    Lane parked[kMaxLanes];  // the lanes that are NOT active live here (parked[lane_cur] is stale: its contents ARE the fields above)
     int lane_cur = 0;  // which lane the fields above hold
-    int ring_lanes = 1;  // 1 or 2 (set in c3_model_create: the kind's default, or env)
+    int ring_lanes = 1;  // 1 .. kMaxLanes (set in c3_model_create: the kind's default, or env)
     int64_t lane_max_batch = 0;  // batches up to this many windows take the lane of their slot, larger ones the first lane (env C3HIP_RING_LANES_MAX_BATCH)
 
     // which kernel forms the last forward pass took (c3_model_describe; bench.py reports it)
@@ -248,10 +250,8 @@ struct c3_model {
 
 static int conv_out(int n, int s) { return (n - 1) / s + 1; }
 
-// make lane k the active one (c3_model::Lane): swap everything a forward pass writes with the lane kept aside
-static int use_lane(c3_model *m, int k) {
-    if (k == m->lane_cur) return 0;
-    c3_model::Lane &o = m->other;
+// make lane k the active one (c3_model::Lane): park everything a forward pass writes and take lane k's out of the parking lot
+static void lane_exchange(c3_model *m, c3_model::Lane &o) {
     std::swap(m->cap, o.cap), std::swap(m->last_planes, o.last_planes), std::swap(m->tail_pending, o.tail_pending);
     m->bufs.swap(o.bufs);
     for (int l = 0; l < 9; ++l) std::swap(m->act[l], o.act[l]);
@@ -259,8 +259,14 @@ static int use_lane(c3_model *m, int k) {
     std::swap(m->h1, o.h1), std::swap(m->gx2, o.gx2), std::swap(m->h2, o.h2), std::swap(m->last_n, o.last_n);
     std::swap(m->stream, o.stream), std::swap(m->tail_stream, o.tail_stream);
     std::swap(m->ev_body_done, o.ev_body_done), std::swap(m->ev_tail_done, o.ev_tail_done);
+}
+static int use_lane(c3_model *m, int k) {
+    if (k == m->lane_cur) return 0;
+    if (k < 0 || k >= c3_model::kMaxLanes) return fail("lane %d out of range", k);
+    lane_exchange(m, m->parked[m->lane_cur]);  // the active fields -> their parking place (which held nothing that matters)
+    lane_exchange(m, m->parked[k]);            // lane k's -> the active fields
     m->lane_cur = k;
-    if (!m->stream) HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));  // (the second lane's kernel stream, on first use)
+    if (!m->stream) HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));  // (a further lane's kernel stream, on first use)
     return 0;
 }
 
@@ -437,9 +443,12 @@ static void free_workspace(c3_model *m) {  // the active lane's
 }
 static void free_all_workspaces(c3_model *m) {  // both lanes' (geometry change, destruction)
     free_workspace(m);
-    for (auto &b : m->other.bufs) (void)hipFree(b.p);
-    m->other.bufs.clear();
-    m->other.cap = 0;
+    for (int k = 0; k < c3_model::kMaxLanes; ++k) {
+        if (k == m->lane_cur) continue;
+        for (auto &b : m->parked[k].bufs) (void)hipFree(b.p);
+        m->parked[k].bufs.clear();
+        m->parked[k].cap = 0;
+    }
 }
 
 static int64_t max_microbatch(const c3_model *m) { return m->kind == C3_KIND_PILEUP ? 16384 : 2048; }

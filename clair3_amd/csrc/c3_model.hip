@@ -106,10 +106,12 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     m->tail_split = kind == C3_KIND_FULL_ALIGNMENT;
     // two lanes for the ring (c3_model.h Lane): the kind's default follows the same-box A/B of profiles/r06_i_ab_ring_lanes.txt
     // (one MI355X, alternating: full alignment ring 728 - 732 k -> 768 - 775 k windows/s at B = 256 but 807 - 809 k -> 768 - 778 k at B = 1000; pileup
-    // 4.24 M -> 4.32 - 4.33 M at B = 1024): two lanes, for batches that do not fill the chip by themselves
-    m->ring_lanes = 2;
+    // 4.24 M -> 4.32 - 4.33 M at B = 1024): more than one lane, for batches that do not fill the chip by themselves
+    // ... and three against two lanes (run 11, another box): full alignment ring 703 - 704 k (one lane) -> 745 k (two) -> 769 - 770 k (three) at B = 256;
+    // pileup 4.11 - 4.14 M -> 4.23 - 4.26 M (two) -> 4.07 - 4.08 M (three: three recurrences side by side starve each other)
+    m->ring_lanes = kind == C3_KIND_FULL_ALIGNMENT ? 3 : 2;
     m->lane_max_batch = kind == C3_KIND_FULL_ALIGNMENT ? 512 : 1024;
-    if (const char *e = getenv("C3HIP_RING_LANES")) m->ring_lanes = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("C3HIP_RING_LANES")) m->ring_lanes = std::min(std::max(atoi(e), 1), (int)c3_model::kMaxLanes);
     if (const char *e = getenv("C3HIP_RING_LANES_MAX_BATCH")) m->lane_max_batch = atoll(e);
     if (const char *e = getenv("C3HIP_TAIL_STREAM")) m->tail_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
@@ -284,8 +286,11 @@ int c3_model_synchronize(c3_model *m) {
     if (!m) return fail("null model");
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->tail_stream) HIP_TRY(hipStreamSynchronize(m->tail_stream));
-    if (m->other.stream) HIP_TRY(hipStreamSynchronize(m->other.stream));
-    if (m->other.tail_stream) HIP_TRY(hipStreamSynchronize(m->other.tail_stream));
+    for (int k = 0; k < c3_model::kMaxLanes; ++k) {
+        if (k == m->lane_cur) continue;
+        if (m->parked[k].stream) HIP_TRY(hipStreamSynchronize(m->parked[k].stream));
+        if (m->parked[k].tail_stream) HIP_TRY(hipStreamSynchronize(m->parked[k].tail_stream));
+    }
     return 0;
 }
 
@@ -294,10 +299,13 @@ int c3_model_destroy(c3_model *m) {
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
     free_all_workspaces(m);
-    if (m->other.stream) (void)hipStreamDestroy(m->other.stream);
-    if (m->other.tail_stream) (void)hipStreamDestroy(m->other.tail_stream);
-    if (m->other.ev_body_done) (void)hipEventDestroy(m->other.ev_body_done);
-    if (m->other.ev_tail_done) (void)hipEventDestroy(m->other.ev_tail_done);
+    for (int k = 0; k < c3_model::kMaxLanes; ++k) {
+        if (k == m->lane_cur) continue;
+        if (m->parked[k].stream) (void)hipStreamDestroy(m->parked[k].stream);
+        if (m->parked[k].tail_stream) (void)hipStreamDestroy(m->parked[k].tail_stream);
+        if (m->parked[k].ev_body_done) (void)hipEventDestroy(m->parked[k].ev_body_done);
+        if (m->parked[k].ev_tail_done) (void)hipEventDestroy(m->parked[k].ev_tail_done);
+    }
     float *ws[] = {m->proj_w[0], m->proj_w[1], m->proj_b[0], m->proj_b[1], m->whh[0], m->whh[1], m->whh16[0], m->whh16[1],
                    m->l4_w, m->l4_b, m->l4_wf, m->b5, m->zeros, m->l1_wih, m->l1_wih16, m->l1_bias, m->conv1_w16,
                    m->conv1_wfrag16, m->w5f, m->whf, m->bh48, m->proj2_pw, m->proj2_pwr, m->proj2_post, m->conv1_post,

@@ -190,7 +190,7 @@ def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
     m0 = make_model(kind, ch, indel, sd)  # round 5's ring: one workspace, one kernel stream, every batch strictly behind the one before
     want = [m0.predict_numpy(x) for x in xs]
     monkeypatch.setenv("C3HIP_TAIL_STREAM", "1")  # (the default for full alignment; off by default for the pileup network, where it measured a loss)
-    monkeypatch.setenv("C3HIP_RING_LANES", "2")   # the batch in slot k in lane k & 1: consecutive batches overlap on the chip
+    monkeypatch.setenv("C3HIP_RING_LANES", "3")   # the batch in slot k in lane k % 3: consecutive batches overlap on the chip
     monkeypatch.setenv("C3HIP_RING_LANES_MAX_BATCH", "100000")  # (by default only batches that leave the chip under-filled: here every size)
     m = make_model(kind, ch, indel, sd)
     for rounds in range(3):
