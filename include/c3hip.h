@@ -122,7 +122,9 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
  * (c3_predict_device_checked does; c3_model_range_status reports). */
 #define C3_HOST_SLOTS 4
 /* asynchronous pair, slot in [0, C3_HOST_SLOTS): submit copies x into pinned staging and enqueues H2D + kernels + D2H;
- * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns. */
+ * wait blocks until y_host of that slot is complete. x_host may be reused as soon as submit returns.  Batches in different slots
+ * may run side by side on the device (the handle keeps up to three lanes -- workspace + streams -- for batches that do not fill the
+ * chip by themselves; C3HIP_RING_LANES): rows never depend on the slot, the lane or the batch a window travels in. */
 int c3_predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t batch, float *y_host, int slot);
 int c3_predict_wait(c3_model *m, int slot);
 /* The same ring with the rows LEFT ON THE DEVICE: y_dev is a device pointer on the model's device (batch x c3_model_row_size()
