@@ -273,12 +273,13 @@ int c3_model_set_sharing(c3_model *m, int handles) {
 int c3_model_describe(c3_model *m, char *buf, int n) {
     if (!m || !buf || n <= 0) return fail("null argument");
     if (m->kind == C3_KIND_PILEUP)
-        snprintf(buf, (size_t)n, "sharing=%d duo=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d precision=%s lstm_wmax=%.4g lstm_hh_norm=%.4g auto_fp32_at=%.4g", m->sharing,
+        snprintf(buf, (size_t)n, "sharing=%d duo=%d lstm1=%s proj2=%s lstm2=%s on_fp32=%d precision=%s lstm_wmax=%.4g lstm_hh_norm=%.4g auto_fp32_at=%.4g "
+                 "ring_lanes=%d lane_max_batch=%lld tail_stream=%d", m->sharing,
                  m->duo, m->choice_lstm1, m->choice_proj2, m->choice_lstm2, (int)!m->f16_ok, m->precision, (double)m->lstm_wmax, (double)m->lstm_hh_norm,
-                 (double)(m->precision_forced ? 0.f : m->auto_fp32_at));
+                 (double)(m->precision_forced ? 0.f : m->auto_fp32_at), m->ring_lanes, (long long)m->lane_max_batch, (int)m->tail_split);
     else
-        snprintf(buf, (size_t)n, "sharing=%d duo=%d conv_stack=%s stride1=%s conv3=%s conv5=%s on_fp32=%d", m->sharing, m->duo, m->choice_fa, m->choice_s1,
-                 m->choice_s2[0], m->choice_s2[1], (int)!m->f16_ok);
+        snprintf(buf, (size_t)n, "sharing=%d duo=%d conv_stack=%s stride1=%s conv3=%s conv5=%s on_fp32=%d ring_lanes=%d lane_max_batch=%lld tail_stream=%d", m->sharing,
+                 m->duo, m->choice_fa, m->choice_s1, m->choice_s2[0], m->choice_s2[1], (int)!m->f16_ok, m->ring_lanes, (long long)m->lane_max_batch, (int)m->tail_split);
     return 0;
 }
 

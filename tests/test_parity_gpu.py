@@ -193,6 +193,8 @@ def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
     monkeypatch.setenv("C3HIP_RING_LANES", "3")   # the batch in slot k in lane k % 3: consecutive batches overlap on the chip
     monkeypatch.setenv("C3HIP_RING_LANES_MAX_BATCH", "100000")  # (by default only batches that leave the chip under-filled: here every size)
     m = make_model(kind, ch, indel, sd)
+    assert "ring_lanes=1" in m0.describe() and "tail_stream=0" in m0.describe()
+    assert "ring_lanes=3 lane_max_batch=100000 tail_stream=1" in m.describe(), m.describe()
     for rounds in range(3):
         tickets = []
         got = [None] * len(xs)
