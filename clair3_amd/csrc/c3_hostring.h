@@ -251,9 +251,23 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
     // (Round 6 also tried EQUAL pieces that each take a lane of their own -- three of 334 windows instead of 250 + 750 for the reference's batch of
     // 1000: 668 - 674 k -> 644 - 646 k windows/s, profiles/r06_i_ab_ring_lanes.txt: the call's one thread stages the pieces one after the other, so
     // a bigger first piece only starts the kernels later.  Not kept.)
+    // C3HIP_PREDICT_PIECES=a,b,c: A/B knob -- the piece sizes themselves (the last one repeats)
+    static const std::vector<int64_t> forced = [] {
+        std::vector<int64_t> v;
+        if (const char *e = getenv("C3HIP_PREDICT_PIECES"))
+            for (const char *q = e; *q;) {
+                char *end = nullptr;
+                const long long n = strtoll(q, &end, 10);
+                if (end == q) break;
+                if (n > 0) v.push_back(n);
+                q = *end ? end + 1 : end;
+            }
+        return v;
+    }();
     for (int64_t off = 0; off < batch && rc == 0; ++n_sub) {
         int64_t take = std::min(next, batch - off);
         if (batch - off - take < next / 2 || batch - off - take < chunk / 2) take = batch - off;
+        if (!forced.empty()) take = std::min<int64_t>(forced[std::min<size_t>((size_t)n_sub, forced.size() - 1)], batch - off);
         take = std::min(take, max_microbatch(m));
         if (n_sub - n_done == kRing) rc = c3_predict_wait(m, (int)(n_done++ % kRing));
         if (rc == 0)
