@@ -215,6 +215,18 @@ def test_texts_of_other_kinds_and_odd_inputs(ref):
     texts, todo = pr._rows_c(pos, odd_alt, y)
     assert {0, 1, 2, 3, 4} <= set(todo)
     assert pr._rows_c([pos[0], "a\0b:1:" + "A" * 33], [alt[0], alt[1]], y[:2]) is None  # a NUL inside a text
+    # more distinct alleles than the C pass keeps per row (192): handed back, printed by the per-row path, same text as without the pass
+    many = "900-" + " ".join(f"I{pos[5].split(':')[-1][16]}{'ACGT'[i % 4]}{'A' * (i // 4)} {1 + i % 7}" for i in range(250)) + " XA 40 XC 7 "
+    big_alt = list(alt)
+    big_alt[5] = many
+    texts, todo = pr._rows_c(pos, big_alt, y)
+    assert 5 in todo and pr.rows(pos, big_alt, y) == pr._rows_py(pos, big_alt, y)
+    # a very long contig name and a very long allele: the output buffer is sized from the texts
+    long_pos = list(pos)
+    long_pos[7] = "contig_" + "x" * 5000 + ":" + ":".join(pos[7].split(":")[-2:])
+    long_alt = list(alt)
+    long_alt[7] = "50-I" + pos[7].split(":")[-1][16] + "ACGT" * 40 + " 30 D" + "GATTACA" * 30 + " 12 XT 5 "
+    assert pr.rows(long_pos, long_alt, y) == pr._rows_py(long_pos, long_alt, y)
     assert pr.rows([], [], y[:0]) == []
     # a strided view of the rows (the loop hands slices of its shared-memory block)
     big = np.zeros((len(y), y.shape[1] + 7), np.float32)
