@@ -56,12 +56,15 @@ def _share_hip_runtime_with_torch():
     ("No HIP GPUs are available").  Pre-loading torch's copy (without importing torch) makes libc3hip's
     NEEDED libamdhip64.so.7 resolve to it, so both share one runtime whatever the import order.  Without
     torch installed nothing happens and /opt/rocm's runtime is used."""
-    import importlib.util
+    import importlib.machinery
     import sys
-    if "torch" in sys.modules:
+    from . import lazy_torch
+    if "torch" in sys.modules and not lazy_torch.standing_in():
         return
+    # (PathFinder, not importlib.util.find_spec: with lazy_torch's stand-in in sys.modules the latter looks at ITS __spec__; the package
+    # may still be imported later in this process, and must then find the runtime it expects)
     try:
-        spec = importlib.util.find_spec("torch")
+        spec = importlib.machinery.PathFinder.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if spec is None or not spec.submodule_search_locations:

@@ -23,15 +23,16 @@ import os
 import sys
 
 from . import _lib, predict
+from . import lazy_torch as _lazy
 from .model import Clair3_F, Clair3_P
 
 
 def _select_device_for_worker(use_gpu):
     """CallVariantsFromCffi._select_device: the worker only uses the result as an opaque handle that is passed
     back to _torch_predict / model.to(), so a string is enough; CPU requests stay with the reference."""
-    import torch
     if use_gpu and _lib.device_count() > 0:
         return "cuda:0"
+    import torch
     return torch.device("cpu")
 
 
@@ -193,15 +194,32 @@ def _make_batch_generator(original):
 PREFETCH_DEPTH = int(os.environ.get("C3HIP_PREFETCH_DEPTH", "2"))
 
 
-def install(worker=True, gpu_wrapper=True, decoder=False):
+def install(worker=True, gpu_wrapper=True, decoder=False, lazy_torch=None):
     """Patch the imported (or importable) reference modules in place.  Returns the list of rebound names.
     decoder=True additionally makes the rows of either network carry the decoder columns of libc3hip and
     rebinds clair3.CallVariants.possible_outcome_probabilites_from / batch_output to read them
     (clair3_amd/decode.py): same VCF text, ~6x the decode rate per host core on rows with the indel-length heads, ~2x on
-    the 24-probability rows of the pileup network."""
+    the 24-probability rows of the pileup network.  lazy_torch (default: C3HIP_LAZY_TORCH, on): see below."""
     done = []
-    import clair3.model as ref_model
-    ref_model.Clair3_P, ref_model.Clair3_F = Clair3_P, Clair3_F
+    # ``import torch`` is 1.2 - 1.9 s of a worker process that, with these names rebound, never uses it (lazy_torch.py): when the package
+    # has not been imported yet, a stand-in takes its place that imports it on first real use, and clair3.model -- whose classes are
+    # replaced anyway, and whose import needs torch.nn -- is stood in for the same way
+    if lazy_torch is None:
+        lazy_torch = _lazy.wanted()
+    if lazy_torch and _lazy.install() and "clair3.model" not in sys.modules:
+        import importlib
+        import clair3
+
+        def load_reference_models():
+            sys.modules.pop("clair3.model", None)
+            real = importlib.import_module("clair3.model")
+            real.Clair3_P, real.Clair3_F = Clair3_P, Clair3_F
+            return real
+        clair3.model = sys.modules["clair3.model"] = _lazy.standin_module("clair3.model", {"Clair3_P": Clair3_P, "Clair3_F": Clair3_F},
+                                                                          load_reference_models)
+    else:
+        import clair3.model as ref_model
+        ref_model.Clair3_P, ref_model.Clair3_F = Clair3_P, Clair3_F
     done += ["clair3.model.Clair3_P", "clair3.model.Clair3_F"]
     if worker:
         import clair3.CallVariantsFromCffi as w

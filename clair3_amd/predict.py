@@ -10,12 +10,23 @@ from .model import Clair3_F, Clair3_P, _device_index
 
 
 def _load_torch_checkpoint(model, checkpoint_path, device=None):
-    """clair3/CallVariantsFromCffi.py:19-28: append '.pt' when missing, torch.load, accept a bare state_dict or
-    {"state_dict": ...}, strict load.  torch is only used to deserialise the file (map_location='cpu')."""
-    import torch
+    """clair3/CallVariantsFromCffi.py:19-28: append '.pt' when missing, deserialise, accept a bare state_dict or {"state_dict": ...},
+    strict load.  The file is read by clair3_amd/ptfile.py (numpy only: a worker process that never needs torch never imports it,
+    clair3_amd/lazy_torch.py); what that reader does not handle -- the legacy non-zip format, exotic dtypes, pickled modules -- goes to
+    torch.load(map_location='cpu') as before (C3HIP_PTFILE=0: always)."""
+    import os
+    from . import ptfile
     if not checkpoint_path.endswith('.pt'):
         checkpoint_path = checkpoint_path + '.pt'
-    checkpoint = torch.load(checkpoint_path, map_location="cpu")
+    checkpoint = None
+    if os.environ.get("C3HIP_PTFILE", "1").strip().lower() not in ("0", "false", "no", "off"):
+        try:
+            checkpoint = ptfile.load(checkpoint_path)
+        except ptfile.Unsupported:
+            checkpoint = None
+    if checkpoint is None:
+        import torch
+        checkpoint = torch.load(checkpoint_path, map_location="cpu")
     if isinstance(checkpoint, dict) and "state_dict" in checkpoint:
         state_dict = checkpoint["state_dict"]
     else:

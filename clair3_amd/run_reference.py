@@ -36,7 +36,9 @@ def main(argv=None):
     if do_install:
         from clair3_amd import callvar
         names = callvar.install(decoder=decoder)
-        print("[clair3_amd] rebound: " + ", ".join(names), file=sys.stderr)
+        from clair3_amd import lazy_torch
+        print("[clair3_amd] rebound: " + ", ".join(names) + ("; torch is imported on first use" if lazy_torch.status()["installed"] else ""),
+              file=sys.stderr)
     sys.argv = [os.path.join(ref, "clair3.py")] + argv
     runpy.run_path(sys.argv[0], run_name="__main__")
 

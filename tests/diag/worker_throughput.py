@@ -33,16 +33,25 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
     ck = os.path.join(d, "model")
     refloop.write_checkpoint(ck + ".pt", kind, channels, indel)
     res = {}
-    for tag, kw in (("libc3hip", dict(hip=True)), ("libc3hip_decoder_columns", dict(hip=True, decoder=True)), ("reference_modules_pytorch", dict(hip=False))):
+    # (round 6: a worker process on libc3hip no longer imports torch -- clair3_amd/lazy_torch.py, ptfile.py; the *_torch_imported leg is
+    # the same command with C3HIP_LAZY_TORCH=0 C3HIP_PTFILE=0, i.e. the process as it was)
+    for tag, kw in (("libc3hip", dict(hip=True)), ("libc3hip_decoder_columns", dict(hip=True, decoder=True)),
+                    ("libc3hip_decoder_columns_torch_imported", dict(hip=True, decoder=True, extra_env={"C3HIP_LAZY_TORCH": "0", "C3HIP_PTFILE": "0"})),
+                    ("reference_modules_pytorch", dict(hip=False))):
         if legs and tag not in legs.split(","):
             continue
         vcf = os.path.join(d, tag + ".vcf")
+        report = os.path.join(d, tag + ".torch.json")
+        kw = dict(kw, extra_env=dict(kw.get("extra_env") or {}, C3HIP_LAZY_TORCH_REPORT=report))
         t0 = time.perf_counter()
         rc, log = refloop.run_worker(ref, lst, ck, vcf, pileup, indel, cpu_threads=threads, **kw)
         wall = time.perf_counter() - t0
         m = re.search(r"Total time elapsed: ([0-9.]+) s", log)
         assert rc == 0 and f"Total processed positions : {n}" in log, log[-2000:]
-        res[tag] = {"loop_seconds": float(m.group(1)), "process_wall_seconds": round(wall, 2), "windows_per_s_in_the_loop": round(n / float(m.group(1)))}
+        res[tag] = {"loop_seconds": float(m.group(1)), "process_wall_seconds": round(wall, 2), "windows_per_s_in_the_loop": round(n / float(m.group(1))),
+                    "windows_per_s_of_the_process": round(n / wall)}
+        if os.path.exists(report):
+            res[tag]["torch_imported"] = json.load(open(report))["real_loaded"]
     if legs:
         out[name] = {"windows": n, "tensor_files": files, "cpu_threads": threads, **res}
         print(name, json.dumps(out[name]), flush=True)
@@ -63,6 +72,9 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
         from tests.test_reference_loop_gpu import explain_call_differences, file_window
         job = dict(ck=ck, kind=kind, channels=channels, indel=indel, window=file_window(d, [per_file * (3 if pileup else 1)] * files))
         res["vcf_call_differs_explained"] = explain_call_differences(job, cmp_["call_differs"], ref)
+    if "libc3hip_decoder_columns_torch_imported" in res:
+        cmp3 = refloop.compare_vcfs(os.path.join(d, "libc3hip_decoder_columns_torch_imported.vcf"), os.path.join(d, "libc3hip_decoder_columns.vcf"))
+        res["vcf_torch_imported_vs_not_identical"] = [cmp3["identical_text"], cmp3["records_a"], cmp3["records_b"]]
     if "libc3hip_decoder_columns" in res:
         cmp2 = refloop.compare_vcfs(os.path.join(d, "libc3hip_decoder_columns.vcf"), os.path.join(d, "libc3hip.vcf"))
         res["vcf_decoder_columns_vs_plain_identical"] = [cmp2["identical_text"], cmp2["records_a"], cmp2["records_b"]]

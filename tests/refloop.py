@@ -88,7 +88,7 @@ def write_pipe_tensors(path, kind, n, channels=None, seed=0):
     return n
 
 
-def run_legacy_worker(ref, tensor_txt, chkpnt, call_fn, pileup, indel, hip=True, decoder=False, timeout=900):
+def run_legacy_worker(ref, tensor_txt, chkpnt, call_fn, pileup, indel, hip=True, decoder=False, timeout=900, extra_env=None):
     """the reference's stdin-pipe worker (``clair3.py CallVariants --tensor_fn PIPE``, clair3/CallVariants.py:1456-1621), on
     libc3hip (--use_gpu True after install()) or on its own modules on the CPU; returns (returncode, stdout + stderr)"""
     cmd = [sys.executable, "-m", "clair3_amd.run_reference", "--ref", ref]
@@ -102,6 +102,7 @@ def run_legacy_worker(ref, tensor_txt, chkpnt, call_fn, pileup, indel, hip=True,
         cmd.append("--pileup")
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([ROOT, STUBS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+    env.update(extra_env or {})
     with open(tensor_txt) as stdin:
         r = subprocess.run(cmd, env=env, stdin=stdin, capture_output=True, text=True, timeout=timeout, cwd=os.path.dirname(call_fn))
     return r.returncode, r.stdout + r.stderr

@@ -143,11 +143,32 @@ def test_unmodified_worker_command_on_libc3hip(name, ref, jobs):
     kind, channels, indel, pileup, dwell, sizes = CASES[name]
     job = jobs(name)
     got = os.path.join(job["dir"], "hip.vcf")
-    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, dwell=dwell, hip=True)
+    report = os.path.join(job["dir"], "torch_report.json")
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, dwell=dwell, hip=True, extra_env={"C3HIP_LAZY_TORCH_REPORT": report})
     assert rc == 0, out[-3000:]
     assert "tensor_generator_for_chunk" in out  # install() ran in that process
     assert f"Total processed positions : {sum(sizes)}" in out, out[-3000:]
     check(name, job, got, out, "hip")
+    # round 6: the whole worker process -- argument parsing, the loader (clair3_amd/ptfile.py), the loop, its decode pool -- ran without
+    # ever importing torch (clair3_amd/lazy_torch.py: a stand-in answered Run()'s thread counts and torch.device("cpu"))
+    assert "torch is imported on first use" in out
+    assert json.load(open(report)) == {"installed": True, "real_loaded": False, "first_touch": None}
+
+
+def test_the_worker_with_torch_imported_up_front_prints_the_same_vcf(ref, jobs):
+    """C3HIP_LAZY_TORCH=0 C3HIP_PTFILE=0 (the process as it was before round 6: torch imported by the reference's modules, the checkpoint
+    read by torch.load): character for character the VCF of the default run"""
+    job = jobs("full_alignment")
+    got, report = os.path.join(job["dir"], "hip_eager.vcf"), os.path.join(job["dir"], "torch_report_eager.json")
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, False, True, hip=True,
+                                 extra_env={"C3HIP_LAZY_TORCH": "0", "C3HIP_PTFILE": "0", "C3HIP_LAZY_TORCH_REPORT": report})
+    assert rc == 0, out[-3000:]
+    assert "torch is imported on first use" not in out and not os.path.exists(report)  # no stand-in: nothing to report
+    check("full_alignment", job, got, out, "hip_eager")
+    plain = os.path.join(job["dir"], "hip.vcf")
+    if os.path.exists(plain):
+        t = refloop.compare_vcfs(got, plain)
+        assert t["identical_text"] == t["records_a"] == t["records_b"], t
 
 
 def test_blocking_calls_without_the_lookahead_generator(ref, jobs):
@@ -211,8 +232,10 @@ def test_legacy_stdin_worker_on_libc3hip(name, decoder, ref, tmp_path):
     want, got = os.path.join(d, "reference_cpu.vcf"), os.path.join(d, "hip.vcf")
     rc, out = refloop.run_legacy_worker(ref, txt, ck, want, pileup, indel, hip=False)
     assert rc == 0 and f"Total processed positions in None : {n}" in out, out[-3000:]
-    rc, out = refloop.run_legacy_worker(ref, txt, ck, got, pileup, indel, hip=True, decoder=decoder)
+    report = os.path.join(d, "torch_report.json")
+    rc, out = refloop.run_legacy_worker(ref, txt, ck, got, pileup, indel, hip=True, decoder=decoder, extra_env={"C3HIP_LAZY_TORCH_REPORT": report})
     assert rc == 0 and f"Total processed positions in None : {n}" in out, out[-3000:]
+    assert json.load(open(report)) == {"installed": True, "real_loaded": False, "first_touch": None}  # this worker too never imports torch
     assert "clair3.CallVariants._torch_predict" in out  # run_reference lists what install() rebound
     x_all = syn.make_windows(kind, n, seed=40, channels=channels)  # what refloop.write_pipe_tensors wrote
     job = dict(want=want, n=n, ref_s=None, ck=ck, kind=kind, channels=channels, indel=indel,
