@@ -1,6 +1,6 @@
 """``import torch`` postponed until something needs it.
 
-The reference's stage-B worker is a process per chunk (clair3/CallVariantsFromCffiGPU.py:163-199), and its modules ``import torch`` at the
+The reference's stage-B worker is a process per GPU slot and stage (clair3/CallVariantsFromCffiGPU.py:138-199), and its modules ``import torch`` at the
 top (clair3/CallVariantsFromCffi.py:5, clair3/CallVariants.py:4).  With the model call, the loader and the device selection rebound to
 libc3hip (clair3_amd/callvar.py) and the checkpoint read by clair3_amd/ptfile.py, what the UNMODIFIED worker still asks torch for on the
 GPU branch is

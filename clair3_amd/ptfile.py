@@ -1,7 +1,7 @@
 """A checkpoint file of ``torch.save`` read without importing torch (numpy + zipfile + a restricted unpickler).
 
-Why: the reference's stage-B worker is one PROCESS per chunk (clair3/CallVariantsFromCffiGPU.py:163-199 builds one command per tensor-file
-group), and with the model call in libc3hip a 120 000-window chunk is 0.2 s of loop inside a 1.7 s process -- 1.2 - 1.5 s of it ``import
+Why: the reference's stage-B worker is one PROCESS per GPU slot and stage (clair3/CallVariantsFromCffiGPU.py:138-199 builds one command per
+group of tensor files), and with the model call in libc3hip a 120 000-window job is 0.2 s of loop inside a 1.7 s process -- 1.2 - 1.5 s of it ``import
 torch``, whose only remaining job on this path is to deserialise the ``.pt`` file (clair3/CallVariantsFromCffi.py:19-28).  This module does
 that job: ``load(path)`` returns what ``torch.load(path, map_location="cpu")`` returns, with every tensor as a numpy array.
 
