@@ -151,7 +151,7 @@ class RowPrinter:
     def __init__(self, cv, output_config):
         c = output_config
         self.cv, self.cfg = cv, c
-        self.usable = not (c.is_debug or c.gvcf or c.is_haploid_precise_mode_enabled or c.is_haploid_sensitive_mode_enabled
+        self.usable = not (c.is_debug or c.is_haploid_precise_mode_enabled or c.is_haploid_sensitive_mode_enabled
                            or c.enable_long_indel or c.is_output_for_ensemble or c.input_probabilities)
         self.width = 90 if c.add_indel_length else 24
         self.flank = cv.param.flankingBaseNum
@@ -193,6 +193,17 @@ class RowPrinter:
         # quality_score_from (:375-381) computes (1.0 - p) on a numpy float32 scalar: float32 arithmetic under numpy >= 2, double before
         cf.f32_arith = int((1.0 - np.float32(0.25)).dtype == np.float32)
         cf.walk = int(os.environ.get("C3HIP_ROWS_C_WALK", "1").strip().lower() not in ("0", "false", "no", "off"))
+        if c.gvcf:  # the PL field (compute_PL :1397-1454): the label tables and the base dictionary the C side was written for
+            labels = ["AA", "AC", "AG", "AT", "CC", "CG", "CT", "GG", "GT", "TT", "DelDel", "ADel", "CDel", "GDel", "TDel", "InsIns", "AIns", "CIns",
+                      "GIns", "TIns", "InsDel"]
+            try:
+                same = [cv.gt21_enum_from_label(x) for x in labels] == list(range(21)) and \
+                    "".join(cv.BASE2ACGT[b] for b in "ACGTURYSWKMBDHVN") == "ACGTTACCAGACAAAA" and len(cv.BASE2ACGT) == 16
+            except (KeyError, AttributeError):
+                same = False
+            if not same:
+                return None
+        cf.gvcf = int(bool(c.gvcf))
         for k, g in enumerate(self.gt + [self.gt_multi]):
             cf.gt[k].value = g.encode()
         self._lib = L
@@ -371,7 +382,7 @@ class RowPrinter:
         return r, "{},{}".format(r[0], ibases + r[1:])
 
     # ------------------------------------------------------------------------------------------------ the tail of output_with
-    def _row(self, cls, ref, alt, prob, chromosome, position, depth, d):
+    def _row(self, cls, ref, alt, prob, chromosome, position, depth, d, y_row=None):
         """the text of output_with (:1176-1394) for a row of class ``cls`` with alleles (ref, alt) and maximum probability
         ``prob`` (the float32 scalar), or None where it prints nothing"""
         cv, c = self.cv, self.cfg
@@ -463,6 +474,10 @@ class RowPrinter:
                 alt = cv.convert_iupac_to_n(alt)
         ad = str(ref_count) + (("," + ",".join([str(n) for n in counts])) if len(counts) else "")  # :1357-1360
         afs = "%.4f" % af if len(counts) <= 1 else ",".join(["%.4f" % (min(1.0, 1.0 * n / depth)) for n in counts])
+        if c.gvcf:  # :1360-1378 -- the PL field; compute_PL (:1397-1454) is the reference's own, on the row's own float32 slices
+            pls = ",".join([str(x) for x in cv.compute_PL(gt, y_row[21:24], y_row[:21], ref, alt)])
+            return "%s\t%d\t.\t%s\t%s\t%.2f\t%s\t%s\tGT:GQ:DP:AD:AF:PL\t%s:%d:%d:%s:%s:%s\n" % (
+                chromosome, position, ref, alt, qual, filt, self.info, gt, qual, depth, ad, afs, pls)
         return "%s\t%d\t.\t%s\t%s\t%.2f\t%s\t%s\tGT:GQ:DP:AD:AF\t%s:%d:%d:%s:%s\n" % (
             chromosome, position, ref, alt, qual, filt, self.info, gt, qual, depth, ad, afs)
 
@@ -529,12 +544,12 @@ class RowPrinter:
             c = cls[i]
             acgt = "ACGT"[bi[i]]
             if c == 0:  # homo reference, early exit or not (:702-707, :735-740): both alleles are the A/C/G/T form of the base
-                out[i] = self._row(0, acgt, acgt, prob[i], chromosome, position, depth, d)
+                out[i] = self._row(0, acgt, acgt, prob[i], chromosome, position, depth, d, batch_Y[i])
                 continue
             look = _Lookups(self.cv, d, self.cfg.maximum_variant_length_that_need_infer)
             alleles = self._alleles(c, pos[i], ref, look)
             if alleles is not None:
-                out[i] = self._row(c, alleles[0], alleles[1], prob[i], chromosome, position, depth, d)
+                out[i] = self._row(c, alleles[0], alleles[1], prob[i], chromosome, position, depth, d, batch_Y[i])
                 continue
             walks.append((i, c, ref, look, chromosome, position, depth, d, acgt))
         if walks:
@@ -555,10 +570,10 @@ class RowPrinter:
                     continue
                 self.retried += 1
                 if found is None:  # nothing above the homo-reference probability is offered by the reads (:735-740)
-                    out[i] = self._row(0, acgt, acgt, homo[j], chromosome, position, depth, d)
+                    out[i] = self._row(0, acgt, acgt, homo[j], chromosome, position, depth, d, batch_Y[i])
                 else:
                     c, alleles, p = found
-                    out[i] = self._row(c, alleles[0], alleles[1], p, chromosome, position, depth, d)
+                    out[i] = self._row(c, alleles[0], alleles[1], p, chromosome, position, depth, d, batch_Y[i])
         back = sum(1 for v in out if v is FALLBACK)
         self.handed_back += back
         self.taken += n - back

@@ -22,6 +22,7 @@ threads = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 ref = refloop.reference_root()
 out = {}
 only = os.environ.get("C3_WT_ONLY")  # "pileup" / "full_alignment": one of the two jobs
+extra_args = os.environ.get("C3_WT_EXTRA_ARGS", "").split()  # e.g. "--gvcf True": appended to every worker command
 legs = os.environ.get("C3_WT_LEGS")  # e.g. "libc3hip_decoder_columns": these legs alone, timing only (no VCF comparison)
 for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMENT, 8, True, False), ("pileup", syn.PILEUP, 18, False, True)):
     if only and only != name:
@@ -44,7 +45,7 @@ for name, kind, channels, indel, pileup in (("full_alignment", syn.FULL_ALIGNMEN
         report = os.path.join(d, tag + ".torch.json")
         kw = dict(kw, extra_env=dict(kw.get("extra_env") or {}, C3HIP_LAZY_TORCH_REPORT=report))
         t0 = time.perf_counter()
-        rc, log = refloop.run_worker(ref, lst, ck, vcf, pileup, indel, cpu_threads=threads, **kw)
+        rc, log = refloop.run_worker(ref, lst, ck, vcf, pileup, indel, cpu_threads=threads, extra_args=extra_args, **kw)
         wall = time.perf_counter() - t0
         m = re.search(r"Total time elapsed: ([0-9.]+) s", log)
         assert rc == 0 and f"Total processed positions : {n}" in log, log[-2000:]

@@ -50,7 +50,7 @@ def write_checkpoint(path, kind, channels, indel, seed=2, peaked=True, **kw):
 
 
 def run_worker(ref, lst, chkpnt, call_fn, pileup, indel, dwell=False, hip=True, decoder=False, cpu_threads=3, gpu_id="0",
-               timeout=900, extra_env=None):
+               timeout=900, extra_env=None, extra_args=()):
     """one run of the reference's stage-B worker command; returns (returncode, stdout + stderr)"""
     cmd = [sys.executable, "-m", "clair3_amd.run_reference", "--ref", ref]
     if not hip:
@@ -68,6 +68,7 @@ def run_worker(ref, lst, chkpnt, call_fn, pileup, indel, dwell=False, hip=True, 
         cmd.append("--add_indel_length")
     if dwell:
         cmd += ["--enable_dwell_time", "True"]
+    cmd += list(extra_args)
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([ROOT, STUBS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
     env.update(extra_env or {})
@@ -138,7 +139,10 @@ def compare_vcfs(path_a, path_b, qual_tol=0.02):
         dq = abs(float(ra[5]) - float(rb[5]))
         s["max_qual_diff"] = max(s["max_qual_diff"], dq)
         same_call = ra[:5] == rb[:5] and fa.get("GT") == fb.get("GT") and ra[7] == rb[7] and \
-            {k2: v for k2, v in fa.items() if k2 != "GQ"} == {k2: v for k2, v in fb.items() if k2 != "GQ"}
+            {k2: v for k2, v in fa.items() if k2 not in ("GQ", "PL")} == {k2: v for k2, v in fb.items() if k2 not in ("GQ", "PL")}
+        if same_call and "PL" in fa:  # --gvcf: ceil() of phred-scaled likelihoods -- like GQ, a value may sit on either side of an integer
+            pa, pb = fa["PL"].split(","), fb.get("PL", "").split(",")
+            same_call = len(pa) == len(pb) and all(x.isdigit() and z.isdigit() and abs(int(x) - int(z)) <= 1 for x, z in zip(pa, pb))
         if same_call and dq <= qual_tol and abs(int(fa.get("GQ", 0)) - int(fb.get("GQ", 0))) <= 1:
             s["qual_only"] += 1
         else:

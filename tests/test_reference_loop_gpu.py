@@ -200,6 +200,25 @@ def test_decoder_columns_through_the_reference_loop(name, ref, jobs):
     assert s["records_a"] > 0
 
 
+@pytest.mark.parametrize("name", ["full_alignment", "pileup"])
+def test_gvcf_rows_through_the_worker_command(name, ref, jobs):
+    """--gvcf True (rows carry the PL field, clair3/CallVariants.py:1360-1378): the worker command on libc3hip with the decoder columns --
+    c3_vcf_rows computes compute_PL (:1397-1454) from the row's own probabilities -- against the same command on the reference's modules"""
+    kind, channels, indel, pileup, dwell, sizes = CASES[name]
+    job = dict(jobs(name))
+    want, got = os.path.join(job["dir"], "reference_cpu_gvcf.vcf"), os.path.join(job["dir"], "hip_gvcf.vcf")
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], want, pileup, indel, hip=False, extra_args=["--gvcf", "True"])
+    assert rc == 0 and f"Total processed positions : {sum(sizes)}" in out, out[-3000:]
+    job["want"] = want
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, hip=True, decoder=True, extra_args=["--gvcf", "True"])
+    assert rc == 0, out[-3000:]
+    s = check(name, job, got, out, "hip_gvcf")
+    rows = [r for r in open(got) if r.strip() and not r.startswith("#")]
+    assert rows and all(r.split("\t")[8] == "GT:GQ:DP:AD:AF:PL" and r.rstrip("\n").split(":")[-1].replace(",", "").isdigit() for r in rows)
+    # the PL field is part of the compared text: identical rows are identical in it (qual_only rows may differ in a PL by one as well)
+    assert s["identical_text"] >= 0.98 * s["records_a"], s
+
+
 def test_gpu_wrapper_slot_probe_on_the_device(ref):
     """CallVariantsFromCffiGPU.check_gpu_memory after install(): hipMemGetInfo instead of nvidia-smi, one slot per MI355X"""
     import subprocess

@@ -96,7 +96,8 @@ def _asked_rows(rng, n, indel, cv):
 
 
 @pytest.mark.parametrize("indel", [True, False])
-@pytest.mark.parametrize("changes", [{}, {"quality_score_for_pass": 12}, {"is_show_reference": False, "keep_iupac_bases": True}])
+@pytest.mark.parametrize("changes", [{}, {"quality_score_for_pass": 12}, {"is_show_reference": False, "keep_iupac_bases": True}, {"gvcf": True},
+                                     {"gvcf": True, "keep_iupac_bases": True, "quality_score_for_pass": 8}])
 def test_every_class_and_entry_against_the_python_path(indel, changes, ref):
     """rows that ask for every class / entry over random alt_info dictionaries: wherever the C pass prints a row (or says the reference
     prints nothing), the per-row Python path -- the reference's own lookup functions -- gives the same text"""
@@ -125,14 +126,15 @@ def test_every_class_and_entry_against_the_python_path(indel, changes, ref):
 
 @pytest.mark.parametrize("indel", [True, False])
 @pytest.mark.parametrize("noise", [0.0, 0.3])
-def test_rows_with_a_story_through_the_whole_decoder(indel, noise, ref):
+@pytest.mark.parametrize("gvcf", [False, True])
+def test_rows_with_a_story_through_the_whole_decoder(indel, noise, gvcf, ref):
     """consistent rows (tests/decode_rows.py: what a trained model and a real pileup hand the decoder): the rebound batch_output with
     the C pass == without it == the UNPATCHED reference decoder, character for character; and nearly every row is printed in C"""
     from tests.test_decode_dropin import config, widen
     cv, unpatched = ref
     n = 3000
     pos, alt, y, _ = consistent_rows(n, seed=5, indel=indel, noise=noise)
-    cfg = config(cv, not indel, indel)
+    cfg = config(cv, not indel, indel, gvcf=gvcf)  # gvcf: rows with the PL field (compute_PL :1397-1454), printed by the same pass
     yw = widen(y, indel)
     cv.batch_output(pos[:1], alt[:1], yw[:1], cfg, None)  # (makes the configuration's printer)
     pr = cv._c3hip_row_printers[(cfg, id(cv.param))]
@@ -147,7 +149,8 @@ def test_rows_with_a_story_through_the_whole_decoder(indel, noise, ref):
         assert cv.batch_output(pos, alt, yw, cfg, None) == text
     finally:
         pr._c = keep
-    print(f"indel={indel} noise={noise}: {100 * share:.1f} % of the rows printed by c3_vcf_rows")
+    assert (text.count("GT:GQ:DP:AD:AF:PL") == text.count("\n")) if gvcf else "PL" not in text
+    print(f"indel={indel} noise={noise} gvcf={gvcf}: {100 * share:.1f} % of the rows printed by c3_vcf_rows")
     assert share > (0.95 if noise == 0 else 0.6)
 
 
@@ -259,6 +262,82 @@ def test_quality_follows_the_numpy_in_use(ref):
         q = cv.quality_score_from(p[i])
         f = texts[i].split("\t")
         assert f[5] == "%.2f" % q and f[9].split(":")[1] == "%d" % q, (i, float(p[i]), q, texts[i])
+
+
+def test_genotype_likelihoods_follow_the_numpy_in_use(ref):
+    """--gvcf: the PL field is compute_PL (:1397-1454) of the row's 21-genotype and zygosity probabilities -- float32 products; sum, division and
+    the 1e-8 guard in float32 under numpy >= 2, in double before (Python's sum() starts from the int 0).  The C pass under the rule of the
+    running numpy must print what the reference's function returns -- on rows whose likelihoods sit at the ceil() boundaries too --, and
+    under the other rule what a restatement of that rule gives"""
+    import math
+    cv, _ = ref
+    pr = _printer(cv, False, True, gvcf=True)
+    rng = np.random.default_rng(17)
+    n = 20000
+    y = np.zeros((n, 90 + 31), np.float32)
+    y[:, :24] = rng.random((n, 24), dtype=np.float32) ** np.float32(4.0)   # peaked, like soft-max rows
+    y[: n // 4, :24] = np.float32(2.0) ** -rng.integers(0, 30, size=(n // 4, 24)).astype(np.float32)  # powers of two: exact ratios, ceil() of integers
+    cols = y[:, 90:]
+    kinds = rng.integers(0, 4, size=n)
+    pos, alt = [], []
+    for i in range(n):
+        cols[i, 0:9] = -1.0
+        if kinds[i] == 0:    # homo SNP C -> A: "AA" of the homo list
+            cols[i, 0], cols[i, 23:27], cols[i, 13] = 0.5, 1, 0
+            a = "30-XA 12 RC 18"
+        elif kinds[i] == 1:  # hetero SNP with two new bases: A,G -> six genotypes
+            cols[i, 1], cols[i, 23:27], cols[i, 14] = 0.5, 2, 1
+            a = "30-XA 12 XG 9"
+        elif kinds[i] == 2:  # homo insertion
+            cols[i, 2], cols[i, 23:27], cols[i, 15] = 0.5, 3, 1
+            a = "30-ICTT 12 RC 18"
+        else:                # homo deletion
+            cols[i, 3], cols[i, 23:27], cols[i, 16] = 0.5, 4, 1
+            a = "30-DGG 12 RC 18"
+        pos.append(f"chr1:{i + 1}:" + "C" * 16 + "C" + "GG" + "C" * 14)
+        alt.append(a)
+    texts, todo = pr._rows_c(pos, alt, y)
+    assert not todo
+    six = 0
+    for i in range(n):
+        f = texts[i].rstrip("\n").split("\t")
+        assert f[8] == "GT:GQ:DP:AD:AF:PL"
+        want = cv.compute_PL(None, y[i, 21:24], y[i, :21], f[3], f[4])
+        assert f[9].split(":")[-1] == ",".join(str(v) for v in want), (i, f, want)
+        six += len(want) == 6
+    assert six > n // 8
+    # the other rule, restated: float32 products, everything else in double
+    keep = pr._c.f32_arith
+    pr._c.f32_arith = 0 if keep else 1
+    try:
+        texts, todo = pr._rows_c(pos, alt, y)
+    finally:
+        pr._c.f32_arith = keep
+    f32 = np.float32
+    for i in range(0, n, 7):
+        f = texts[i].rstrip("\n").split("\t")
+        alts = f[4].split(",")
+        ref_b = f[3]
+        all_base = [ref_b] + alts
+        genos = [[0, 0], [0, 1], [1, 1]] if len(alts) == 1 else [[0, 0], [0, 1], [1, 1], [0, 2], [1, 2], [2, 2]]
+        like = []
+        for g0, g1 in genos:
+            lab = cv.mix_two_partial_labels(cv.partial_label_from(ref_b, all_base[g0]), cv.partial_label_from(ref_b, all_base[g1]))
+            z = 0 if g0 == g1 == 0 else 1 if g0 == g1 else 2
+            like.append(f32(y[i, cv.gt21_enum_from_label(lab)]) * f32(y[i, 21 + z]))
+        if keep:   # the running numpy is >= 2: the other rule is the double one
+            total = 0.0
+            for v in like:
+                total += float(v)
+            xs = [float(v) / total + 1e-8 for v in like]
+        else:
+            total = f32(0)
+            for v in like:
+                total = f32(total + v)
+            xs = [float(f32(f32(v / total) + f32(1e-8))) for v in like]
+        pls = [-10 * (math.log(v) / math.log(10.0)) for v in xs]
+        want = [int(math.ceil(v - min(pls))) for v in pls]
+        assert f[9].split(":")[-1] == ",".join(str(v) for v in want), (i, f, want)
 
 
 def test_rows_per_second_of_one_decode_core(ref):
