@@ -28,7 +28,7 @@ class RowsConfig(C.Structure):
     """c3_rows_config (include/c3hip.h)"""
     _fields_ = [("width", C.c_int32), ("flank", C.c_int32), ("show_reference", C.c_int32), ("keep_iupac", C.c_int32),
                 ("has_qs_pass", C.c_int32), ("pileup", C.c_int32), ("max_len", C.c_int32), ("infer", C.c_int32),
-                ("f32_arith", C.c_int32), ("walk", C.c_int32), ("gvcf", C.c_int32), ("reserved_", C.c_int32),
+                ("f32_arith", C.c_int32), ("walk", C.c_int32), ("gvcf", C.c_int32), ("haploid", C.c_int32),
                 ("qs_pass", C.c_double), ("phred_trans", C.c_double),
                 ("gt", (C.c_char * 8) * 4)]
 

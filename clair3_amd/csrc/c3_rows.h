@@ -495,7 +495,10 @@ static bool row_text(const c3_rows_config &cf, const Row &r, int cls, std::strin
     const bool is_ref = cls == 0;
     if ((!cf.show_reference && is_ref) || (!is_ref && ref == alt)) return true;  // prints nothing (:1176-1180)
     const bool multi = alt.find(',') != std::string::npos;
+    if ((cf.haploid & 1) && (cls == 2 || cls >= 5)) return true;  // haploid, precise mode: no heterozygous call is printed (:1191-1196)
+    else if ((cf.haploid & 2) && multi) return true;             // sensitive mode: none with two alternative alleles (:1197-1199)
     const char *gt = cf.gt[multi ? 3 : kGenotypeOfClass[cls]];
+    if (cf.haploid) gt = strchr(gt, '1') ? "1" : "0";  // :1327-1329
     // decode_alt_info (:1215-1230)
     long long snp[128];
     bool has_snp[128] = {false};

@@ -28,6 +28,7 @@ from . import decode as dec
 
 FALLBACK = object()  # "print this row with the reference's output_with"
 
+_HETERO_CLASSES = frozenset((2, 5, 6, 7, 8, 9))  # the classes a haploid-precise run drops (:1191-1196)
 _GENOTYPE_OF_CLASS = (0, 1, 2, 1, 1, 2, 2, 2, 2, None)  # homo_reference / homo_variant / hetero_variant per class (:1204-1209)
 # rank of a class in output_from's if / elif chain (:748, :758, :778, :800, :830, :879, :897, :924, :977): among classes that
 # hold the same maximum the first of the chain is the one whose candidate is looked up (and zeroed on rejection)
@@ -151,8 +152,7 @@ class RowPrinter:
     def __init__(self, cv, output_config):
         c = output_config
         self.cv, self.cfg = cv, c
-        self.usable = not (c.is_debug or c.is_haploid_precise_mode_enabled or c.is_haploid_sensitive_mode_enabled
-                           or c.enable_long_indel or c.is_output_for_ensemble or c.input_probabilities)
+        self.usable = not (c.is_debug or c.enable_long_indel or c.is_output_for_ensemble or c.input_probabilities)
         self.width = 90 if c.add_indel_length else 24
         self.flank = cv.param.flankingBaseNum
         G = cv.Genotype
@@ -204,6 +204,7 @@ class RowPrinter:
             if not same:
                 return None
         cf.gvcf = int(bool(c.gvcf))
+        cf.haploid = int(bool(c.is_haploid_precise_mode_enabled)) | (int(bool(c.is_haploid_sensitive_mode_enabled)) << 1)
         for k, g in enumerate(self.gt + [self.gt_multi]):
             cf.gt[k].value = g.encode()
         self._lib = L
@@ -390,7 +391,13 @@ class RowPrinter:
         if (not c.is_show_reference and is_ref) or (not is_ref and ref == alt):  # :1176-1180
             return None
         multi = "," in str(alt)
+        if c.is_haploid_precise_mode_enabled and cls in _HETERO_CLASSES:  # :1191-1196 (hetero SNP, ACGT + Ins, InsIns, ACGT + Del, DelDel, Ins and Del)
+            return None
+        elif c.is_haploid_sensitive_mode_enabled and multi:  # :1197-1199
+            return None
         gt = self.gt_multi if multi else self.gt[_GENOTYPE_OF_CLASS[cls]]  # :1203-1211 (class 9 always carries two alleles)
+        if c.is_haploid_precise_mode_enabled or c.is_haploid_sensitive_mode_enabled:  # :1327-1329 (placed here: nothing in between reads it)
+            gt = "1" if "1" in gt else "0"
         snp, insd, deld, ref_count = {}, {}, {}, 0  # decode_alt_info (:1215-1230)
         for k, n in d.items():
             n = int(n)

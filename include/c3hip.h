@@ -198,7 +198,8 @@ int c3_decode_columns(c3_model *m, const float *y_host, int64_t batch, float *ro
  *               rejected candidates); empty: the reference prints nothing for it.  status[i] == 1: the caller prints the row itself */
 typedef struct {
     int32_t width, flank, show_reference, keep_iupac, has_qs_pass, pileup, max_len, infer, f32_arith, walk;
-    int32_t gvcf, reserved_;  /* gvcf: rows carry the PL field (output_config.gvcf, clair3/CallVariants.py:1360-1378, compute_PL :1397-1454) */
+    int32_t gvcf, haploid;  /* gvcf: rows carry the PL field (output_config.gvcf, clair3/CallVariants.py:1360-1378, compute_PL :1397-1454);
+                             * haploid: bit 0 is_haploid_precise_mode_enabled, bit 1 is_haploid_sensitive_mode_enabled (:1191-1199, :1327-1329) */
     double qs_pass, phred_trans;
     char gt[4][8];
 } c3_rows_config;

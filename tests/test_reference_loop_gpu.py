@@ -119,10 +119,10 @@ def explain_call_differences(job, diffs, ref_root):
     return notes
 
 
-def check(name, job, got_vcf, out, tag):
+def check(name, job, got_vcf, out, tag, min_share=0.5):
     s = refloop.compare_vcfs(got_vcf, job["want"])
     s.update(case=name, run=tag, windows=job["n"], loop_seconds=elapsed(out), reference_cpu_loop_seconds=job["ref_s"])
-    assert s["records_a"] == s["records_b"] and s["records_a"] >= job["n"] // 2, s
+    assert s["records_a"] == s["records_b"] and s["records_a"] >= int(job["n"] * min_share), s
     assert not s["only_a"] and not s["only_b"], s
     # the same calls.  QUAL is printed with two decimals from a log of probabilities that agree to ~1e-6, so a handful of rows may
     # differ in the last digit (counted in qual_only).  A different CALL must be proven a near-tie of the reference's own joint
@@ -200,21 +200,27 @@ def test_decoder_columns_through_the_reference_loop(name, ref, jobs):
     assert s["records_a"] > 0
 
 
-@pytest.mark.parametrize("name", ["full_alignment", "pileup"])
-def test_gvcf_rows_through_the_worker_command(name, ref, jobs):
-    """--gvcf True (rows carry the PL field, clair3/CallVariants.py:1360-1378): the worker command on libc3hip with the decoder columns --
-    c3_vcf_rows computes compute_PL (:1397-1454) from the row's own probabilities -- against the same command on the reference's modules"""
+@pytest.mark.parametrize("name,flags", [("full_alignment", ["--gvcf", "True"]), ("pileup", ["--gvcf", "True"]),
+                                        ("pileup", ["--haploid_sensitive", "--gvcf", "True", "--qual", "8"]), ("full_alignment", ["--haploid_precise"])])
+def test_gvcf_and_haploid_rows_through_the_worker_command(name, flags, ref, jobs):
+    """--gvcf True (rows carry the PL field, clair3/CallVariants.py:1360-1378) and the haploid modes (:1191-1199, :1327-1329): the worker
+    command on libc3hip with the decoder columns -- c3_vcf_rows restates compute_PL (:1397-1454) from the row's own probabilities and the
+    haploid rules -- against the same command on the reference's modules"""
     kind, channels, indel, pileup, dwell, sizes = CASES[name]
     job = dict(jobs(name))
-    want, got = os.path.join(job["dir"], "reference_cpu_gvcf.vcf"), os.path.join(job["dir"], "hip_gvcf.vcf")
-    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], want, pileup, indel, hip=False, extra_args=["--gvcf", "True"])
+    tag = "hip" + "".join(f.strip("-").replace("haploid_", "_h").replace("True", "") for f in flags if not f.isdigit())
+    want, got = os.path.join(job["dir"], f"reference_cpu_{tag}.vcf"), os.path.join(job["dir"], f"{tag}.vcf")
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], want, pileup, indel, hip=False, extra_args=flags)
     assert rc == 0 and f"Total processed positions : {sum(sizes)}" in out, out[-3000:]
     job["want"] = want
-    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, hip=True, decoder=True, extra_args=["--gvcf", "True"])
+    rc, out = refloop.run_worker(ref, job["lst"], job["ck"], got, pileup, indel, hip=True, decoder=True, extra_args=flags)
     assert rc == 0, out[-3000:]
-    s = check(name, job, got, out, "hip_gvcf")
+    s = check(name, job, got, out, tag, min_share=0.02 if any("haploid" in f for f in flags) else 0.5)  # (a haploid run prints no heterozygous call)
     rows = [r for r in open(got) if r.strip() and not r.startswith("#")]
-    assert rows and all(r.split("\t")[8] == "GT:GQ:DP:AD:AF:PL" and r.rstrip("\n").split(":")[-1].replace(",", "").isdigit() for r in rows)
+    if "--gvcf" in flags:
+        assert rows and all(r.split("\t")[8] == "GT:GQ:DP:AD:AF:PL" and r.rstrip("\n").split(":")[-1].replace(",", "").isdigit() for r in rows)
+    if any("haploid" in f for f in flags):
+        assert rows and all(r.split("\t")[9].split(":")[0] in ("0", "1") for r in rows)
     # the PL field is part of the compared text: identical rows are identical in it (qual_only rows may differ in a PL by one as well)
     assert s["identical_text"] >= 0.98 * s["records_a"], s
 

@@ -97,7 +97,8 @@ def _asked_rows(rng, n, indel, cv):
 
 @pytest.mark.parametrize("indel", [True, False])
 @pytest.mark.parametrize("changes", [{}, {"quality_score_for_pass": 12}, {"is_show_reference": False, "keep_iupac_bases": True}, {"gvcf": True},
-                                     {"gvcf": True, "keep_iupac_bases": True, "quality_score_for_pass": 8}])
+                                     {"gvcf": True, "keep_iupac_bases": True, "quality_score_for_pass": 8}, {"is_haploid_precise_mode_enabled": True},
+                                     {"is_haploid_sensitive_mode_enabled": True, "gvcf": True}])
 def test_every_class_and_entry_against_the_python_path(indel, changes, ref):
     """rows that ask for every class / entry over random alt_info dictionaries: wherever the C pass prints a row (or says the reference
     prints nothing), the per-row Python path -- the reference's own lookup functions -- gives the same text"""
@@ -119,6 +120,12 @@ def test_every_class_and_entry_against_the_python_path(indel, changes, ref):
         c = int(y[i, -8])
         by_class[c] = by_class.get(c, 0) + 1
     assert set(by_class) == set(range(10)) and min(by_class.values()) > 50, by_class  # every class is printed by the C pass
+    if any(k.startswith("is_haploid") for k in changes):  # (:1191-1199, :1327-1329)
+        printed = [t for i, t in enumerate(texts) if i not in back and t]
+        assert printed and all(t.split("\t")[9].split(":")[0] in ("0", "1") for t in printed)
+        if changes.get("is_haploid_precise_mode_enabled"):  # the heterozygous classes are not printed (a row whose first candidate was
+            quiet = sum(texts[i] is None for i in range(n) if i not in back)  # rejected may end in another class: counted, not matched)
+            assert quiet > 0.2 * (n - len(back)), quiet
     assert len(todo) < 0.7 * n  # (random dictionaries rarely offer what a random entry asks for: rejected first candidates go back)
     # and the public entry gives the same list
     assert pr.rows(pos, alt, y) == want
