@@ -32,8 +32,9 @@ def _teacher_labels(x, seed, n_heads):
     return y
 
 
-def train_reference(root, kind, channels, indel, steps=150, batch=24, seed=0, threads=8):
-    """-> (state_dict as numpy arrays, list of the loss every 10 steps).  The reference's module in train() mode, AdamW, focal loss."""
+def train_reference(root, kind, channels, indel, steps=150, batch=24, seed=0, threads=8, device="cpu", lr_scale=1.0):
+    """-> (state_dict as numpy arrays, list of the loss every 10 steps).  The reference's module in train() mode, AdamW, focal loss.
+    device="cuda": the same training through PyTorch-ROCm (tests/diag/long_training_parity.py: thousands of steps in a minute)."""
     import torch
     torch.manual_seed(seed)
     torch.set_num_threads(threads)
@@ -43,14 +44,15 @@ def train_reference(root, kind, channels, indel, steps=150, batch=24, seed=0, th
         param = importlib.import_module("shared.param_p" if kind == syn.PILEUP else "shared.param_f")
         cls = model_py.Clair3_P if kind == syn.PILEUP else model_py.Clair3_F
         m = cls(add_indel_length=indel, predict=False, input_channels=channels)
-        lr, wd = float(param.initialLearningRate), float(param.l2RegularizationLambda)
+        lr, wd = float(param.initialLearningRate) * lr_scale, float(param.l2RegularizationLambda)
+    m.to(device)
     m.train()
     opt = torch.optim.AdamW(m.parameters(), lr=lr, weight_decay=wd)  # clair3/Train.py:386-388
     losses = []
     for step in range(steps):
         x = syn.make_windows(kind, batch, seed=seed * 100003 + step, channels=channels)
-        y_true = torch.from_numpy(_teacher_labels(x, seed, n_heads))
-        heads = m(torch.from_numpy(x))
+        y_true = torch.from_numpy(_teacher_labels(x, seed, n_heads)).to(device)
+        heads = m(torch.from_numpy(x).to(device))
         loss = 0.0
         for (lo, hi), y_pred in zip(HEADS[:n_heads], heads):  # FocalLoss.forward, clair3/Train.py:100-107 (gamma 2, no class weights)
             p = torch.clamp(y_pred, min=1e-9, max=1 - 1e-9)
@@ -62,5 +64,6 @@ def train_reference(root, kind, channels, indel, steps=150, batch=24, seed=0, th
         if step % 10 == 0 or step == steps - 1:
             losses.append(float(loss.detach()))
     m.eval()
+    m.to("cpu")
     sd = {k: np.ascontiguousarray(v.detach().cpu().numpy()) for k, v in m.state_dict().items()}
     return sd, losses
