@@ -365,6 +365,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     // int8 windows feed the fp16 projection fragments (counts are exact in fp16); int32 windows keep an fp32 projection inside
     // the fp16x3 recurrence kernel
     const bool l1_f16 = m->f16_ok && m->whh16[0] && (sizeof(T) != 1 || m->l1_wih16);
+    const int beside = std::max(m->sharing, m->lane_sharing);  // other batches on the chip: the caller's handles, or this handle's other lanes (c3_model.h)
     const bool h1_planes = l1_f16 && m->proj2_pw;  // h1 leaves LSTM1 as fp16 piece planes for c3_dense.h
     m->last_planes = h1_planes;
     {
@@ -372,7 +373,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
         // half tiles (8 windows per workgroup, c3_lstm_fused.h OPT bit 2) while the full tiles would leave half the CUs without a
         // workgroup (<= 1024 windows on 256 CUs; beyond that two half tiles share a CU and take twice as long: 1100 windows 94 us
         // against 60 us on full tiles)
-        const bool half1 = l1_f16 && m->half_tiles && m->sharing <= 1 && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 4;
+        const bool half1 = l1_f16 && m->half_tiles && beside <= 1 && h1_planes && sizeof(T) == 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 4;
         const double tiles = (double)(half1 ? (n + 7) / 8 * 16 : (n + 15) / 16 * 16) * Tn * 2;  // (window, step, direction) rows of the 16-row tiles
         // recurrent part 512 x 128 as fp16x3 (or fp32); input part: int8 windows 512 x 32 against two weight pieces, else 512 x 20 fp32
         ps.mfma(l1_f16 ? tiles * 2.0 * 512 * (128 * 3 + (sizeof(T) == 1 ? 32 * 2 : 0)) : tiles * 2.0 * 512 * (128 + 20), l1_f16);
@@ -410,8 +411,8 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
             wp.lanes_per_xcd = std::max(1, m->wg_slots / 16 / wp.tiles_n);  // CUs per XCD / column tiles (32 / 5 = 6)
             // beside other handles half as many, twice as long workgroups: 120 of them leave room for the 128 of another batch's
             // LSTM launch (three batches in flight 5.46 M -> 5.59 M windows/s; alone 4.9 M -> 4.3 M, hence the caller's hint)
-            if (m->sharing > 1) wp.lanes_per_xcd = std::max(1, wp.lanes_per_xcd / 2);
-            m->choice_proj2 = m->sharing > 1 ? "weights-resident-half-grid" : "weights-resident";
+            if (beside > 1) wp.lanes_per_xcd = std::max(1, wp.lanes_per_xcd / 2);
+            m->choice_proj2 = beside > 1 ? "weights-resident-half-grid" : "weights-resident";
             static const bool gx2_nt = getenv("C3HIP_GX2_NT") && atoi(getenv("C3HIP_GX2_NT")) != 0;  // A/B knob (profiles/r05_*_ab_gx2_nt.txt)
             if (gx2_nt) hipLaunchKernelGGL(dense_planes_wres_kernel<64>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
             else hipLaunchKernelGGL(dense_planes_wres_kernel<0>, dim3(8 * wp.lanes_per_xcd * wp.tiles_n), dim3(kDnThreads), 0, s, wp);
@@ -434,7 +435,7 @@ static int run_pileup_t(c3_model *m, hipStream_t s, const T *x, int64_t n, float
     {
         ProfScope ps(m, s, "p.lstm2", 2.0 * M * 2.0 * 640.0 * 160.0, 4.0 * M * (1280.0 + 320.0));
         const bool l2_f16 = m->f16_ok && m->whh16[1];
-        const bool half2 = l2_f16 && m->half_tiles && m->sharing <= 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 4;
+        const bool half2 = l2_f16 && m->half_tiles && beside <= 1 && 2 * ((n + 15) / 16) <= m->wg_slots / 4;
         ps.mfma((double)(half2 ? (n + 7) / 8 * 16 : (n + 15) / 16 * 16) * Tn * 2 * 2.0 * 640 * 160 * (l2_f16 ? 3 : 1), l2_f16);
         Lstm2Params lp{m->gx2, m->whh[1], m->h2, (int)n, Tn, 1280};
         if (l2_f16) {

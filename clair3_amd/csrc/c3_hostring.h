@@ -124,7 +124,10 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     // neighbouring slot on the chip; keep mode, the two-halves knob and profiling stay in one lane
     // -- and so does a batch that fills the chip by itself: two of those side by side only get in each other's way (same-box A/B,
     // profiles/r06_i_ab_ring_lanes.txt: full alignment ring +5.5 % at B = 256, -4 % at B = 1000)
-    TRY(use_lane(m, (m->ring_lanes > 1 && batch <= m->lane_max_batch && !m->keep && m->duo == 0 && !m->prof) ? slot % m->ring_lanes : 0));
+    const bool in_lane = m->ring_lanes > 1 && batch <= m->lane_max_batch && !m->keep && m->duo == 0 && !m->prof;
+    // lanes are dealt in the ORDER of the submits, not by slot number: three slots on two lanes (the pileup network) would put two of every
+    // three batches behind each other in lane 0 (C3HIP_LANE_ORDER=slot: the slot's number, as before)
+    TRY(use_lane(m, in_lane ? (m->lane_by_slot ? slot : (int)(m->lane_next++ % (unsigned)m->ring_lanes)) % m->ring_lanes : 0));
     const size_t xb = (size_t)(batch * c3_model_window_bytes(m, x_dtype));
     const size_t yb = (size_t)batch * m->row * sizeof(float);
     // C3HIP_HOST_COPY_KERNEL: 0 = never, 1 = up to kKernelCopyMax, n > 1 = up to n KB (A/B of the threshold)
@@ -134,6 +137,23 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     // chunk 3.87 M against 3.64 M)
     bool alone = true;
     for (int k = 0; k < kHostSlots; ++k) alone &= !m->slot[k].busy;
+    // beside batches in the other lanes: the kernel forms for a shared chip (c3_model.h lane_sharing; rows bit-identical either way) -- when this
+    // batch and the largest ones in flight in the other lanes would, on half tiles (two workgroups per 8 windows), ask for more workgroups than
+    // the chip has CUs (ring of 1024-window batches: yes; the blocking call's 250 + 750 pieces: no, 252 half-tile workgroups fit side by side)
+    int64_t beside_windows = 0;
+    if (in_lane && !alone && m->lane_sharing_ok) {
+        int64_t other[kHostSlots];
+        int no = 0;
+        for (int k = 0; k < kHostSlots; ++k)
+            if (m->slot[k].busy && m->slot[k].batch <= m->lane_max_batch) other[no++] = m->slot[k].batch;
+        std::sort(other, other + no, std::greater<int64_t>());
+        for (int k = 0; k < no && k < m->ring_lanes - 1; ++k) beside_windows += other[k];
+    }
+    struct LaneSharing {
+        c3_model *m;
+        LaneSharing(c3_model *m_, int v) : m(m_) { m->lane_sharing = v; }
+        ~LaneSharing() { m->lane_sharing = 1; }
+    } lane_sharing(m, (beside_windows > 0 && 2 * ((batch + beside_windows + 7) / 8) > m->wg_slots / 2) ? m->ring_lanes : 1);
     if (batch > 0 && m->host_copy_kernel && alone && xb <= kcopy_max && yb <= kcopy_max) {
         TRY(ensure_slot(m, sl, (xb + 255) & ~(size_t)255, y_dev_out ? 0 : (yb + 255) & ~(size_t)255));  // (rows that stay on the device need no slot buffers)
         StagePool::get().copy(sl.pin_x, x_host, xb);  // (plain memcpy below 1 MB, split over the helpers above)

@@ -17,6 +17,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -195,6 +196,14 @@ struct c3_model {
     bool half_tiles = true;   // LSTM recurrences on 8-window tiles while 16-window tiles would leave CUs without a workgroup; env C3HIP_HALF_TILES
     int sharing = 1;          // handles the CALLER says feed this GPU side by side (c3_model_set_sharing): beside other batches the chip is
                               // full, so the recurrences stay on full tiles and the projection launches half as many, twice as long workgroups
+    // a batch of the ring that runs in a lane NEXT TO another batch of the same handle (c3_hostring.h predict_submit) is in the same position
+    // as one beside another handle: its recurrences take full 16-window tiles (128 workgroups per 1024 windows, so that two batches fill the 256
+    // CUs between them -- a half-tile launch alone owns every CU: 144 KB of LDS per workgroup, and the second lane's batch waits), the
+    // LSTM2 projection half its grid.  Set around forward_device by the ring; 1 everywhere else.  C3HIP_LANE_SHARING=0: never.
+    int lane_sharing = 1;
+    bool lane_sharing_ok = true;
+    unsigned lane_next = 0;     // the lane of the ring's next small batch (round robin over the submits)
+    bool lane_by_slot = false;  // env C3HIP_LANE_ORDER=slot: lane = slot % lanes (round 6's first form)
     int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
     bool tail_fused = false;  // the split-K sum of L4 inside fc_tail_mfma_kernel (c3_tail.h) instead of its own launch: on for the pileup network (+0.7 %:
                               // 15 partials of 128 features), off for full alignment (-1 %: four branch workgroups re-read 28 partials of 256); env C3HIP_TAIL_FUSED
@@ -218,8 +227,8 @@ struct c3_model {
 
     // ---- the ring's second lane (round 6) ----
     // Batches of the submit / wait ring used to run strictly one after the other: ONE workspace and ONE kernel stream per handle.  A lane is
-    // everything a forward pass writes -- the workspace, the kernel stream, the tail stream and its events: with two of them the batch in slot
-    // k runs on lane k % lanes, consecutive batches overlap on the chip (what three HANDLES in flight do, 876 k against 735 k windows/s at
+    // everything a forward pass writes -- the workspace, the kernel stream, the tail stream and its events: with two of them consecutive
+    // small batches (dealt to the lanes in submit order, c3_hostring.h) overlap on the chip (what three HANDLES in flight do, 876 k against 735 k windows/s at
     // B = 256, without a second copy of the weights) and fill each other's under-filled launches.  The fields above ARE the
     // active lane; use_lane() parks them and takes another lane's out of `parked`.  Rows do not depend on the lane (same kernels, same data).
     // env C3HIP_RING_LANES=1: one lane.

@@ -114,6 +114,8 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_RING_LANES")) m->ring_lanes = std::min(std::max(atoi(e), 1), (int)c3_model::kMaxLanes);
     if (const char *e = getenv("C3HIP_RING_LANES_MAX_BATCH")) m->lane_max_batch = atoll(e);
     if (const char *e = getenv("C3HIP_TAIL_STREAM")) m->tail_split = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_LANE_SHARING")) m->lane_sharing_ok = atoi(e) != 0;
+    if (const char *e = getenv("C3HIP_LANE_ORDER")) m->lane_by_slot = strcmp(e, "slot") == 0;
     if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
     {
         hipDeviceProp_t prop;

@@ -219,6 +219,42 @@ def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
     assert np.array_equal(m.wait(t1), m0.predict_numpy(xs[0])) and np.array_equal(m.wait(t2), m0.predict_numpy(xs[2]))
 
 
+def test_ring_batches_beside_each_other_take_the_shared_chip_forms(monkeypatch):
+    """Round 6: a pileup batch of the ring that would, on half tiles, ask for more workgroups than the chip has CUs together with the batches in
+    flight in the other lanes runs on the forms for a shared chip -- full 16-window tiles in both recurrences, half the grid of the LSTM2
+    projection (what c3_model_set_sharing asks for beside other HANDLES) -- so that two batches fill the CUs between them; a batch alone, small
+    batches beside each other and the blocking call's pieces keep the half tiles.  Lanes are dealt in submit order.  Rows: bit-identical to
+    the one-lane ring whatever the form (the property every tile form of these kernels is held to)."""
+    sd = syn.make_state_dict(syn.PILEUP, 18, True, seed=93)
+    xs = [syn.make_windows(syn.PILEUP, n, seed=94 + i, channels=18) for i, n in enumerate([1024, 1024, 1000, 1024, 300, 200, 1024])]
+    monkeypatch.setenv("C3HIP_RING_LANES", "1")
+    m0 = make_model(syn.PILEUP, 18, True, sd)
+    want = [m0.predict_numpy(x) for x in xs]
+    monkeypatch.delenv("C3HIP_RING_LANES")
+    m = make_model(syn.PILEUP, 18, True, sd)
+    assert "ring_lanes=2 lane_max_batch=1024" in m.describe(), m.describe()
+    t = m.submit(xs[0], slot=0)  # alone on the chip: half tiles
+    assert "lstm1=fused-f16x3-half-tiles" in m.describe() and "lstm2=f16x3-half-tiles" in m.describe() and "proj2=weights-resident " in m.describe() + " ", m.describe()
+    t1 = m.submit(xs[1], slot=1)  # beside it: 2048 windows of half tiles would be 512 workgroups
+    d = m.describe()
+    assert "lstm1=fused-f16x3-full-tiles" in d and "lstm2=f16x3-full-tiles" in d and "proj2=weights-resident-half-grid" in d, d
+    t2 = m.submit(xs[2], slot=2)
+    assert "lstm2=f16x3-full-tiles" in m.describe()
+    assert np.array_equal(m.wait(t), want[0]) and np.array_equal(m.wait(t1), want[1]) and np.array_equal(m.wait(t2), want[2])
+    ta, tb = m.submit(xs[4], slot=0), m.submit(xs[5], slot=1)  # 300 + 200 windows: 126 half-tile workgroups fit side by side
+    assert "lstm2=f16x3-half-tiles" in m.describe(), m.describe()
+    tc = m.submit(xs[3], slot=2)  # 1024 beside 300: over the chip again
+    assert "lstm2=f16x3-full-tiles" in m.describe(), m.describe()
+    assert np.array_equal(m.wait(ta), want[4]) and np.array_equal(m.wait(tb), want[5]) and np.array_equal(m.wait(tc), want[3])
+    assert np.array_equal(m.predict_numpy(xs[2]), want[2])  # the blocking call of 1000 windows: its pieces side by side on half tiles
+    assert "lstm2=f16x3-half-tiles" in m.describe(), m.describe()
+    monkeypatch.setenv("C3HIP_LANE_SHARING", "0")
+    m2 = make_model(syn.PILEUP, 18, True, sd)
+    u, v = m2.submit(xs[0], slot=0), m2.submit(xs[6], slot=1)
+    assert "lstm2=f16x3-half-tiles" in m2.describe()
+    assert np.array_equal(m2.wait(u), want[0]) and np.array_equal(m2.wait(v), want[6])
+
+
 def test_strict_state_dict_loading():
     sd = syn.make_state_dict(syn.PILEUP, seed=61)
     m = Clair3_P(predict=True).to("cuda:0")
