@@ -14,7 +14,7 @@ static int tail_begin(c3_model *m, hipStream_t s, hipStream_t *ts) {
     *ts = s;
     if (!m->tail_now) return tail_guard(m, s);  // (a chain on s itself: behind one that may still be running on tail_stream -- they share the partials)
     if (!m->tail_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&m->tail_stream, hipStreamNonBlocking));
+        HIP_TRY(new_stream(m, &m->tail_stream));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_body_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_tail_done, hipEventDisableTiming));
     }
@@ -482,7 +482,7 @@ static int forward_device(c3_model *m, hipStream_t s, const void *x, int x_dtype
         const int64_t duo_min = m->kind == C3_KIND_FULL_ALIGNMENT ? 192 : 768;
         if (m->duo > 0 && !m->keep && m->sharing <= 1 && n >= duo_min) {
             if (!m->duo_stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&m->duo_stream, hipStreamNonBlocking));
+                HIP_TRY(new_stream(m, &m->duo_stream));
                 HIP_TRY(hipEventCreateWithFlags(&m->duo_fork, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&m->duo_join, hipEventDisableTiming));
             }

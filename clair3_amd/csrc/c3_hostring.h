@@ -174,9 +174,16 @@ static int predict_submit(c3_model *m, const void *x_host, int x_dtype, int64_t 
     if (batch > 0) {
         // the slot becomes busy only once everything has been queued: a failure on the way leaves it free
         TRY(ensure_slot(m, sl, xb, y_dev_out ? 0 : yb));  // (rows that stay on the device need no slot buffers)
-        TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream));
-        HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
-        HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
+        if (in_lane && m->lane_h2d) {
+            // a small batch in a lane brings its windows in on the lane's OWN stream: copy, kernels and the copy-out in order in one queue, no
+            // event between two streams -- the batches of the other lanes are what the copy runs under (c3_model.h lane_h2d)
+            TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->stream));
+        } else {
+            if (!m->h2d_stream) HIP_TRY(new_stream(m, &m->h2d_stream));
+            TRY(stage_h2d(sl.dev_x, sl.pin_x, x_host, xb, m->h2d_stream));
+            HIP_TRY(hipEventRecord(sl.ev_h2d, m->h2d_stream));
+            HIP_TRY(hipStreamWaitEvent(m->stream, sl.ev_h2d, 0));
+        }
         const bool f16 = m->f16_ok;
         hipStream_t outs;
         TRY(ring_forward(m, sl.dev_x, x_dtype, batch, y_dev_out ? y_dev_out : sl.dev_y, &outs));

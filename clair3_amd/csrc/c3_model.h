@@ -203,6 +203,16 @@ struct c3_model {
     int lane_sharing = 1;
     bool lane_sharing_ok = true;
     unsigned lane_next = 0;     // the lane of the ring's next small batch (round robin over the submits)
+    int stream_priority = 0;    // env C3HIP_STREAM_PRIORITY=-1/0/1: the priority every stream of this handle is created with (new_stream below)
+    // As few streams as the work needs.  The runtime gives a process FOUR hardware queues (GPU_MAX_HW_QUEUES) and places every stream on the
+    // least-used one; two streams on one queue run in submission order, and a wait between streams on two queues costs tens of microseconds.
+    // Which streams meet on a queue depends on everything else the process created before -- measured (profiles/r06_o_*): the same ring of
+    // 256-window batches ran at 650 k windows/s on the first handle of a fresh process and at 800 k on a second one, 620 k with 8 or 16 queues
+    // (every stream alone: every dependency crosses queues).  So a small batch of the ring lives on its lane's stream ALONE -- staged windows in,
+    // kernels, FC chain, rows out, in order, no event (lane_h2d; the batches of the other lanes are what its copy runs under) -- and the transfer
+    // stream exists only from the first large batch on (lazy_h2d): three lanes + the null stream are the four queues.
+    bool lazy_h2d = true;       // env C3HIP_LAZY_H2D_STREAM=0: the transfer stream is created with the handle
+    bool lane_h2d = true;       // env C3HIP_LANE_H2D=0: a lane batch's staged windows travel on the transfer stream, an event in between
     bool lane_by_slot = false;  // env C3HIP_LANE_ORDER=slot: lane = slot % lanes (round 6's first form)
     int host_copy_kernel = 1;  // env C3HIP_HOST_COPY_KERNEL=0: every batch through the DMA engines on the transfer streams
     bool tail_fused = false;  // the split-K sum of L4 inside fc_tail_mfma_kernel (c3_tail.h) instead of its own launch: on for the pileup network (+0.7 %:
@@ -259,6 +269,13 @@ struct c3_model {
 
 static int conv_out(int n, int s) { return (n - 1) / s + 1; }
 
+// Every stream of a handle: non-blocking, at the handle's priority.  The runtime keeps one pool of at most GPU_MAX_HW_QUEUES (4) hardware queues
+// per priority and hands a new stream the least-used queue of its pool; two streams on one hardware queue run in submission order.
+static hipError_t new_stream(const c3_model *m, hipStream_t *s) {
+    return m->stream_priority ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, m->stream_priority) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+
 // make lane k the active one (c3_model::Lane): park everything a forward pass writes and take lane k's out of the parking lot
 static void lane_exchange(c3_model *m, c3_model::Lane &o) {
     std::swap(m->cap, o.cap), std::swap(m->last_planes, o.last_planes), std::swap(m->tail_pending, o.tail_pending);
@@ -275,7 +292,7 @@ static int use_lane(c3_model *m, int k) {
     lane_exchange(m, m->parked[m->lane_cur]);  // the active fields -> their parking place (which held nothing that matters)
     lane_exchange(m, m->parked[k]);            // lane k's -> the active fields
     m->lane_cur = k;
-    if (!m->stream) HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));  // (a further lane's kernel stream, on first use)
+    if (!m->stream) HIP_TRY(new_stream(m, &m->stream));  // (a further lane's kernel stream, on first use)
     return 0;
 }
 

@@ -81,8 +81,9 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     m->row = m->nout;
     m->FC = kind == C3_KIND_PILEUP ? 128 : 256;
     m->K4 = kind == C3_KIND_PILEUP ? m->positions * 320 : 14 * 256;
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&m->h2d_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (const char *e = getenv("C3HIP_STREAM_PRIORITY")) m->stream_priority = atoi(e);
+    if (const char *e = getenv("C3HIP_LAZY_H2D_STREAM")) m->lazy_h2d = atoi(e) != 0;
+    if (new_stream(m, &m->stream) != hipSuccess || (!m->lazy_h2d && new_stream(m, &m->h2d_stream) != hipSuccess)) {
         fail("hipStreamCreate failed");
         delete m;
         return nullptr;
@@ -103,7 +104,10 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     // the ring's FC chain on its own stream: on for full alignment (same-box A/B, profiles/r06_h_ab_tail_stream.txt: ring 680 - 685 k -> 696 k windows/s at
     // B = 256, 687 -> 705 - 709 k over the driver's 100 steps, 768 -> 778 - 780 k at B = 1000), off for the pileup network (4.09 - 4.14 M -> 4.03 M: a chain
     // beside the next batch's latency-bound LSTM1 slows the recurrence more than it hides)
-    m->tail_split = kind == C3_KIND_FULL_ALIGNMENT;
+    // (round 6, later: OFF for both.  The +1.5 - 2 % of that A/B was one placement of the handle's streams on the runtime's four hardware queues;
+    // another placement of the same streams loses 15 %, and a handle with FEWER streams is what holds everywhere: see lane_h2d in c3_model.h and
+    // profiles/r06_o_ring_streams_and_hardware_queues.txt)
+    m->tail_split = false;
     // two lanes for the ring (c3_model.h Lane): the kind's default follows the same-box A/B of profiles/r06_i_ab_ring_lanes.txt
     // (one MI355X, alternating: full alignment ring 728 - 732 k -> 768 - 775 k windows/s at B = 256 but 807 - 809 k -> 768 - 778 k at B = 1000; pileup
     // 4.24 M -> 4.32 - 4.33 M at B = 1024): more than one lane, for batches that do not fill the chip by themselves
@@ -116,6 +120,7 @@ c3_model *c3_model_create(int kind, int in_channels, int add_indel_length, int d
     if (const char *e = getenv("C3HIP_TAIL_STREAM")) m->tail_split = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LANE_SHARING")) m->lane_sharing_ok = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_LANE_ORDER")) m->lane_by_slot = strcmp(e, "slot") == 0;
+    if (const char *e = getenv("C3HIP_LANE_H2D")) m->lane_h2d = atoi(e) != 0;
     if (const char *e = getenv("C3HIP_HOST_COPY_KERNEL")) m->host_copy_kernel = atoi(e);
     {
         hipDeviceProp_t prop;
