@@ -275,9 +275,14 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
     // 750 instead of 128 + 256 + 616: 0.79 -> 0.82 of device-resident; a tail shorter than half the next size joins the last piece
     int64_t next = std::min<int64_t>(std::max<int64_t>(chunk / 2, batch / 4), chunk);
     next = std::max<int64_t>(next, 1);
-    // (Round 6 also tried EQUAL pieces that each take a lane of their own -- three of 334 windows instead of 250 + 750 for the reference's batch of
-    // 1000: 668 - 674 k -> 644 - 646 k windows/s, profiles/r06_i_ab_ring_lanes.txt: the call's one thread stages the pieces one after the other, so
-    // a bigger first piece only starts the kernels later.  Not kept.)
+    // A batch that fits the ring's lanes as EQUAL pieces -- one lane-sized piece per lane: 334 + 333 + 333 full-alignment windows for the
+    // reference's batch of 1000 -- is cut that way: every piece brings its windows in on its own lane's stream and runs beside the others
+    // (profiles/r06_o_*: 656 - 667 k -> 700 - 721 k windows/s same-box; with the lanes' first form -- up to three streams each -- the same cut
+    // LOST 4 %, profiles/r06_i_ab_ring_lanes.txt).  C3HIP_PREDICT_EQUAL=0: the growing pieces below for every batch.
+    static const bool equal_ok = !(getenv("C3HIP_PREDICT_EQUAL") && atoi(getenv("C3HIP_PREDICT_EQUAL")) == 0);
+    const bool lanes_on = m->ring_lanes > 1 && !m->keep && m->duo == 0 && !m->prof;
+    const int64_t equal = (equal_ok && lanes_on && m->kind == C3_KIND_FULL_ALIGNMENT && batch <= (int64_t)m->ring_lanes * m->lane_max_batch)
+                              ? (batch + m->ring_lanes - 1) / m->ring_lanes : 0;
     // C3HIP_PREDICT_PIECES=a,b,c: A/B knob -- the piece sizes themselves (the last one repeats)
     static const std::vector<int64_t> forced = [] {
         std::vector<int64_t> v;
@@ -294,6 +299,7 @@ int c3_predict(c3_model *m, const void *x_host, int x_dtype, int64_t batch, floa
     for (int64_t off = 0; off < batch && rc == 0; ++n_sub) {
         int64_t take = std::min(next, batch - off);
         if (batch - off - take < next / 2 || batch - off - take < chunk / 2) take = batch - off;
+        if (equal > 0) take = std::min(equal, batch - off);
         if (!forced.empty()) take = std::min<int64_t>(forced[std::min<size_t>((size_t)n_sub, forced.size() - 1)], batch - off);
         take = std::min(take, max_microbatch(m));
         if (n_sub - n_done == kRing) rc = c3_predict_wait(m, (int)(n_done++ % kRing));
