@@ -171,8 +171,8 @@ def test_async_submit_wait_and_device_paths_agree():
     assert yd.is_cuda and np.array_equal(yd.cpu().numpy(), ya)
 
 
-@pytest.mark.parametrize("kind", [syn.FULL_ALIGNMENT, syn.PILEUP])
-def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
+@pytest.mark.parametrize("kind,lane_h2d", [(syn.FULL_ALIGNMENT, "1"), (syn.PILEUP, "1"), (syn.FULL_ALIGNMENT, "0")])
+def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, lane_h2d, monkeypatch):
     """Round 6: a batch of the submit / wait ring runs its FC chain (L4, the split-K sum, the tail, the decoder columns, the copy-out) on
     the handle's tail stream, so that the NEXT batch's first layers are queued behind this batch's last layer, not behind three small
     launches they do not depend on; the next batch waits for the chain only before it overwrites what the chain reads (the pooled tensor /
@@ -192,6 +192,10 @@ def test_the_fc_chain_of_a_ring_batch_on_its_own_stream(kind, monkeypatch):
     monkeypatch.setenv("C3HIP_TAIL_STREAM", "1")  # (the default for full alignment; off by default for the pileup network, where it measured a loss)
     monkeypatch.setenv("C3HIP_RING_LANES", "3")   # the batch in slot k in lane k % 3: consecutive batches overlap on the chip
     monkeypatch.setenv("C3HIP_RING_LANES_MAX_BATCH", "100000")  # (by default only batches that leave the chip under-filled: here every size)
+    # (the end of round 6 made both of these knobs: by default a lane batch is ONE stream -- no tail stream, its staged windows on the lane's own
+    # stream -- because of the runtime's four hardware queues; "0": the windows on the transfer stream, an event in between)
+    monkeypatch.setenv("C3HIP_LANE_H2D", lane_h2d)
+    monkeypatch.setenv("C3HIP_LAZY_H2D_STREAM", lane_h2d)
     m = make_model(kind, ch, indel, sd)
     assert "ring_lanes=1" in m0.describe() and "tail_stream=0" in m0.describe()
     assert "ring_lanes=3 lane_max_batch=100000 tail_stream=1" in m.describe(), m.describe()
