@@ -29,7 +29,7 @@ class RowsConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("flank", C.c_int32), ("show_reference", C.c_int32), ("keep_iupac", C.c_int32),
                 ("has_qs_pass", C.c_int32), ("pileup", C.c_int32), ("max_len", C.c_int32), ("infer", C.c_int32),
                 ("f32_arith", C.c_int32), ("walk", C.c_int32), ("gvcf", C.c_int32), ("haploid", C.c_int32),
-                ("qs_pass", C.c_double), ("phred_trans", C.c_double),
+                ("long_indel", C.c_int32), ("long_infer", C.c_int32), ("qs_pass", C.c_double), ("phred_trans", C.c_double), ("long_prop", C.c_double),
                 ("gt", (C.c_char * 8) * 4)]
 
 

@@ -538,6 +538,20 @@ static bool row_text(const c3_rows_config &cf, const Row &r, int cls, std::strin
             if (dk[i].n == len) return dc[i];
         return 0;
     };
+    // --enable_long_indel: the reads of the OTHER insertion alleles whose length lies within long_prop of a long proposed allele's count with
+    // it (get_long_indel_read_count, :383-402; lengths include the reference base, the proposal's own does not: :393).  The reference calls
+    // the same function for deletions WITHOUT is_del (:1273-1275, :1282-1283, :1294-1297, :1313-1315): the proposal's length is then
+    // len("") - 1, the window [50, -1.1] holds nothing, and a deletion's count stays what it is -- restated as it runs, not as it reads.
+    auto long_ins = [&](const char *p, int n) -> long long {
+        if (!cf.long_indel || !(n > cf.long_infer)) return 0;
+        const double len = (double)(n - 1);
+        const double lo = std::max(len * (1.0 - cf.long_prop), (double)cf.long_infer), hi = len * (1.0 + cf.long_prop);
+        const Str s{p, n};
+        long long sum = 0;
+        for (int i = 0; i < ni; ++i)
+            if (!ik[i].eq(s) && (double)ik[i].n >= lo && (double)ik[i].n <= hi) sum += ic[i];
+        return sum;
+    };
     long long supported = 0, counts[8];
     int nc = 0;
     // alt.split(","): the pieces
@@ -565,7 +579,7 @@ static bool row_text(const c3_rows_config &cf, const Row &r, int cls, std::strin
     } else if (cls == 3 || cls == 6) {
         for (int k = 0; k < ncut; ++k) {
             piece(k, &pp, &pn);
-            const long long n = ins_of(pp, pn);
+            const long long n = ins_of(pp, pn) + long_ins(pp, pn);
             supported += n, counts[nc++] = n;
         }
     } else if (cls == 5) {
@@ -578,13 +592,14 @@ static bool row_text(const c3_rows_config &cf, const Row &r, int cls, std::strin
         } else {
             piece(0, &pp, &pn);
         }
-        const long long n_ins = ins_of(pp, pn);
+        const long long n_ins = ins_of(pp, pn) + long_ins(pp, pn);
         supported = n_ins + n_snp;
         if (multi) counts[nc++] = n_snp;
         counts[nc++] = n_ins;
     } else if (cls == 4 || cls == 8) {
         if (nd > 0) {
             if (cls == 4) {
+                if (cf.long_indel && ref.size() <= 1) return false;  // (len(None): the reference raises)
                 supported = ref.size() > 1 ? del_of(ref.data() + 1, (int)ref.size() - 1) : 0;
                 counts[nc++] = supported;
             } else if (nd > 1) {
@@ -603,6 +618,7 @@ static bool row_text(const c3_rows_config &cf, const Row &r, int cls, std::strin
             if (pn < 1) return false;
             has_base = true, n_snp = has_snp[(int)pp[0]] ? snp[(int)pp[0]] : 0;
         }
+        if (cf.long_indel && ref.size() <= 1) return false;  // (len(None): the reference raises)
         const long long n_del = ref.size() > 1 ? del_of(ref.data() + 1, (int)ref.size() - 1) : 0;
         supported = n_del + n_snp;
         if (has_base) counts[nc++] = n_snp;
@@ -612,7 +628,10 @@ static bool row_text(const c3_rows_config &cf, const Row &r, int cls, std::strin
             piece(k, &pp, &pn);
             const int n_del = (int)ref.size() - pn;
             long long n;
-            if (n_del < 0) n = ref.size() > 1 ? ins_of(pp, pn - ((int)ref.size() - 1)) : ins_of(pp, pn);
+            if (n_del < 0) {
+                const int in = ref.size() > 1 ? pn - ((int)ref.size() - 1) : pn;
+                n = ins_of(pp, in) + long_ins(pp, in);
+            }
             else n = del_of_len(n_del);
             counts[nc++] = n, supported += n;
         }

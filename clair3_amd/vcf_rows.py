@@ -152,7 +152,7 @@ class RowPrinter:
     def __init__(self, cv, output_config):
         c = output_config
         self.cv, self.cfg = cv, c
-        self.usable = not (c.is_debug or c.enable_long_indel or c.is_output_for_ensemble or c.input_probabilities)
+        self.usable = not (c.is_debug or c.is_output_for_ensemble or c.input_probabilities)
         self.width = 90 if c.add_indel_length else 24
         self.flank = cv.param.flankingBaseNum
         G = cv.Genotype
@@ -205,6 +205,12 @@ class RowPrinter:
                 return None
         cf.gvcf = int(bool(c.gvcf))
         cf.haploid = int(bool(c.is_haploid_precise_mode_enabled)) | (int(bool(c.is_haploid_sensitive_mode_enabled)) << 1)
+        if c.enable_long_indel:  # get_long_indel_read_count reads three constants of the module's param at call time (:390-395)
+            prm = cv.param
+            if not (isinstance(prm.maximum_variant_length_that_need_infer, int) and isinstance(prm.long_indel_distance_proportion, float)):
+                return None
+            cf.long_indel = int(not prm.cal_precise_long_indel_af)
+            cf.long_infer, cf.long_prop = int(prm.maximum_variant_length_that_need_infer), float(prm.long_indel_distance_proportion)
         for k, g in enumerate(self.gt + [self.gt_multi]):
             cf.gt[k].value = g.encode()
         self._lib = L
@@ -412,6 +418,10 @@ class RowPrinter:
                 ref_count = n
         ref_count = max(0, ref_count)
         supported, counts = 0, []
+        # --enable_long_indel: the reads of alleles within 10 % of a long allele's length are counted with it (get_long_indel_read_count,
+        # :383-402 -- the reference's own function; as the reference calls it, i.e. for a deletion WITHOUT is_del, where it finds nothing)
+        long_ins = (lambda bases: cv.get_long_indel_read_count(alt_info=insd, proposed_ins_base=bases, is_del=False)) if c.enable_long_indel else (lambda bases: 0)
+        long_del = (lambda n: cv.get_long_indel_read_count(alt_info=deld, propose_del_base_length=n)) if c.enable_long_indel else (lambda n: 0)
         if is_ref:  # :1236-1238
             supported, alt = ref_count, "."
         elif cls <= 2:  # SNPs (:1240-1246)
@@ -423,14 +433,14 @@ class RowPrinter:
                 counts.append(n)
         elif cls == 3 or cls == 6:  # insertions (:1247-1255)
             for bases in alt.split(","):
-                n = insd[bases] if bases in insd else 0
+                n = (insd[bases] if bases in insd else 0) + long_ins(bases)
                 supported += n
                 counts.append(n)
         elif cls == 5:  # SNP + insertion (:1256-1270)
             snp_base = alt.split(",")[0][0] if multi else None
             bases = alt.split(",")[1] if multi else alt
             n_snp = (snp[snp_base] if snp_base in snp else 0) if multi else 0
-            n_ins = insd[bases] if bases in insd else 0
+            n_ins = (insd[bases] if bases in insd else 0) + long_ins(bases)
             supported = n_ins + n_snp
             if snp_base:
                 counts.append(n_snp)
@@ -439,13 +449,13 @@ class RowPrinter:
             if len(deld) > 0:
                 if cls == 4:
                     bases = ref[1:] if len(ref) > 1 else None
-                    supported = deld[bases] if bases in deld else 0
+                    supported = (deld[bases] if bases in deld else 0) + (long_del(len(bases)) if c.enable_long_indel else 0)
                     counts.append(supported)
                 elif len(deld) > 1:
                     for bases in alt.split(","):
                         n_del = len(ref) - len(bases)
                         hit = [deld[k] for k in deld if len(k) == n_del]
-                        n = hit[0] if len(hit) > 0 else 0
+                        n = (hit[0] if len(hit) > 0 else 0) + long_del(n_del)
                         counts.append(n)
                         supported += n
         elif cls == 7:  # SNP + deletion (:1289-1305)
@@ -453,7 +463,7 @@ class RowPrinter:
             snp_base = (alts[1][0] if len(alts) > 1 else None) if multi else None
             n_snp = (snp[snp_base] if snp_base in snp else 0) if multi else 0
             bases = ref[1:] if len(ref) > 1 else None
-            n_del = deld[bases] if bases in deld else 0
+            n_del = (deld[bases] if bases in deld else 0) + (long_del(len(bases)) if c.enable_long_indel else 0)
             supported = n_del + n_snp
             if snp_base:
                 counts.append(n_snp)
@@ -463,10 +473,10 @@ class RowPrinter:
                 n_del = len(ref) - len(bases)
                 if n_del < 0:
                     ibases = bases[:-(len(ref) - 1)] if len(ref) > 1 else bases
-                    n = insd[ibases] if ibases in insd else 0
+                    n = (insd[ibases] if ibases in insd else 0) + long_ins(ibases)
                 else:
                     hit = [deld[k] for k in deld if len(k) == n_del]
-                    n = hit[0] if len(hit) > 0 else 0
+                    n = (hit[0] if len(hit) > 0 else 0) + long_del(n_del)
                 counts.append(n)
                 supported += n
         af = ((supported + 0.0) / depth) if depth != 0 else 0.0  # :1324-1326

@@ -200,7 +200,10 @@ typedef struct {
     int32_t width, flank, show_reference, keep_iupac, has_qs_pass, pileup, max_len, infer, f32_arith, walk;
     int32_t gvcf, haploid;  /* gvcf: rows carry the PL field (output_config.gvcf, clair3/CallVariants.py:1360-1378, compute_PL :1397-1454);
                              * haploid: bit 0 is_haploid_precise_mode_enabled, bit 1 is_haploid_sensitive_mode_enabled (:1191-1199, :1327-1329) */
-    double qs_pass, phred_trans;
+    int32_t long_indel, long_infer;  /* --enable_long_indel (and not param.cal_precise_long_indel_af): the reads of insertion alleles within long_prop of a
+                                      * long allele's length count with it (get_long_indel_read_count, clair3/CallVariants.py:383-402); long_infer =
+                                      * param.maximum_variant_length_that_need_infer (50), long_prop = param.long_indel_distance_proportion (0.1) */
+    double qs_pass, phred_trans, long_prop;
     char gt[4][8];
 } c3_rows_config;
 int c3_vcf_rows(const c3_rows_config *cfg, int64_t n, const char *pos_text, int64_t pos_bytes, const char *alt_text, int64_t alt_bytes,

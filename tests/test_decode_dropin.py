@@ -211,7 +211,7 @@ def test_rows_with_a_story_print_the_reference_s_text(indel, noise, ref):
 def test_output_modes_and_odd_inputs(indel, ref):
     """the switches of OutputConfig and the input forms output_with accepts (clair3/CallVariants.py:1127-1154): bytes and
     numpy.bytes_ strings, contig names with colons, IUPAC and lower-case bases, depth 0, a QUAL threshold, no reference rows,
-    kept IUPAC bases, gVCF rows (the PL field) and the two haploid modes (round 6); the modes the row printer leaves to the reference (long indels, ensemble output) go through it unchanged"""
+    kept IUPAC bases, gVCF rows (the PL field) and the two haploid modes (round 6); --enable_long_indel (round 6); the mode the row printer leaves to the reference (ensemble output) goes through it unchanged"""
     from tests.decode_rows import consistent_rows
     cv, unpatched = ref
     pos, alt, y, classes = consistent_rows(400, seed=19, indel=indel, noise=0.2)
@@ -237,13 +237,14 @@ def test_output_modes_and_odd_inputs(indel, ref):
                     {"gvcf": True}, {"gvcf": True, "keep_iupac_bases": True, "is_show_reference": False},
                     {"is_haploid_precise_mode_enabled": True}, {"is_haploid_sensitive_mode_enabled": True},
                     {"is_haploid_precise_mode_enabled": True, "is_haploid_sensitive_mode_enabled": True, "gvcf": True},
-                    {"enable_long_indel": True}, {"is_output_for_ensemble": True}):
+                    {"enable_long_indel": True}, {"enable_long_indel": True, "maximum_variant_length_that_need_infer": 100000, "gvcf": True},
+                    {"is_output_for_ensemble": True}):
         cfg = config(cv, not indel, indel, **changes)
         want = unpatched(pos, alt, y, cfg, None)
         got = cv.batch_output(pos, alt, yw, cfg, None)
         assert got == want, changes
         pr = cv._c3hip_row_printers[(cfg, id(cv.param))]
-        assert pr.usable == (not (changes.get("enable_long_indel") or changes.get("is_output_for_ensemble")))
+        assert pr.usable == (not changes.get("is_output_for_ensemble"))
         if any(k.startswith("is_haploid") for k in changes):
             gts = {r.split("\t")[9].split(":")[0] for r in got.splitlines()}
             assert gts and gts <= {"0", "1"}, gts

@@ -201,14 +201,16 @@ def test_decoder_columns_through_the_reference_loop(name, ref, jobs):
 
 
 @pytest.mark.parametrize("name,flags", [("full_alignment", ["--gvcf", "True"]), ("pileup", ["--gvcf", "True"]),
-                                        ("pileup", ["--haploid_sensitive", "--gvcf", "True", "--qual", "8"]), ("full_alignment", ["--haploid_precise"])])
+                                        ("pileup", ["--haploid_sensitive", "--gvcf", "True", "--qual", "8"]), ("full_alignment", ["--haploid_precise"]),
+                                        ("full_alignment", ["--enable_long_indel", "True"])])
 def test_gvcf_and_haploid_rows_through_the_worker_command(name, flags, ref, jobs):
-    """--gvcf True (rows carry the PL field, clair3/CallVariants.py:1360-1378) and the haploid modes (:1191-1199, :1327-1329): the worker
+    """--gvcf True (rows carry the PL field, clair3/CallVariants.py:1360-1378), the haploid modes (:1191-1199, :1327-1329) and --enable_long_indel
+    (lookups up to 100 000 bases, get_long_indel_read_count :383-402): the worker
     command on libc3hip with the decoder columns -- c3_vcf_rows restates compute_PL (:1397-1454) from the row's own probabilities and the
     haploid rules -- against the same command on the reference's modules"""
     kind, channels, indel, pileup, dwell, sizes = CASES[name]
     job = dict(jobs(name))
-    tag = "hip" + "".join(f.strip("-").replace("haploid_", "_h").replace("True", "") for f in flags if not f.isdigit())
+    tag = "hip" + "".join(f.strip("-").replace("haploid_", "_h").replace("enable_long_indel", "_longindel").replace("True", "") for f in flags if not f.isdigit())
     want, got = os.path.join(job["dir"], f"reference_cpu_{tag}.vcf"), os.path.join(job["dir"], f"{tag}.vcf")
     rc, out = refloop.run_worker(ref, job["lst"], job["ck"], want, pileup, indel, hip=False, extra_args=flags)
     assert rc == 0 and f"Total processed positions : {sum(sizes)}" in out, out[-3000:]

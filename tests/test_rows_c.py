@@ -60,6 +60,10 @@ def _random_alt_info(rng, ref_base):
         else:
             key = kind + ref_base
         parts.append(f"{key} {count()}")
+        if kind == "I" and len(key) > 45 and rng.random() < 0.7:  # neighbours of a long insertion: other alleles within ~10 % of its length (--enable_long_indel)
+            for _ in range(int(rng.integers(1, 4))):
+                near = max(2, int((len(key) - 1) * (1 + rng.uniform(-0.14, 0.14))))
+                parts.append(f"I{ref_base}{bases(near - 1)} {count()}")
         if rng.random() < 0.08:
             parts.append(f"{key} {count()}")  # the same key again: the last count wins, the key keeps its place
     return f"{depth}-" + " ".join(parts) + (" " if rng.random() < 0.7 else "")
@@ -98,7 +102,9 @@ def _asked_rows(rng, n, indel, cv):
 @pytest.mark.parametrize("indel", [True, False])
 @pytest.mark.parametrize("changes", [{}, {"quality_score_for_pass": 12}, {"is_show_reference": False, "keep_iupac_bases": True}, {"gvcf": True},
                                      {"gvcf": True, "keep_iupac_bases": True, "quality_score_for_pass": 8}, {"is_haploid_precise_mode_enabled": True},
-                                     {"is_haploid_sensitive_mode_enabled": True, "gvcf": True}])
+                                     {"is_haploid_sensitive_mode_enabled": True, "gvcf": True},
+                                     {"enable_long_indel": True, "maximum_variant_length_that_need_infer": 100000},
+                                     {"enable_long_indel": True, "maximum_variant_length_that_need_infer": 100000, "gvcf": True, "quality_score_for_pass": 5}])
 def test_every_class_and_entry_against_the_python_path(indel, changes, ref):
     """rows that ask for every class / entry over random alt_info dictionaries: wherever the C pass prints a row (or says the reference
     prints nothing), the per-row Python path -- the reference's own lookup functions -- gives the same text"""
